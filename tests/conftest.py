@@ -1,0 +1,40 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def stage_names():
+    return sorted(p.stem[len("stage_"):] for p in GOLD.glob("stage_*.npz"))
+
+
+def load_stage(name):
+    z = np.load(GOLD / f"stage_{name}.npz", allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["sep"] = str(d["sep"])
+    d["max_dist"] = int(d["max_dist"])
+    d["min_cluster_size"] = int(d["min_cluster_size"])
+    d["features"] = [str(x) for x in d["features"]]
+    d["ufeatures"] = [str(x) for x in d["ufeatures"]]
+    d["clusters_tsv"] = d["clusters_tsv"].tobytes()
+    return d
+
+
+@pytest.fixture(scope="session")
+def kats():
+    return json.loads((GOLD / "kats.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def cli_runs():
+    return json.loads((GOLD / "cli_runs.json").read_text())
