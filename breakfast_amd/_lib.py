@@ -1,0 +1,215 @@
+"""ctypes binding of libbfk.so (include/bfk.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in the product path."""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libbfk.so"
+_lib = None
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class BfkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbfk error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("nnz", C.c_int64), ("pairs_resolved", C.c_int64), ("pairs_in_band", C.c_int64),
+        ("pairs_filtered", C.c_int64), ("n_candidates", C.c_int64), ("n_edges", C.c_int64), ("n_inline", C.c_int64),
+        ("max_row_len", C.c_int32), ("sig_words", C.c_int32), ("n_work_items", C.c_int32), ("profiled", C.c_int32),
+        ("ms_prep", C.c_float), ("ms_prefilter", C.c_float), ("ms_verify", C.c_float), ("ms_flatten", C.c_float),
+        ("ms_total", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+EXPORTS = {
+    "bfk_abi_version": (C.c_int, []),
+    "bfk_device_count": (C.c_int, []),
+    "bfk_last_error": (C.c_char_p, []),
+    "bfk_free": (None, [C.c_void_p]),
+    "bfk_build_csr": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, C.POINTER(c_i32p),
+                                c_i64p, c_i32p]),
+    "bfk_cluster_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_i32p, C.POINTER(Stats)]),
+    "bfk_neighbours_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, C.POINTER(c_i64p),
+                                     C.POINTER(c_i32p)]),
+    "bfk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "bfk_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "bfk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bfk_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bfk_ctx_upload_csr": (C.c_int, [C.c_void_p, c_i32p, c_i32p, C.c_int64]),
+    "bfk_ctx_bind_csr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "bfk_ctx_cluster": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "bfk_ctx_merge_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bfk_ctx_sync": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "bfk_ctx_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "bfk_ctx_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "bfk_ctx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bfk_ctx_set_edge_capture": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bfk_ctx_edges": (C.c_int, [C.c_void_p, C.POINTER(c_i32p), c_i64p]),
+}
+
+
+def load():
+    """Load libbfk.so once.  Raises if it was not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP library must be built first "
+                "(make -C breakfast_amd/csrc, or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.bfk_abi_version() != 1:
+            raise RuntimeError("libbfk ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BfkError(rc, load().bfk_last_error().decode(errors="replace"))
+
+
+def _p32(a):
+    return a.ctypes.data_as(c_i32p)
+
+
+def _p64(a):
+    return a.ctypes.data_as(c_i64p)
+
+
+def build_csr(features, sep: str):
+    """bfk_build_csr on a sequence of str (floats/NaN count as empty rows, breakfast.py:200-201).
+    -> (indptr int32[N+1], indices int32[nnz], n_vocab)"""
+    lib = load()
+    rows = [b"" if isinstance(f, float) else f.encode() for f in features]
+    n = len(rows)
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum(np.fromiter((len(r) for r in rows), dtype=np.int64, count=n), out=off[1:])
+    buf = b"".join(rows)
+    sepb = sep.encode()
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    out = c_i32p()
+    nnz = C.c_int64()
+    nv = C.c_int32()
+    rc = lib.bfk_build_csr(buf, _p64(off), n, sepb, len(sepb), _p32(indptr), C.byref(out), C.byref(nnz), C.byref(nv))
+    if rc == -1 and len(sepb) == 0:
+        raise ValueError("empty separator")
+    _check(rc)
+    indices = np.ctypeslib.as_array(out, shape=(max(nnz.value, 1),))[: nnz.value].copy()
+    lib.bfk_free(out)
+    return indptr, indices, int(nv.value)
+
+
+def cluster_csr(indptr, indices, max_dist: int):
+    """bfk_cluster_csr -> (labels int32[N] = min row index of the component, stats dict)"""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n = len(indptr) - 1
+    labels = np.empty(max(n, 1), dtype=np.int32)
+    st = Stats()
+    _check(lib.bfk_cluster_csr(_p32(indptr), _p32(indices), n, int(max_dist), 1, _p32(labels), C.byref(st)))
+    return labels[:n], st.as_dict()
+
+
+def neighbours_csr(indptr, indices, max_dist: int, select_ind=None):
+    """bfk_neighbours_csr -> (nbr_indptr int64[Q+1], nbr_indices int32[...]) ascending lists incl. self"""
+    lib = load()
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n = len(indptr) - 1
+    sel = None if select_ind is None else np.ascontiguousarray(select_ind, dtype=np.int64)
+    op, oi = c_i64p(), c_i32p()
+    _check(lib.bfk_neighbours_csr(_p32(indptr), _p32(indices), n, int(max_dist), None if sel is None else _p64(sel),
+                                  0 if sel is None else len(sel), C.byref(op), C.byref(oi)))
+    nq = n if sel is None else len(sel)
+    nbr_indptr = np.ctypeslib.as_array(op, shape=(nq + 1,)).copy()
+    tot = int(nbr_indptr[-1])
+    nbr_indices = np.ctypeslib.as_array(oi, shape=(max(tot, 1),))[:tot].copy()
+    lib.bfk_free(op)
+    lib.bfk_free(oi)
+    return nbr_indptr, nbr_indices
+
+
+class Context:
+    """Resident-context API (bfk_ctx_*): CSR and labels live in HBM, launches go to a HIP stream."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        _check(self.lib.bfk_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.n_rows = 0
+        self._owned = []
+
+    def close(self):
+        if self.h:
+            for p in self._owned:
+                self.lib.bfk_ctx_device_free(self.h, p)
+            self._owned = []
+            self.lib.bfk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _check(self.lib.bfk_ctx_set_stream(self.h, C.c_void_p(stream_handle or 0)))
+
+    def set_profiling(self, on=True):
+        _check(self.lib.bfk_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def upload_csr(self, indptr, indices):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.n_rows = len(indptr) - 1
+        _check(self.lib.bfk_ctx_upload_csr(self.h, _p32(indptr), _p32(indices), self.n_rows))
+
+    def bind_csr_device(self, d_indptr: int, d_indices: int, n_rows: int):
+        self.n_rows = int(n_rows)
+        _check(self.lib.bfk_ctx_bind_csr_device(self.h, C.c_void_p(d_indptr), C.c_void_p(d_indices), self.n_rows))
+
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _check(self.lib.bfk_ctx_device_alloc(self.h, int(nbytes), C.byref(p)))
+        self._owned.append(p)
+        return p.value
+
+    def cluster(self, max_dist: int, d_labels: int, shard: int = 0, n_shards: int = 1):
+        _check(self.lib.bfk_ctx_cluster(self.h, int(max_dist), int(shard), int(n_shards), C.c_void_p(d_labels)))
+
+    def merge_labels(self, d_gathered: int, n_parts: int, d_labels: int, d_changed: int = 0):
+        _check(self.lib.bfk_ctx_merge_labels(self.h, C.c_void_p(d_gathered), int(n_parts), C.c_void_p(d_labels),
+                                             C.c_void_p(d_changed or 0)))
+
+    def sync(self) -> dict:
+        st = Stats()
+        _check(self.lib.bfk_ctx_sync(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def download_i32(self, d_ptr: int, n: int) -> np.ndarray:
+        out = np.empty(max(n, 1), dtype=np.int32)
+        _check(self.lib.bfk_ctx_download(self.h, C.c_void_p(d_ptr), out.ctypes.data_as(C.c_void_p), int(n) * 4))
+        return out[:n]

@@ -1,0 +1,62 @@
+// bfk_device.h — shared between bfk_kernels.hip (device code + launchers) and bfk_host.cpp (C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bfk {
+
+constexpr int HIST_LDS_BINS = 2048;    // row lengths below this are histogrammed in LDS
+constexpr int SIG2_WORDS = 4;          // second-level signature: 128 bits
+constexpr int CAND_SHARDS = 8;         // candidate queue shards (block % 8 ~ XCD)
+constexpr int PF_LDS_QUEUE = 1024;     // per-block LDS candidate queue entries (8 KiB)
+constexpr int VERIFY_LDS_ROW = 512;    // tokens of row B staged per wave in k_verify (2 KiB/wave)
+constexpr int PF_ROWS_W1 = 4;          // rows per thread in k_prefilter by signature width
+constexpr int PF_ROWS_W2 = 4;
+constexpr int PF_ROWS_W4 = 2;
+constexpr int PF_TC = 512;             // columns per work item
+constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
+constexpr int LONG_LDS_CAP = 15360;    // tokens of a long row staged in LDS by k_canon_long (60 KiB)
+
+enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
+
+struct Counters {
+    unsigned int ncand[CAND_SHARDS];
+    int err;
+    unsigned int n_work;
+    unsigned int n_long;
+    unsigned int pad0;
+    unsigned long long pairs_in_band;
+    unsigned long long pairs_filtered;
+    unsigned long long n_cand_total;
+    unsigned long long n_edges;
+    unsigned long long n_edges_inline;
+    unsigned long long n_inline;
+    unsigned long long n_edges_cap;
+};
+
+// Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
+struct Plan {
+    int n, kcap, d, w1;
+    int tr, tc;
+    int shard, n_shards;
+    int pf_grid, verify_grid;
+    int work_cap, cand_cap_shard, edge_cap, long_lds_cap;
+    const int *indptr;
+    const uint32_t *indices;
+    uint32_t *cols;
+    int *hist, *start, *cursor;
+    int *perm, *pos, *ksorted, *parent, *longrows;
+    uint32_t *sig1, *sig2;
+    int4 *work;
+    int2 *cand;
+    int2 *edges;  // NULL unless edge capture is on
+    int *labels;
+    Counters *ctr;
+};
+
+int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
+int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
+int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
+                 hipStream_t st);
+
+}  // namespace bfk

@@ -1,0 +1,625 @@
+// bfk_host.cpp — the C-ABI of libbfk.so (include/bfk.h): context / workspace management around the
+// HIP pipeline in bfk_kernels.hip, plus the host-side tokeniser + vocabulary (bfk_build_csr).
+// There is no CPU compute fallback in this library: without a gfx950 device every compute entry
+// point returns BFK_ENODEV.
+#include "../../include/bfk.h"
+#include "bfk_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace bfk;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(BFK_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+extern "C" int bfk_abi_version(void) { return BFK_ABI_VERSION; }
+extern "C" const char *bfk_last_error(void) { return g_err.c_str(); }
+extern "C" void bfk_free(void *p) { free(p); }
+
+extern "C" int bfk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) ok++;
+    }
+    return ok;
+}
+
+// ================================================================================================
+// a1: tokeniser + first-appearance vocabulary (replaces sparse_feature_matrix, breakfast.py:193-215)
+// ================================================================================================
+namespace {
+struct Slot {
+    const char *p;
+    uint32_t len;
+    int32_t id;
+};
+
+inline uint64_t tok_hash(const char *p, size_t n) {
+    // 8 bytes at a time multiply-mix (tokens are ~6-12 bytes: "C14408T", "del:11288:9")
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        h = (h ^ v) * 0xC4CEB9FE1A85EC53ull;
+        h ^= h >> 29;
+        p += 8;
+        n -= 8;
+    }
+    uint64_t v = 0;
+    memcpy(&v, p, n);
+    h = (h ^ v) * 0xC4CEB9FE1A85EC53ull;
+    return h ^ (h >> 32);
+}
+}  // namespace
+
+extern "C" int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                             int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off || !indptr_out || !indices_out || !nnz_out || !n_vocab_out || n_rows < 0 || (!buf && n_rows > 0 && row_off[n_rows] > 0))
+        return fail(BFK_EARG, "bfk_build_csr: null argument");
+    if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
+    size_t tcap = 1u << 16, tcount = 0;
+    std::vector<Slot> tab(tcap, Slot{nullptr, 0, 0});
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)std::max<int64_t>(1024, row_off[n_rows] / 6));
+    const char s0 = sep[0];
+    indptr_out[0] = 0;
+    for (int64_t r = 0; r < n_rows; r++) {
+        const char *s = buf + row_off[r];
+        const int64_t n = row_off[r + 1] - row_off[r];
+        if (n < 0) return fail(BFK_EARG, "bfk_build_csr: row_off not monotone");
+        int64_t pos = 0;
+        while (pos <= n) {
+            int64_t nx = -1;  // next separator at or after pos
+            if (sep_len == 1) {
+                const void *f = pos < n ? memchr(s + pos, s0, (size_t)(n - pos)) : nullptr;
+                if (f) nx = (const char *)f - s;
+            } else {
+                for (int64_t i = pos; i + sep_len <= n; i++)
+                    if (s[i] == s0 && memcmp(s + i, sep, (size_t)sep_len) == 0) {
+                        nx = i;
+                        break;
+                    }
+            }
+            const int64_t tl = (nx < 0 ? n : nx) - pos;
+            if (tl > 0) {
+                const char *t = s + pos;
+                size_t i = tok_hash(t, (size_t)tl) & (tcap - 1);
+                while (tab[i].p && !(tab[i].len == (uint32_t)tl && memcmp(tab[i].p, t, (size_t)tl) == 0))
+                    i = (i + 1) & (tcap - 1);
+                if (!tab[i].p) {
+                    tab[i] = Slot{t, (uint32_t)tl, (int32_t)tcount++};
+                    idx.push_back(tab[i].id);
+                    if (tcount * 2 > tcap) {
+                        std::vector<Slot> nt(tcap * 2, Slot{nullptr, 0, 0});
+                        for (const Slot &sl : tab)
+                            if (sl.p) {
+                                size_t j = tok_hash(sl.p, sl.len) & (tcap * 2 - 1);
+                                while (nt[j].p) j = (j + 1) & (tcap * 2 - 1);
+                                nt[j] = sl;
+                            }
+                        tab.swap(nt);
+                        tcap *= 2;
+                    }
+                } else {
+                    idx.push_back(tab[i].id);
+                }
+            }
+            if (nx < 0) break;
+            pos = nx + sep_len;
+        }
+        if (idx.size() > (size_t)INT32_MAX) return fail(BFK_EARG, "bfk_build_csr: more than 2^31-1 entries");
+        indptr_out[r + 1] = (int32_t)idx.size();
+    }
+    int32_t *out = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, idx.size()));
+    if (!out) return fail(BFK_ENOMEM, "bfk_build_csr: out of memory");
+    if (!idx.empty()) memcpy(out, idx.data(), sizeof(int32_t) * idx.size());
+    *indices_out = out;
+    *nnz_out = (int64_t)idx.size();
+    *n_vocab_out = (int32_t)tcount;
+    return BFK_OK;
+}
+
+// ================================================================================================
+// context
+// ================================================================================================
+struct bfk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    bool profiling = false, edge_capture = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // CSR
+    const int *d_indptr = nullptr;
+    const uint32_t *d_indices = nullptr;
+    int *own_indptr = nullptr;
+    uint32_t *own_indices = nullptr;
+    int64_t own_n_cap = 0, own_nnz_cap = 0;
+    int64_t n = -1, nnz = 0;
+    int kcap = 0;
+    // workspace
+    char *d_head = nullptr;  // Counters | hist[bins]
+    int64_t bins_cap = 0;
+    int *d_start = nullptr, *d_cursor = nullptr;
+    uint32_t *d_cols = nullptr;
+    int64_t cols_cap = 0;
+    int *d_perm = nullptr, *d_pos = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
+    uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr;
+    int64_t rows_cap = 0;
+    int4 *d_work = nullptr;
+    int64_t work_cap = 0;
+    int2 *d_cand = nullptr;
+    int64_t cand_cap_total = 0, cand_cap_shard = 0;
+    int2 *d_edges = nullptr;
+    int64_t edge_cap = 0;
+    int *d_small = nullptr;  // 4 ints scratch (maxlen, err, ...)
+    // last run
+    bool ran = false;
+    int last_d = 0, last_w1 = 0, last_shards = 1;
+    bfk_stats stats{};
+};
+
+static int ctx_enter(bfk_ctx *c) {
+    if (!c) return fail(BFK_EARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    return BFK_OK;
+}
+
+template <typename T>
+static int dev_realloc(T **p, int64_t *cap, int64_t want, double slack = 1.0) {
+    if (want <= *cap && *p) return BFK_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    int64_t ncap = (int64_t)((double)want * slack) + 16;
+    hipError_t e = hipMalloc((void **)p, (size_t)ncap * sizeof(T));
+    if (e != hipSuccess) {
+        *cap = 0;
+        return fail(BFK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    *cap = ncap;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
+    if (!ctx_out) return fail(BFK_EARG, "null ctx_out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BFK_ENODEV, "no HIP device visible (libbfk has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(BFK_EARG, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(BFK_ENODEV, std::string("device is ") + prop.gcnArchName + ", libbfk is built for gfx950 only");
+    HIP_TRY(hipSetDevice(device));
+    bfk_ctx *c = new bfk_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(BFK_EHIP, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return fail(BFK_EHIP, "hipEventCreate failed");
+        }
+    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess) {
+        delete c;
+        return fail(BFK_ENOMEM, "hipMalloc failed");
+    }
+    *ctx_out = c;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
+    if (!c) return BFK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,    c->d_start, c->d_cursor, c->d_cols, c->d_perm,
+                    c->d_pos,      c->d_ksorted,   c->d_parent,  c->d_longrows, c->d_sig1, c->d_sig2, c->d_work,
+                    c->d_cand,     c->d_edges,     c->d_small};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_set_stream(bfk_ctx *c, void *hip_stream) {
+    if (int rc = ctx_enter(c)) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_set_profiling(bfk_ctx *c, int32_t enable) {
+    if (!c) return fail(BFK_EARG, "null ctx");
+    c->profiling = enable != 0;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_set_edge_capture(bfk_ctx *c, int32_t enable) {
+    if (!c) return fail(BFK_EARG, "null ctx");
+    c->edge_capture = enable != 0;
+    return BFK_OK;
+}
+
+static int64_t work_items_bound(int64_t n, int tr, int tc) {
+    int64_t T = (n + tr - 1) / tr;
+    return T * ((n + tc - 1) / tc + 2) + 16;
+}
+
+static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
+    const int64_t n = c->n, nnz = c->nnz;
+    const int64_t bins = (int64_t)c->kcap + 4 + std::max(d_hint, 64);
+    if (bins > c->bins_cap || !c->d_head) {
+        if (c->d_head) (void)hipFree(c->d_head);
+        if (c->d_start) (void)hipFree(c->d_start);
+        if (c->d_cursor) (void)hipFree(c->d_cursor);
+        c->d_head = nullptr;
+        c->d_start = c->d_cursor = nullptr;
+        c->bins_cap = 0;
+        size_t head = sizeof(Counters) + (size_t)bins * 4;
+        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins * 4) != hipSuccess ||
+            hipMalloc((void **)&c->d_cursor, (size_t)bins * 4) != hipSuccess)
+            return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
+        c->bins_cap = bins;
+    }
+    if (int rc = dev_realloc(&c->d_cols, &c->cols_cap, nnz + 1, 1.0)) return rc;
+    if (n + SIG_PAD_ROWS > c->rows_cap) {
+        int64_t cap = 0, want = n + SIG_PAD_ROWS;
+        int rc = 0;
+        cap = 0; rc |= dev_realloc(&c->d_perm, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_pos, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
+        cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
+        if (rc) return BFK_ENOMEM;
+        c->rows_cap = want;
+        // padded signature rows are read (never trusted): give them defined contents once
+        HIP_TRY(hipMemsetAsync(c->d_sig1, 0xFF, (size_t)(want * 4 + 16) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_sig2, 0xFF, (size_t)(want * SIG2_WORDS + 16) * 4, c->stream));
+    }
+    // all-pairs upper bound for the smallest row tile (R=2 -> 512 rows)
+    if (int rc = dev_realloc(&c->d_work, &c->work_cap, work_items_bound(n, 256 * PF_ROWS_W4, PF_TC))) return rc;
+    {
+        int64_t want = std::max<int64_t>(1 << 14, 4 * n + 4096);  // per shard; 8 shards -> 32 N pairs
+        if (int rc = dev_realloc(&c->d_cand, &c->cand_cap_total, want * CAND_SHARDS)) return rc;
+        c->cand_cap_shard = c->cand_cap_total / CAND_SHARDS;
+    }
+    return BFK_OK;
+}
+
+static int ctx_after_bind(bfk_ctx *c) {
+    // nnz and the longest row come back once per bind (set-up, not part of a timed step)
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+    int nnz32 = 0;
+    if (c->n > 0) {
+        if (int e = launch_maxlen(c->d_indptr, (int)c->n, c->d_small, c->stream))
+            return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
+        HIP_TRY(hipMemcpyAsync(h, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&nnz32, c->d_indptr + c->n, 4, hipMemcpyDeviceToHost, c->stream));
+        int first = 0;
+        HIP_TRY(hipMemcpyAsync(&first, c->d_indptr, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h[1] || first != 0 || nnz32 < 0) return fail(BFK_EARG, "malformed CSR: indptr must start at 0 and be non-decreasing");
+    }
+    c->nnz = nnz32;
+    c->kcap = h[0];
+    c->ran = false;
+    return ctx_size_workspace(c, 0);
+}
+
+extern "C" int bfk_ctx_bind_csr_device(bfk_ctx *c, const void *d_indptr, const void *d_indices, int64_t n_rows) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (n_rows < 0 || n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
+    if (n_rows > 0 && !d_indptr) return fail(BFK_EARG, "null indptr");
+    c->d_indptr = (const int *)d_indptr;
+    c->d_indices = (const uint32_t *)d_indices;
+    c->n = n_rows;
+    return ctx_after_bind(c);
+}
+
+extern "C" int bfk_ctx_upload_csr(bfk_ctx *c, const int32_t *indptr, const int32_t *indices, int64_t n_rows) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (n_rows < 0 || n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
+    if (!indptr) return fail(BFK_EARG, "null indptr");
+    const int64_t nnz = indptr[n_rows];
+    if (indptr[0] != 0 || nnz < 0 || (nnz > 0 && !indices)) return fail(BFK_EARG, "malformed CSR");
+    if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1)) return rc;
+    if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz + 1)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->own_indptr, indptr, (size_t)(n_rows + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) HIP_TRY(hipMemcpyAsync(c->own_indices, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->d_indptr = c->own_indptr;
+    c->d_indices = c->own_indices;
+    c->n = n_rows;
+    return ctx_after_bind(c);
+}
+
+static int sig_words_for(int d) { return d <= 2 ? 1 : (d <= 5 ? 2 : 4); }
+
+extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (c->n < 0) return fail(BFK_ESTATE, "bfk_ctx_cluster: no CSR bound");
+    if (max_dist < 0) return fail(BFK_EARG, "max_dist must be >= 0");
+    if (n_shards <= 0) n_shards = 1;
+    if (shard < 0 || shard >= n_shards) return fail(BFK_EARG, "shard out of range");
+    if (c->n > 0 && !d_labels_out) return fail(BFK_EARG, "null labels");
+    c->ran = true;
+    c->last_d = max_dist;
+    c->last_shards = n_shards;
+    c->last_w1 = sig_words_for(max_dist);
+    if (c->n == 0) return BFK_OK;
+    if ((int64_t)c->kcap + 4 + max_dist > c->bins_cap)
+        if (int rc = ctx_size_workspace(c, max_dist)) return rc;
+    if (c->edge_capture) {
+        if (int rc = dev_realloc(&c->d_edges, &c->edge_cap, c->cand_cap_shard * CAND_SHARDS)) return rc;
+    }
+    Plan pl{};
+    pl.n = (int)c->n;
+    pl.kcap = c->kcap;
+    pl.d = std::min<int>(max_dist, 1 << 20);
+    pl.w1 = c->last_w1;
+    const int R = pl.w1 == 1 ? PF_ROWS_W1 : (pl.w1 == 2 ? PF_ROWS_W2 : PF_ROWS_W4);
+    pl.tr = 256 * R;
+    pl.tc = PF_TC;
+    pl.shard = shard;
+    pl.n_shards = n_shards;
+    pl.pf_grid = 2048;
+    pl.verify_grid = 512;
+    pl.work_cap = (int)std::min<int64_t>(c->work_cap, INT32_MAX);
+    pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
+    pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
+    pl.long_lds_cap = LONG_LDS_CAP;
+    pl.indptr = c->d_indptr;
+    pl.indices = c->d_indices;
+    pl.cols = c->d_cols;
+    pl.ctr = (Counters *)c->d_head;
+    pl.hist = (int *)(c->d_head + sizeof(Counters));
+    pl.start = c->d_start;
+    pl.cursor = c->d_cursor;
+    pl.perm = c->d_perm;
+    pl.pos = c->d_pos;
+    pl.ksorted = c->d_ksorted;
+    pl.parent = c->d_parent;
+    pl.longrows = c->d_longrows;
+    pl.sig1 = c->d_sig1;
+    pl.sig2 = c->d_sig2;
+    pl.work = c->d_work;
+    pl.cand = c->d_cand;
+    pl.edges = c->edge_capture ? c->d_edges : nullptr;
+    pl.labels = (int *)d_labels_out;
+    HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)(c->kcap + 1) * 4, c->stream));
+    if (int e = launch_pipeline(pl, c->stream, c->profiling ? c->ev : nullptr))
+        return fail(BFK_EHIP, std::string("kernel launch: ") + hipGetErrorString((hipError_t)e));
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t n_parts, void *d_labels_out,
+                                    void *d_changed) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (!c->ran) return fail(BFK_ESTATE, "bfk_ctx_merge_labels before bfk_ctx_cluster");
+    if (c->n == 0) return BFK_OK;
+    if (!d_gathered || !d_labels_out || n_parts <= 0) return fail(BFK_EARG, "bad merge arguments");
+    if (d_changed) HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream));
+    if (int e = launch_merge(c->d_parent, (int)c->n, (const int *)d_gathered, n_parts, (int *)d_labels_out,
+                             (int *)d_changed, (Counters *)c->d_head, c->stream))
+        return fail(BFK_EHIP, std::string("merge launch: ") + hipGetErrorString((hipError_t)e));
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
+    if (int rc = ctx_enter(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    bfk_stats s{};
+    s.n_rows = c->n < 0 ? 0 : c->n;
+    s.nnz = c->nnz;
+    s.max_row_len = c->kcap;
+    if (c->ran && c->n > 0) {
+        Counters h;
+        HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
+        if (h.err & ERR_ROWLEN) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
+        if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow");
+        if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
+        const int64_t n = c->n;
+        s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
+        s.pairs_in_band = (int64_t)h.pairs_in_band;
+        s.pairs_filtered = (int64_t)h.pairs_filtered;
+        s.n_candidates = (int64_t)h.n_cand_total;
+        s.n_edges = (int64_t)(h.n_edges + h.n_edges_inline);
+        s.n_inline = (int64_t)h.n_inline;
+        s.sig_words = c->last_w1;
+        s.n_work_items = (int32_t)h.n_work;
+        if (c->profiling) {
+            float a = 0, b = 0, v = 0, f = 0, t = 0;
+            if (hipEventElapsedTime(&a, c->ev[0], c->ev[1]) == hipSuccess && hipEventElapsedTime(&b, c->ev[1], c->ev[2]) == hipSuccess &&
+                hipEventElapsedTime(&v, c->ev[2], c->ev[3]) == hipSuccess && hipEventElapsedTime(&f, c->ev[3], c->ev[4]) == hipSuccess &&
+                hipEventElapsedTime(&t, c->ev[0], c->ev[4]) == hipSuccess) {
+                s.profiled = 1;
+                s.ms_prep = a;
+                s.ms_prefilter = b;
+                s.ms_verify = v;
+                s.ms_flatten = f;
+                s.ms_total = t;
+            }
+        }
+    }
+    c->stats = s;
+    if (out) *out = s;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_download(bfk_ctx *c, const void *d_src, void *h_dst, int64_t bytes) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (bytes < 0 || (bytes > 0 && (!d_src || !h_dst))) return fail(BFK_EARG, "bad download arguments");
+    if (bytes == 0) return BFK_OK;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_device_alloc(bfk_ctx *c, int64_t bytes, void **d_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (!d_out || bytes < 0) return fail(BFK_EARG, "bad alloc arguments");
+    hipError_t e = hipMalloc(d_out, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) return fail(BFK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_device_free(bfk_ctx *c, void *d_ptr) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_edges(bfk_ctx *c, int32_t **edges_out, int64_t *n_edges_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (!edges_out || !n_edges_out) return fail(BFK_EARG, "null output");
+    if (!c->ran || !c->edge_capture) return fail(BFK_ESTATE, "edge capture was not enabled for the last run");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int64_t ne = 0;
+    if (c->n > 0) {
+        Counters h;
+        HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
+        if (h.n_inline) return fail(BFK_EOVERFLOW, "candidate queue overflowed during an edge-capture run");
+        ne = (int64_t)h.n_edges_cap;
+        if (ne > c->edge_cap) return fail(BFK_EOVERFLOW, "edge buffer overflow");
+    }
+    int32_t *out = (int32_t *)malloc(std::max<size_t>(8, (size_t)ne * 8));
+    if (!out) return fail(BFK_ENOMEM, "out of memory");
+    if (ne > 0) HIP_TRY(hipMemcpy(out, c->d_edges, (size_t)ne * 8, hipMemcpyDeviceToHost));
+    *edges_out = out;
+    *n_edges_out = ne;
+    return BFK_OK;
+}
+
+// ================================================================================================
+// one-shot entry points on a lazily created default context (serialised by a mutex)
+// ================================================================================================
+static std::mutex g_mu;
+static bfk_ctx *g_default = nullptr;
+
+static int default_ctx(bfk_ctx **out) {
+    if (!g_default) {
+        int dev = 0;
+        if (const char *e = getenv("BFK_DEVICE")) dev = atoi(e);
+        if (int rc = bfk_ctx_create(dev, &g_default)) return rc;
+    }
+    *out = g_default;
+    return BFK_OK;
+}
+
+extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
+                               int32_t n_gpus, int32_t *labels_out, bfk_stats *stats_out) {
+    if (n_gpus > 1)
+        return fail(BFK_EARG, "bfk_cluster_csr drives one GPU; multi-GPU runs one process per GPU through bfk_ctx_*");
+    if (n_rows < 0 || !indptr || (n_rows > 0 && !labels_out)) return fail(BFK_EARG, "bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
+    void *d_labels = nullptr;
+    if (int rc = bfk_ctx_device_alloc(c, n_rows * 4, &d_labels)) return rc;
+    int rc = bfk_ctx_cluster(c, max_dist, 0, 1, d_labels);
+    if (!rc) rc = bfk_ctx_sync(c, stats_out);
+    if (!rc) rc = bfk_ctx_download(c, d_labels, labels_out, n_rows * 4);
+    std::string keep = g_err;
+    (void)bfk_ctx_device_free(c, d_labels);
+    g_err = keep;
+    return rc;
+}
+
+extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
+                                  const int64_t *select_ind, int64_t n_select, int64_t **nbr_indptr_out,
+                                  int32_t **nbr_indices_out) {
+    if (n_rows < 0 || !indptr || !nbr_indptr_out || !nbr_indices_out || (select_ind == nullptr && n_select > 0))
+        return fail(BFK_EARG, "bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
+    void *d_labels = nullptr;
+    if (int rc = bfk_ctx_device_alloc(c, n_rows * 4, &d_labels)) return rc;
+    int32_t *edges = nullptr;
+    int64_t ne = 0;
+    int rc = BFK_OK;
+    for (int attempt = 0; attempt < 8; attempt++) {  // grow the queues until the run fits
+        bfk_ctx_set_edge_capture(c, 1);
+        rc = bfk_ctx_cluster(c, max_dist, 0, 1, d_labels);
+        if (!rc) rc = bfk_ctx_sync(c, nullptr);
+        if (!rc) rc = bfk_ctx_edges(c, &edges, &ne);
+        if (rc != BFK_EOVERFLOW) break;
+        int64_t want = c->cand_cap_total * 4;
+        if ((rc = dev_realloc(&c->d_cand, &c->cand_cap_total, want))) break;
+        c->cand_cap_shard = c->cand_cap_total / CAND_SHARDS;
+    }
+    bfk_ctx_set_edge_capture(c, 0);
+    std::string keep = g_err;
+    (void)bfk_ctx_device_free(c, d_labels);
+    g_err = keep;
+    if (rc) return rc;
+    // adjacency (both directions) + self, ascending
+    std::vector<int64_t> deg((size_t)n_rows + 1, 0);
+    for (int64_t e = 0; e < ne; e++) {
+        deg[(size_t)edges[2 * e] + 1]++;
+        deg[(size_t)edges[2 * e + 1] + 1]++;
+    }
+    for (int64_t i = 0; i < n_rows; i++) deg[(size_t)i + 1] += deg[(size_t)i] + 1;  // +1: self
+    std::vector<int32_t> adj((size_t)deg[(size_t)n_rows]);
+    std::vector<int64_t> fill(deg.begin(), deg.end() - 1);
+    for (int64_t i = 0; i < n_rows; i++) adj[(size_t)fill[(size_t)i]++] = (int32_t)i;
+    for (int64_t e = 0; e < ne; e++) {
+        int32_t a = edges[2 * e], b = edges[2 * e + 1];
+        adj[(size_t)fill[(size_t)a]++] = b;
+        adj[(size_t)fill[(size_t)b]++] = a;
+    }
+    free(edges);
+    for (int64_t i = 0; i < n_rows; i++) std::sort(adj.begin() + deg[(size_t)i], adj.begin() + deg[(size_t)i + 1]);
+    const int64_t nq = select_ind ? n_select : n_rows;
+    int64_t total = 0;
+    for (int64_t s = 0; s < nq; s++) {
+        int64_t i = select_ind ? select_ind[s] : s;
+        if (i < 0 || i >= n_rows) return fail(BFK_EARG, "select_ind out of range");
+        total += deg[(size_t)i + 1] - deg[(size_t)i];
+    }
+    int64_t *op = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(1, total));
+    if (!op || !oi) {
+        free(op);
+        free(oi);
+        return fail(BFK_ENOMEM, "out of memory");
+    }
+    op[0] = 0;
+    for (int64_t s = 0; s < nq; s++) {
+        int64_t i = select_ind ? select_ind[s] : s;
+        int64_t len = deg[(size_t)i + 1] - deg[(size_t)i];
+        memcpy(oi + op[s], adj.data() + deg[(size_t)i], sizeof(int32_t) * (size_t)len);
+        op[s + 1] = op[s] + len;
+    }
+    *nbr_indptr_out = op;
+    *nbr_indices_out = oi;
+    return BFK_OK;
+}

@@ -1,0 +1,139 @@
+/*
+ * bfk.h — C-ABI of libbfk.so: the MI355X (gfx950) replacement for the clustering hot path of
+ * rki-mf1/breakfast v0.4.6.  Plain pointers and sizes only; no torch / pandas / scipy types.
+ *
+ * The reference has no FFI: its boundary is a set of Python functions in src/breakfast/breakfast.py.
+ * Each entry point below names the reference function (file:line) whose work it replaces; the
+ * reference-side binding a maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - return 0 on success, <0 on error (BFK_E*); bfk_last_error() returns a thread-local message.
+ *   - inputs are borrowed for the duration of the call only (device pointers bound with
+ *     bfk_ctx_bind_csr_device must stay valid and unchanged until re-bound or the ctx is destroyed).
+ *   - outputs are caller-allocated unless the name ends in _out with a ** type: those are
+ *     library-allocated and released with bfk_free().
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device and fails with
+ *     BFK_ENODEV otherwise.  bfk_build_csr (tokeniser + vocabulary) is host code by nature.
+ *   - a bfk_ctx is not re-entrant: calls on one ctx must be serialised by the caller; different
+ *     ctxs (one per GPU / per process rank) are independent.
+ *   - labels are canonical: labels[i] = smallest row index in i's connected component.
+ */
+#ifndef BFK_H
+#define BFK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFK_ABI_VERSION 1
+
+#define BFK_OK 0
+#define BFK_EARG -1      /* bad argument (NULL pointer, negative size, malformed indptr, ...) */
+#define BFK_ENOMEM -2    /* host or device allocation failed */
+#define BFK_ENODEV -3    /* no usable gfx950 device / HIP runtime error at init */
+#define BFK_EHIP -4      /* HIP runtime error during the call (message has the hipError string) */
+#define BFK_EOVERFLOW -5 /* an internal device buffer overflowed and could not be recovered */
+#define BFK_ESTATE -6    /* call order violated (e.g. cluster before a CSR was bound) */
+
+typedef struct bfk_ctx bfk_ctx;
+
+/* Counters and timings of the last bfk_ctx_cluster / bfk_ctx_merge_labels, filled by bfk_ctx_sync. */
+typedef struct bfk_stats {
+    int64_t n_rows;          /* N_u: rows of the bound CSR */
+    int64_t nnz;             /* stored entries (multiset sizes summed) */
+    int64_t pairs_resolved;  /* unordered pairs whose <=max_dist status this shard decided: N(N-1)/2 for 1 shard */
+    int64_t pairs_in_band;   /* unordered pairs with |k_i-k_j| <= max_dist (need a set comparison), all shards */
+    int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded) */
+    int64_t n_candidates;    /* pairs that passed both signature levels and were merged exactly */
+    int64_t n_edges;         /* candidates with exact distance <= max_dist */
+    int64_t n_inline;        /* candidates verified inline because the candidate buffer was full */
+    int32_t max_row_len;     /* largest multiset size k */
+    int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
+    int32_t n_work_items;    /* (row tile, column chunk) items in the band */
+    int32_t profiled;        /* 1 if the ms fields below are valid (bfk_ctx_set_profiling) */
+    float ms_prep;           /* histogram + scan + scatter + row canonicalisation/signatures */
+    float ms_prefilter;      /* all-pairs signature kernel (the dominant kernel) */
+    float ms_verify;         /* exact merge of candidates + union-find hooks */
+    float ms_flatten;        /* label flatten */
+    float ms_total;          /* first launch to last launch completion */
+} bfk_stats;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int bfk_abi_version(void);
+int bfk_device_count(void); /* number of visible gfx950 devices; 0 if none / no HIP runtime */
+const char *bfk_last_error(void);
+void bfk_free(void *p);
+
+/* ---- a1: vocabulary + CSR --------------------------------------------------------------------
+ * Replaces sparse_feature_matrix(features, feature_sep)            src/breakfast/breakfast.py:193-215.
+ * Row r is the byte range buf[row_off[r] .. row_off[r+1]).  Tokens are split on `sep` (non-overlapping,
+ * left to right, like str.split), empty tokens are skipped (:208-209), ids are assigned by first
+ * appearance (:210), repeated tokens are kept (the matrix is a count matrix).  indptr_out has
+ * n_rows+1 entries and is caller-allocated; *indices_out is library-allocated (bfk_free).
+ * sep_len == 0 -> BFK_EARG (Python raises ValueError("empty separator")).                          */
+int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                  int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out);
+
+/* ---- a2..a8 one-shot, host buffers ------------------------------------------------------------
+ * Replaces the body of cluster_features between the CSR and the components:
+ *   n_features / band loop (:287-319) -> get_neighbours_batch (:223-276) -> sklearn _sparse_manhattan
+ *   -> _reduce_func (:226-228) -> _to_graph (:93-113) -> networkx connected_components (:325-326).
+ * indices may be unsorted and may contain repeats (multiset rows).  labels_out: int32[n_rows].
+ * n_gpus must be 1 here (multi-GPU runs one process per GPU through the ctx API below).
+ * stats_out may be NULL.                                                                            */
+int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist, int32_t n_gpus,
+                    int32_t *labels_out, bfk_stats *stats_out);
+
+/* ---- a4 canonicalised: neighbour lists ----------------------------------------------------------
+ * Replaces what get_neighbours_batch (:223-276) computes, over all lengths at once: for every query row
+ * (all rows, or select_ind[0..n_select) in that order) the ascending list of rows j with L1(i,j) <=
+ * max_dist, self included.  CSR-style output: list s is nbr_indices[nbr_indptr[s] .. nbr_indptr[s+1]).
+ * Both outputs are library-allocated (bfk_free).  select_ind == NULL means all rows.                 */
+int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
+                       const int64_t *select_ind, int64_t n_select, int64_t **nbr_indptr_out,
+                       int32_t **nbr_indices_out);
+
+/* ---- resident context: device buffers, one ctx per GPU ---------------------------------------------
+ * The same path with the CSR resident in HBM and launches enqueued on a caller-supplied HIP stream
+ * (e.g. torch.cuda.current_stream().cuda_stream); used by bench.py and by the one-process-per-GPU
+ * multi-GPU driver (breakfast_amd/distributed.py).                                                   */
+int bfk_ctx_create(int device, bfk_ctx **ctx_out);
+int bfk_ctx_destroy(bfk_ctx *ctx);
+int bfk_ctx_set_stream(bfk_ctx *ctx, void *hip_stream);   /* NULL = the ctx's own stream */
+int bfk_ctx_set_profiling(bfk_ctx *ctx, int32_t enable);  /* record HIP events between phases */
+
+/* copy a host CSR into ctx-owned device buffers (synchronous) */
+int bfk_ctx_upload_csr(bfk_ctx *ctx, const int32_t *indptr, const int32_t *indices, int64_t n_rows);
+/* borrow a CSR that already lives in device memory (int32 indptr[n_rows+1], int32 indices[nnz]);
+ * sizes the workspace (synchronous: reads indptr[n_rows] and the longest row back) */
+int bfk_ctx_bind_csr_device(bfk_ctx *ctx, const void *d_indptr, const void *d_indices, int64_t n_rows);
+
+/* enqueue CSR -> labels for shard `shard` of `n_shards` (work items are dealt round-robin; 0,1 = all).
+ * d_labels_out: device int32[n_rows]; with n_shards > 1 these are the labels of the LOCAL forest.
+ * Asynchronous: returns after the launches are enqueued.                                            */
+int bfk_ctx_cluster(bfk_ctx *ctx, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out);
+
+/* enqueue the multi-GPU merge: d_gathered = int32[n_parts][n_rows] label arrays (all_gather output, or
+ * 1 part holding an elementwise-min all-reduce); every (i, gathered[g][i]) is united into this ctx's
+ * forest and d_labels_out is re-flattened.  d_changed (device int32, may be NULL) is set to 1 if any
+ * label differs from d_gathered part 0 (fix-point test for the all-reduce(min) form).                */
+int bfk_ctx_merge_labels(bfk_ctx *ctx, const void *d_gathered, int32_t n_parts, void *d_labels_out, void *d_changed);
+
+/* wait for the stream, check device-side error flags, fill stats (may be NULL) */
+int bfk_ctx_sync(bfk_ctx *ctx, bfk_stats *stats_out);
+
+/* device <-> host helpers on the ctx stream (synchronous) */
+int bfk_ctx_download(bfk_ctx *ctx, const void *d_src, void *h_dst, int64_t bytes);
+int bfk_ctx_device_alloc(bfk_ctx *ctx, int64_t bytes, void **d_out);
+int bfk_ctx_device_free(bfk_ctx *ctx, void *d_ptr);
+
+/* edges of the last bfk_ctx_cluster run with edge capture enabled: (i<j) int32 pairs, library-allocated */
+int bfk_ctx_set_edge_capture(bfk_ctx *ctx, int32_t enable);
+int bfk_ctx_edges(bfk_ctx *ctx, int32_t **edges_out, int64_t *n_edges_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFK_H */

@@ -1,0 +1,251 @@
+"""GPU parity: the HIP path, called through the C-ABI (libbfk.so), against (a) the golden vectors produced
+by the imported reference, (b) the CPU oracle on seeded inputs, (c) size-independent properties at the
+BASELINE.json sizes.  Integer work: the bar is bit-exact."""
+
+import hashlib
+import io
+import json
+from contextlib import redirect_stdout
+
+import click.testing
+import numpy as np
+import pandas as pd
+import pytest
+from conftest import GOLD, load_stage, stage_names
+
+from breakfast_amd import _lib, breakfast, console
+from breakfast_amd.synth import generate_profiles
+from oracle import ref_port as orc
+
+pytestmark = pytest.mark.gpu
+FIX = GOLD / "ref_fixtures"
+
+
+def test_device_present():
+    assert _lib.load().bfk_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", stage_names())
+def test_labels_match_reference_golden(name):
+    g = load_stage(name)
+    labels, st = _lib.cluster_csr(g["indptr"], g["indices"], g["max_dist"])
+    assert np.array_equal(labels, g["labels"])
+    assert st["n_edges"] == len(g["edges"])  # every reference edge, and only those, passed the exact merge
+    assert st["n_inline"] == 0
+
+
+@pytest.mark.parametrize("name", stage_names())
+def test_neighbour_lists_match_reference_golden(name):
+    g = load_stage(name)
+    ptr, idx = _lib.neighbours_csr(g["indptr"], g["indices"], g["max_dist"])
+    n = len(g["indptr"]) - 1
+    got = {(i, int(j)) for i in range(n) for j in idx[ptr[i]: ptr[i + 1]] if j > i}
+    assert got == {tuple(e) for e in g["edges"].tolist()}
+    for i in range(n):
+        l = idx[ptr[i]: ptr[i + 1]]
+        assert i in l and np.all(np.diff(l) > 0)
+
+
+@pytest.mark.parametrize("name", ["syn200_d1", "multiset300_d2", "indel200_d5", "longrows_d2"])
+def test_get_neighbours_batch_mirror_matches_reference_order(name):
+    """band by band through the mirror API: exactly the list the reference builds"""
+    g = load_stage(name)
+    nf = g["n_features"]
+    lists = []
+    for q in dict.fromkeys(nf.tolist()):
+        lists += breakfast.get_neighbours_batch((g["indptr"], g["indices"]), nf, q, g["max_dist"])
+    flat = np.concatenate(lists)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    assert np.array_equal(off, g["neigh_off"]) and np.array_equal(flat, g["neigh_flat"])
+
+
+@pytest.mark.parametrize("name", stage_names())
+def test_clusters_tsv_bytes_from_features(name, tmp_path):
+    """feature strings -> clusters.tsv through collapse + cluster (GPU) + write_output"""
+    g = load_stage(name)
+    meta = pd.DataFrame({"id": [f"seq{i:07d}" for i in range(len(g["features"]))], "feature": g["features"]})
+    with redirect_stdout(io.StringIO()):
+        nod = breakfast.collapse_duplicates(meta)
+        cl = breakfast.cluster(nod, g["sep"], g["max_dist"], g["min_cluster_size"], None, None)
+        breakfast.write_output(cl, meta, tmp_path)
+    assert (tmp_path / "clusters.tsv").read_bytes() == g["clusters_tsv"]
+    assert np.array_equal(np.asarray(cl["n_features"]), g["n_features"])
+
+
+def test_cluster_kats(kats, tmp_path):
+    for n, c in enumerate(kats["cluster"]):
+        meta = pd.DataFrame({"id": [f"s{i}" for i in range(len(c["features"]))], "feature": c["features"]})
+        with redirect_stdout(io.StringIO()):
+            nod = breakfast.collapse_duplicates(meta)
+            if "error" in c:
+                with pytest.raises(ValueError):
+                    breakfast.cluster(nod, c["sep"], c["max_dist"], c["min_cluster_size"], None, None)
+                continue
+            cl = breakfast.cluster(nod, c["sep"], c["max_dist"], c["min_cluster_size"], None, None)
+            out = tmp_path / str(n)
+            breakfast.write_output(cl, meta, out)
+        assert (out / "clusters.tsv").read_text() == c["clusters_tsv"], c
+
+
+@pytest.mark.parametrize("scenario", ["dist0", "dist1", "dist1_noskipdel", "raw_defaults", "raw_explicit",
+                                      "nextclade_dist0", "nextclade_dist1", "dist2_mcs3", "dist1_mcs3_noskip"])
+def test_cli_matches_reference_bytes(scenario, cli_runs, tmp_path, monkeypatch):
+    """the reference's own CLI scenarios (tests/test_breakfast.py) — byte-identical clusters.tsv"""
+    monkeypatch.chdir(FIX)
+    run = cli_runs[scenario]
+    res = click.testing.CliRunner().invoke(console.main, run["args"] + ["--outdir", str(tmp_path)])
+    assert res.exit_code == 0, res.output
+    data = (tmp_path / "clusters.tsv").read_bytes()
+    assert data.decode() == run["clusters_tsv"]
+    assert hashlib.sha256(data).hexdigest() == run["sha256"]
+
+
+@pytest.mark.parametrize("fixture,expected", [
+    (["--input-file", "testfile.tsv", "--max-dist", "1"], "expected_clusters_dist1.tsv"),
+    (["--input-file", "testfile.tsv", "--max-dist", "1", "--no-skip-del"], "expected_clusters_dist1_noskipdel.tsv"),
+    (["--input-file", "testfile.tsv", "--var-type", "raw"], "expected_clusters_dist1_noskipdel.tsv"),
+])
+def test_cli_like_reference_tests(fixture, expected, tmp_path, monkeypatch):
+    monkeypatch.chdir(FIX)
+    res = click.testing.CliRunner().invoke(console.main, fixture + ["--outdir", str(tmp_path)])
+    assert res.exit_code == 0
+    assert pd.read_table(expected, sep="\t").equals(pd.read_table(tmp_path / "clusters.tsv", sep="\t"))
+
+
+# ---- seeded inputs vs the oracle ------------------------------------------------------------------
+def _random_multisets(n, seed, alphabet, kmax, p_empty=0.05):
+    rng = np.random.default_rng(seed)
+    base = [rng.integers(0, alphabet, size=int(rng.integers(0, kmax + 1))) for _ in range(max(2, n // 8))]
+    rows = []
+    for _ in range(n):
+        r = list(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 4))):
+            op = rng.random()
+            if op < 0.45 and r:
+                r.pop(int(rng.integers(0, len(r))))
+            elif op < 0.9:
+                r.append(int(rng.integers(0, alphabet)))
+            elif r:
+                r.append(r[int(rng.integers(0, len(r)))])
+        if rng.random() < p_empty:
+            r = []
+        rng.shuffle(r)
+        rows.append(np.array(r, dtype=np.int32))
+    indptr = np.zeros(n + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+    return indptr, indices
+
+
+@pytest.mark.parametrize("n,alphabet,kmax,d,seed", [
+    (1, 5, 3, 1, 0), (2, 5, 3, 1, 1), (7, 4, 3, 2, 2), (500, 40, 10, 1, 3), (500, 40, 10, 3, 4),
+    (1500, 200, 40, 2, 5), (1500, 30, 6, 1, 6), (800, 1000, 300, 5, 7), (600, 3000, 700, 7, 8),
+    (400, 8, 90, 4, 9), (1200, 100, 70, 12, 10),
+])
+def test_random_multisets_vs_oracle(n, alphabet, kmax, d, seed):
+    indptr, indices = _random_multisets(n, seed, alphabet, kmax)
+    if indptr[-1] == 0:
+        indices = np.zeros(0, np.int32)
+    want = orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"]
+    got, st = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(got, want)
+    assert st["sig_words"] == (1 if d <= 2 else 2 if d <= 5 else 4)
+
+
+def test_all_identical_rows_clique():
+    """every pair is within distance 0: a dense candidate set (queue pressure) must still be exact"""
+    n = 3000
+    rng = np.random.default_rng(5)
+    row = rng.permutation(40).astype(np.int32)
+    indices = np.concatenate([rng.permutation(row) for _ in range(n)]).astype(np.int32)
+    indptr = (np.arange(n + 1) * 40).astype(np.int32)
+    got, st = _lib.cluster_csr(indptr, indices, 1)
+    assert np.all(got == 0)
+    assert st["n_edges"] + 0 >= n - 1
+
+
+def test_empty_and_degenerate_inputs():
+    got, _ = _lib.cluster_csr(np.array([0], np.int32), np.zeros(0, np.int32), 1)
+    assert len(got) == 0
+    got, _ = _lib.cluster_csr(np.array([0, 0, 0, 0], np.int32), np.zeros(0, np.int32), 1)
+    assert got.tolist() == [0, 0, 0]  # three empty rows: distance 0
+    got, _ = _lib.cluster_csr(np.array([0, 0, 2, 3], np.int32), np.array([5, 6, 5], np.int32), 1)
+    assert got.tolist() == [0, 0, 0]  # {} -1- {5} -1- {5,6}
+    got, _ = _lib.cluster_csr(np.array([0, 0, 2, 5], np.int32), np.array([5, 6, 7, 8, 9], np.int32), 1)
+    assert got.tolist() == [0, 1, 2]
+    with pytest.raises(_lib.BfkError):
+        _lib.cluster_csr(np.array([0, 2, 1], np.int32), np.array([1, 2], np.int32), 1)  # indptr not monotone
+
+
+def test_run_to_run_determinism_of_labels():
+    rows = generate_profiles(5000)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    a, _ = _lib.cluster_csr(indptr, indices, 2)
+    for _ in range(3):
+        b, _ = _lib.cluster_csr(indptr, indices, 2)
+        assert np.array_equal(a, b)
+
+
+# ---- BASELINE.json sizes ---------------------------------------------------------------------------
+def _cli_sha(n, tmp_path, extra=()):
+    from breakfast_amd.synth import generate_tsv
+
+    inp = tmp_path / "in.tsv"
+    generate_tsv(inp, n)
+    res = click.testing.CliRunner().invoke(console.main, ["--input-file", str(inp), "--outdir", str(tmp_path),
+                                                          "--max-dist", "1", *extra])
+    assert res.exit_code == 0, res.output
+    return hashlib.sha256(inp.read_bytes()).hexdigest(), hashlib.sha256((tmp_path / "clusters.tsv").read_bytes()).hexdigest()
+
+
+@pytest.mark.parametrize("key", ["syn2000_d1", "syn10000_d1", "syn100000_d1"])
+def test_clusters_tsv_sha256_at_baseline_sizes(key, tmp_path):
+    """configs[1] (10k) and configs[2] (100k): the whole CLI, digest recorded from the reference"""
+    want = json.loads((GOLD / "sha256.json").read_text())[key]
+    h_in, h_out = _cli_sha(want["n"], tmp_path)
+    assert h_in == want["input_sha256"]
+    assert h_out == want["clusters_sha256"]
+
+
+def test_10k_vs_oracle_full():
+    rows = list(dict.fromkeys(generate_profiles(10000)))
+    indptr, indices, _ = _lib.build_csr(rows, " ")
+    want = orc.cluster_csr(indptr, indices, 1, n_threads=16)
+    got, st = _lib.cluster_csr(indptr, indices, 1)
+    assert np.array_equal(got, want["labels"])
+    assert st["pairs_resolved"] == len(rows) * (len(rows) - 1) // 2
+
+
+def test_properties_at_100k_d2_and_indels():
+    """size-independent properties where the oracle would take too long: idempotence under row permutation
+    (labels are canonical), monotonicity in d (partition at d refines partition at d+1), labels are fix points"""
+    rows = list(dict.fromkeys(generate_profiles(100000, p_del=0.05, p_ins=0.01)))
+    indptr, indices, _ = _lib.build_csr(rows, " ")
+    l1, _ = _lib.cluster_csr(indptr, indices, 1)
+    l2, st2 = _lib.cluster_csr(indptr, indices, 2)
+    assert np.array_equal(l1[l1], l1) and np.array_equal(l2[l2], l2) and np.all(l1 <= np.arange(len(l1)))
+    assert np.array_equal(l2[l1], l2)  # same d=1 component -> same d=2 component
+    # permute rows: the partition must be the same
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(rows))
+    ip2, ix2, _ = _lib.build_csr([rows[i] for i in perm], " ")
+    lp, _ = _lib.cluster_csr(ip2, ix2, 2)
+    back = np.empty(len(rows), np.int64)
+    back[perm] = np.arange(len(rows))           # original row -> permuted row
+    canon = np.full(len(rows), len(rows), np.int64)
+    np.minimum.at(canon, lp[back], np.arange(len(rows)))  # min original index per permuted-run component
+    assert np.array_equal(canon[lp[back]], l2)
+    # sampled rows against the oracle's select_ind path (rows x all columns)
+    sel = np.sort(rng.choice(len(rows), size=300, replace=False)).astype(np.int64)
+    ptr, idx = _lib.neighbours_csr(indptr, indices, 2, sel)
+    nf = np.diff(indptr).astype(np.int64)
+    for s, i in enumerate(sel[:40].tolist()):
+        want = set()
+        for q in range(int(nf[i]) - 2, int(nf[i]) + 3):
+            if q < 0:
+                continue
+            for l in orc.get_neighbours_batch(indptr, indices, nf, q, 2, select_ind=np.array([i], np.int64),
+                                              n_threads=16):
+                want |= set(l.tolist())
+        assert set(idx[ptr[s]: ptr[s + 1]].tolist()) == want

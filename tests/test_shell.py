@@ -1,0 +1,133 @@
+"""CPU: the Python shell around the hot path (reader, filter, collapse, writer, CLI plumbing) against the
+reference's fixtures and the golden vectors.  Nothing here needs a GPU: max-dist 0 never reaches libbfk."""
+
+import io
+from contextlib import redirect_stdout
+from pathlib import Path
+
+import click.testing
+import numpy as np
+import pandas as pd
+import pytest
+from conftest import GOLD
+
+from breakfast_amd import breakfast, console
+
+FIX = GOLD / "ref_fixtures"
+
+
+@pytest.fixture
+def runner():
+    return click.testing.CliRunner()
+
+
+def test_entrypoint(runner):
+    assert runner.invoke(console.main, ["--help"]).exit_code == 0
+
+
+def test_filter_kats(kats):
+    for c in kats["filter"]:
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            r = breakfast.filter_features([c["input"]], c["sep"], c["var_type"], c["skip_ins"], c["skip_del"],
+                                          c["trim_start"], c["trim_end"], c["reference_length"])
+        assert list(r)[0] == c["output"], c
+        assert buf.getvalue() == c["stdout"], c
+
+
+@pytest.mark.parametrize("features,expected,args", [
+    (["C241T"], ["C241T"], (False, False, 0, 0, 1000)),
+    (["C241T"], [""], (False, False, 250, 0, 1000)),
+    ([""], [""], (False, False, 250, 0, 1000)),
+    (["  "], [""], (False, False, 250, 0, 1000)),
+    (["C241T del:10:1 G5343TT"], ["C241T G5343TT"], (False, True, 0, 0, 1000)),
+    (["C241T del:10:1 G5343TT"], ["C241T del:10:1"], (True, False, 0, 0, 1000)),
+    (["C241T del:10:1 G5343TT"], ["C241T"], (True, True, 0, 0, 1000)),
+    (["G24C C241T del:10:1 G533TT A990T"], ["C241T"], (True, True, 100, 100, 1000)),
+])
+def test_filter_like_reference_unit_tests(features, expected, args):
+    """the cases of the reference's tests/test_filtering.py:4-71"""
+    with redirect_stdout(io.StringIO()):
+        assert breakfast.filter_features(features, " ", "covsonar_dna", *args)[0] == expected[0]
+
+
+def test_filter_aa_like_reference_unit_tests():
+    with redirect_stdout(io.StringIO()):
+        assert breakfast.filter_features(["S:N501Y ORF1:del:12:7 N:A34AK"], " ", "covsonar_aa", True, True, 0, 0,
+                                         1000)[0] == "S:N501Y"
+        assert breakfast.filter_features(["S:N501Y S:V70-"], " ", "nextclade_aa", False, True, 0, 0,
+                                         1000)[0] == "S:N501Y"
+
+
+def test_filter_identity_returns_same_object():
+    feats = ["A12C  A12C   T5G "]
+    assert breakfast.filter_features(feats, " ", "covsonar_dna", False, False, 0, 0, 29903) is feats
+
+
+def test_filter_bad_type_exits():
+    with pytest.raises(SystemExit), redirect_stdout(io.StringIO()):
+        breakfast.filter_features(["A1C"], " ", "nope", True, True, 0, 0, 100)
+
+
+def test_sparse_feature_matrix_ignores_empty_features():
+    m = breakfast.sparse_feature_matrix(["", "C241T"], " ")
+    assert m.shape == (2, 1) and m[0].count_nonzero() == 0 and m[1].count_nonzero() == 1
+
+
+def test_read_input_and_duplicates():
+    with redirect_stdout(io.StringIO()):
+        meta = breakfast.read_input(FIX / "testfile.tsv", "\t", "accession", "dna_profile")
+    assert list(meta.columns) == ["id", "feature"] and len(meta) == 7
+    with pytest.raises(ValueError, match="Duplicate sequence identifiers"), redirect_stdout(io.StringIO()):
+        breakfast.read_input(FIX / "duplicate-ids.tsv", "\t", "accession", "dna_profile")
+
+
+def test_read_input_na_rules(tmp_path):
+    p = tmp_path / "x.tsv"
+    p.write_text('accession\tdna_profile\nNA2\tA1C\n"q 1"\t\nz\tnull\n')
+    with redirect_stdout(io.StringIO()):
+        meta = breakfast.read_input(p, "\t", "accession", "dna_profile")
+    assert meta["feature"].tolist() == ["A1C", "", ""] and meta["id"].tolist() == ["NA2", "q 1", "z"]
+
+
+def test_collapse_and_write_roundtrip(tmp_path):
+    meta = pd.DataFrame({"id": ["a", "b", "c", "d", "e"], "feature": ["X", "Y", "X", "Z", "Y"]})
+    with redirect_stdout(io.StringIO()):
+        nod = breakfast.collapse_duplicates(meta)
+    assert nod["id"].tolist() == [("a", "c"), ("b", "e"), ("d",)]
+    nod["cluster_id"] = pd.array([7, pd.NA, 3], dtype="Int64").astype(object)
+    breakfast.write_output(nod, meta, tmp_path)
+    assert (tmp_path / "clusters.tsv").read_bytes() == b"id\tcluster_id\na\t1\nb\t\nc\t1\nd\t2\ne\t\n"
+
+
+@pytest.mark.parametrize("scenario", ["dist0", "nextclade_dist0"])
+def test_cli_dist0_bytes(runner, tmp_path, monkeypatch, cli_runs, scenario):
+    """max-dist 0 end to end (no GPU involved): byte-identical to what the reference CLI wrote"""
+    monkeypatch.chdir(FIX)
+    run = cli_runs[scenario]
+    res = runner.invoke(console.main, run["args"] + ["--outdir", str(tmp_path)])
+    assert res.exit_code == 0, res.output
+    assert (tmp_path / "clusters.tsv").read_text() == run["clusters_tsv"]
+    exp = pd.read_table(FIX / "expected_clusters_dist0.tsv", sep="\t")
+    assert exp.equals(pd.read_table(tmp_path / "clusters.tsv", sep="\t"))
+
+
+def test_cli_errors(runner, tmp_path, monkeypatch):
+    monkeypatch.chdir(FIX)
+    base = ["--outdir", str(tmp_path), "--max-dist", "0"]
+    assert runner.invoke(console.main, ["--input-file", "duplicate-ids.tsv"] + base).exit_code != 0
+    assert runner.invoke(console.main, ["--input-file", "testfile.tsv", "--clust-col", "missing"] + base).exit_code != 0
+    assert runner.invoke(console.main, ["--input-file", "testfile.tsv", "--id-col", "missing"] + base).exit_code != 0
+    assert runner.invoke(console.main, ["--input-file", "testfile.tsv", "--var-type", "raw", "--trim-start", "5"]
+                         + base).exit_code != 0
+    assert runner.invoke(console.main, ["--input-file", "testfile.tsv", "--var-type", "covsonar_aa", "--skip-del"]
+                         + base).exit_code != 0
+    assert runner.invoke(console.main, ["--input-file", "testfile.tsv", "--trim-start", "40000"] + base).exit_code != 0
+
+
+def test_cluster_identical_features_min_size():
+    meta = pd.DataFrame({"id": [("a", "b"), ("c",), ("d", "e", "f")], "feature": ["X", "Y", "Z"]})
+    with redirect_stdout(io.StringIO()):
+        out = breakfast.cluster(meta, " ", 0, 2, None, None)
+    assert out["cluster_id"].tolist()[0] == 1 and pd.isna(out["cluster_id"].tolist()[1])
+    assert out["cluster_id"].tolist()[2] == 2
