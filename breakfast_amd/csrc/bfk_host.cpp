@@ -146,7 +146,10 @@ struct bfk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool profiling = false, edge_capture = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int EV_SLOTS = 64;  // ring of per-step event sets: up to 64 steps are averaged per sync
+    hipEvent_t ev[EV_SLOTS][5] = {};
+    bool ev_ready = false;
+    int n_prof_calls = 0;
     // CSR
     const int *d_indptr = nullptr;
     const uint32_t *d_indices = nullptr;
@@ -216,11 +219,6 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
         return fail(BFK_EHIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    for (auto &e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
-            return fail(BFK_EHIP, "hipEventCreate failed");
-        }
     if (hipMalloc((void **)&c->d_small, 64) != hipSuccess) {
         delete c;
         return fail(BFK_ENOMEM, "hipMalloc failed");
@@ -238,8 +236,9 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_cand,     c->d_edges,     c->d_small};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &slot : c->ev)
+        for (auto &e : slot)
+            if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BFK_OK;
@@ -252,8 +251,15 @@ extern "C" int bfk_ctx_set_stream(bfk_ctx *c, void *hip_stream) {
 }
 
 extern "C" int bfk_ctx_set_profiling(bfk_ctx *c, int32_t enable) {
-    if (!c) return fail(BFK_EARG, "null ctx");
+    if (int rc = ctx_enter(c)) return rc;
+    if (enable && !c->ev_ready) {
+        for (auto &slot : c->ev)
+            for (auto &e : slot)
+                if (hipEventCreate(&e) != hipSuccess) return fail(BFK_EHIP, "hipEventCreate failed");
+        c->ev_ready = true;
+    }
     c->profiling = enable != 0;
+    c->n_prof_calls = 0;
     return BFK_OK;
 }
 
@@ -413,7 +419,8 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
     pl.labels = (int *)d_labels_out;
     HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)(c->kcap + 1) * 4, c->stream));
-    if (int e = launch_pipeline(pl, c->stream, c->profiling ? c->ev : nullptr))
+    hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
+    if (int e = launch_pipeline(pl, c->stream, evs))
         return fail(BFK_EHIP, std::string("kernel launch: ") + hipGetErrorString((hipError_t)e));
     return BFK_OK;
 }
@@ -453,18 +460,27 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.n_inline = (int64_t)h.n_inline;
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;
-        if (c->profiling) {
-            float a = 0, b = 0, v = 0, f = 0, t = 0;
-            if (hipEventElapsedTime(&a, c->ev[0], c->ev[1]) == hipSuccess && hipEventElapsedTime(&b, c->ev[1], c->ev[2]) == hipSuccess &&
-                hipEventElapsedTime(&v, c->ev[2], c->ev[3]) == hipSuccess && hipEventElapsedTime(&f, c->ev[3], c->ev[4]) == hipSuccess &&
-                hipEventElapsedTime(&t, c->ev[0], c->ev[4]) == hipSuccess) {
-                s.profiled = 1;
-                s.ms_prep = a;
-                s.ms_prefilter = b;
-                s.ms_verify = v;
-                s.ms_flatten = f;
-                s.ms_total = t;
+        if (c->profiling && c->n_prof_calls > 0) {
+            const int used = std::min(c->n_prof_calls, (int)bfk_ctx::EV_SLOTS);
+            double acc[5] = {0, 0, 0, 0, 0};
+            bool ok = true;
+            for (int i = 0; i < used && ok; i++) {
+                hipEvent_t *e = c->ev[i];
+                float v[5];
+                ok = hipEventElapsedTime(&v[0], e[0], e[1]) == hipSuccess && hipEventElapsedTime(&v[1], e[1], e[2]) == hipSuccess &&
+                     hipEventElapsedTime(&v[2], e[2], e[3]) == hipSuccess && hipEventElapsedTime(&v[3], e[3], e[4]) == hipSuccess &&
+                     hipEventElapsedTime(&v[4], e[0], e[4]) == hipSuccess;
+                for (int k = 0; k < 5; k++) acc[k] += v[k];
             }
+            if (ok) {
+                s.profiled = used;
+                s.ms_prep = (float)(acc[0] / used);
+                s.ms_prefilter = (float)(acc[1] / used);
+                s.ms_verify = (float)(acc[2] / used);
+                s.ms_flatten = (float)(acc[3] / used);
+                s.ms_total = (float)(acc[4] / used);
+            }
+            c->n_prof_calls = 0;
         }
     }
     c->stats = s;

@@ -52,7 +52,7 @@ typedef struct bfk_stats {
     int32_t max_row_len;     /* largest multiset size k */
     int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
     int32_t n_work_items;    /* (row tile, column chunk) items in the band */
-    int32_t profiled;        /* 1 if the ms fields below are valid (bfk_ctx_set_profiling) */
+    int32_t profiled;        /* number of steps the ms fields below are averaged over (0 = profiling off) */
     float ms_prep;           /* histogram + scan + scatter + row canonicalisation/signatures */
     float ms_prefilter;      /* all-pairs signature kernel (the dominant kernel) */
     float ms_verify;         /* exact merge of candidates + union-find hooks */
