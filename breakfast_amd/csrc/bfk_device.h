@@ -9,7 +9,7 @@ constexpr int HIST_LDS_BINS = 2048;    // row lengths below this are histogramme
 constexpr int SIG2_WORDS = 4;          // second-level signature: 128 bits
 constexpr int CAND_SHARDS = 8;         // candidate queue shards (block % 8 ~ XCD)
 constexpr int PF_LDS_QUEUE = 1024;     // per-block LDS candidate queue entries (8 KiB)
-constexpr int VERIFY_LDS_ROW = 512;    // tokens of row B staged per wave in k_verify (2 KiB/wave)
+constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane group in k_verify (512 B/group)
 constexpr int PF_ROWS_W1 = 4;          // rows per thread in k_prefilter by signature width
 constexpr int PF_ROWS_W2 = 4;
 constexpr int PF_ROWS_W4 = 2;
@@ -24,13 +24,11 @@ struct Counters {
     int err;
     unsigned int n_work;
     unsigned int n_long;
-    unsigned int pad0;
+    int overflow;
     unsigned long long pairs_in_band;
     unsigned long long pairs_filtered;
     unsigned long long n_cand_total;
     unsigned long long n_edges;
-    unsigned long long n_edges_inline;
-    unsigned long long n_inline;
     unsigned long long n_edges_cap;
 };
 
@@ -39,7 +37,7 @@ struct Plan {
     int n, kcap, d, w1;
     int tr, tc;
     int shard, n_shards;
-    int pf_grid, verify_grid;
+    int pf_grid, verify_grid, union_grid;
     int work_cap, cand_cap_shard, edge_cap, long_lds_cap;
     const int *indptr;
     const uint32_t *indices;
@@ -48,7 +46,8 @@ struct Plan {
     int *perm, *pos, *ksorted, *parent, *longrows;
     uint32_t *sig1, *sig2;
     int4 *work;
-    int2 *cand;
+    int4 *cand;
+    int2 *candk;
     int2 *edges;  // NULL unless edge capture is on
     int *labels;
     Counters *ctr;
@@ -56,6 +55,8 @@ struct Plan {
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
+int launch_pairs(const Plan &pl, int w_begin, int w_end, hipStream_t st, hipEvent_t *ev);
+int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
                  hipStream_t st);
 

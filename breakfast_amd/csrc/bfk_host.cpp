@@ -169,7 +169,9 @@ struct bfk_ctx {
     int64_t rows_cap = 0;
     int4 *d_work = nullptr;
     int64_t work_cap = 0;
-    int2 *d_cand = nullptr;
+    int4 *d_cand = nullptr;
+    int2 *d_candk = nullptr;
+    int64_t candk_cap = 0;
     int64_t cand_cap_total = 0, cand_cap_shard = 0;
     int2 *d_edges = nullptr;
     int64_t edge_cap = 0;
@@ -177,6 +179,7 @@ struct bfk_ctx {
     // last run
     bool ran = false;
     int last_d = 0, last_w1 = 0, last_shards = 1;
+    Plan plan{};  // the last enqueued run (bfk_ctx_sync re-runs it in slices after a queue overflow)
     bfk_stats stats{};
 };
 
@@ -233,7 +236,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,    c->d_start, c->d_cursor, c->d_cols, c->d_perm,
                     c->d_pos,      c->d_ksorted,   c->d_parent,  c->d_longrows, c->d_sig1, c->d_sig2, c->d_work,
-                    c->d_cand,     c->d_edges,     c->d_small};
+                    c->d_cand,     c->d_candk,     c->d_edges,     c->d_small};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -274,6 +277,16 @@ static int64_t work_items_bound(int64_t n, int tr, int tc) {
     return T * ((n + tc - 1) / tc + 2) + 16;
 }
 
+static int ctx_size_cand(bfk_ctx *c, int64_t total) {
+    if (total > c->cand_cap_total || !c->d_cand || !c->d_candk) {
+        if (int rc = dev_realloc(&c->d_cand, &c->cand_cap_total, total)) return rc;
+        c->candk_cap = 0;
+        if (int rc = dev_realloc(&c->d_candk, &c->candk_cap, c->cand_cap_total)) return rc;
+    }
+    c->cand_cap_shard = c->cand_cap_total / CAND_SHARDS;
+    return BFK_OK;
+}
+
 static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     const int64_t n = c->n, nnz = c->nnz;
     const int64_t bins = (int64_t)c->kcap + 4 + std::max(d_hint, 64);
@@ -310,9 +323,10 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     // all-pairs upper bound for the smallest row tile (R=2 -> 512 rows)
     if (int rc = dev_realloc(&c->d_work, &c->work_cap, work_items_bound(n, 256 * PF_ROWS_W4, PF_TC))) return rc;
     {
-        int64_t want = std::max<int64_t>(1 << 14, 4 * n + 4096);  // per shard; 8 shards -> 32 N pairs
-        if (int rc = dev_realloc(&c->d_cand, &c->cand_cap_total, want * CAND_SHARDS)) return rc;
-        c->cand_cap_shard = c->cand_cap_total / CAND_SHARDS;
+        // per shard: 4N pairs (8 shards -> 32N), and never less than one work item's pair slots, so that a
+        // single-item slice of the overflow recovery always fits
+        int64_t want = std::max<int64_t>((int64_t)256 * PF_ROWS_W1 * PF_TC, 4 * n + 4096);
+        if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;
 }
@@ -395,7 +409,8 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.shard = shard;
     pl.n_shards = n_shards;
     pl.pf_grid = 2048;
-    pl.verify_grid = 512;
+    pl.verify_grid = 2048;
+    pl.union_grid = 512;
     pl.work_cap = (int)std::min<int64_t>(c->work_cap, INT32_MAX);
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
@@ -416,8 +431,10 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.sig2 = c->d_sig2;
     pl.work = c->d_work;
     pl.cand = c->d_cand;
+    pl.candk = c->d_candk;
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
     pl.labels = (int *)d_labels_out;
+    c->plan = pl;
     HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)(c->kcap + 1) * 4, c->stream));
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
     if (int e = launch_pipeline(pl, c->stream, evs))
@@ -438,6 +455,61 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
     return BFK_OK;
 }
 
+// The candidate queue overflowed (very dense input: far more first-level hits than 32*N): the forest
+// already holds every edge that was verified, the dropped ones are recovered by re-running prefilter +
+// verify over slices of the work list small enough for the queue, halving a slice that still overflows.
+// Unions are idempotent, so re-verifying pairs is harmless.  Synchronous (called from bfk_ctx_sync).
+static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {
+    Plan &pl = c->plan;
+    const int n_work = (int)h->n_work;
+    std::vector<std::pair<int, int>> todo;
+    const int step0 = std::max(1, n_work / 16);
+    for (int b = n_work; b > 0; b -= step0) todo.push_back({std::max(0, b - step0), b});
+    h->n_edges = h->n_cand_total = h->n_edges_cap = h->pairs_filtered = 0;
+    unsigned long long edges_acc = 0, cand_acc = 0, filt_acc = 0;
+    while (!todo.empty()) {
+        auto [b, e] = todo.back();
+        todo.pop_back();
+        for (auto &x : h->ncand) x = 0;
+        h->overflow = 0;
+        h->n_edges = h->n_cand_total = h->pairs_filtered = 0;
+        const unsigned long long cap_mark = h->n_edges_cap;
+        HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
+        if (int er = launch_pairs(pl, b, e, c->stream, nullptr))
+            return fail(BFK_EHIP, std::string("recovery launch: ") + hipGetErrorString((hipError_t)er));
+        HIP_TRY(hipMemcpyAsync(h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (*n_slices)++;
+        if (h->overflow) {
+            h->n_edges_cap = cap_mark;  // drop this slice's captured edges, it is redone
+            if (e - b > 1) {
+                const int mid = b + (e - b) / 2;
+                todo.push_back({mid, e});
+                todo.push_back({b, mid});
+            } else {  // cannot happen with the sizing rule of ctx_size_workspace; grow and retry anyway
+                if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
+                pl.cand = c->d_cand;
+                pl.candk = c->d_candk;
+                pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
+                todo.push_back({b, e});
+            }
+            continue;
+        }
+        edges_acc += h->n_edges;
+        cand_acc += h->n_cand_total;
+        filt_acc += h->pairs_filtered;
+    }
+    h->n_edges = edges_acc;
+    h->n_cand_total = cand_acc;
+    h->pairs_filtered = filt_acc;
+    h->overflow = 0;
+    HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
+    if (int er = launch_flatten(pl, c->stream, nullptr))
+        return fail(BFK_EHIP, std::string("recovery flatten: ") + hipGetErrorString((hipError_t)er));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFK_OK;
+}
+
 extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
     if (int rc = ctx_enter(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -451,13 +523,17 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (h.err & ERR_ROWLEN) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
+        int64_t retry_slices = 0;
+        if (h.overflow) {
+            if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
+        }
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
         s.pairs_in_band = (int64_t)h.pairs_in_band;
         s.pairs_filtered = (int64_t)h.pairs_filtered;
         s.n_candidates = (int64_t)h.n_cand_total;
-        s.n_edges = (int64_t)(h.n_edges + h.n_edges_inline);
-        s.n_inline = (int64_t)h.n_inline;
+        s.n_edges = (int64_t)h.n_edges;
+        s.n_retry_slices = retry_slices;
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;
         if (c->profiling && c->n_prof_calls > 0) {
@@ -520,13 +596,17 @@ extern "C" int bfk_ctx_edges(bfk_ctx *c, int32_t **edges_out, int64_t *n_edges_o
     if (c->n > 0) {
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
-        if (h.n_inline) return fail(BFK_EOVERFLOW, "candidate queue overflowed during an edge-capture run");
         ne = (int64_t)h.n_edges_cap;
         if (ne > c->edge_cap) return fail(BFK_EOVERFLOW, "edge buffer overflow");
     }
     int32_t *out = (int32_t *)malloc(std::max<size_t>(8, (size_t)ne * 8));
     if (!out) return fail(BFK_ENOMEM, "out of memory");
     if (ne > 0) HIP_TRY(hipMemcpy(out, c->d_edges, (size_t)ne * 8, hipMemcpyDeviceToHost));
+    if (ne > 1) {  // a recovered (sliced) run may report an edge more than once
+        int64_t *e64 = reinterpret_cast<int64_t *>(out);
+        std::sort(e64, e64 + ne);
+        ne = std::unique(e64, e64 + ne) - e64;
+    }
     *edges_out = out;
     *n_edges_out = ne;
     return BFK_OK;
@@ -588,9 +668,7 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
         if (!rc) rc = bfk_ctx_sync(c, nullptr);
         if (!rc) rc = bfk_ctx_edges(c, &edges, &ne);
         if (rc != BFK_EOVERFLOW) break;
-        int64_t want = c->cand_cap_total * 4;
-        if ((rc = dev_realloc(&c->d_cand, &c->cand_cap_total, want))) break;
-        c->cand_cap_shard = c->cand_cap_total / CAND_SHARDS;
+        if ((rc = ctx_size_cand(c, c->cand_cap_total * 4))) break;
     }
     bfk_ctx_set_edge_capture(c, 0);
     std::string keep = g_err;

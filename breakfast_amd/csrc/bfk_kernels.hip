@@ -32,8 +32,10 @@ __device__ __forceinline__ int ld_agent(const int *p) {
 __device__ __forceinline__ uint32_t ld_agent_u(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_agent(int *p, int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// path-compression store: a plain store (no sc bits, acked by L2) — it sits in the dependent chain of the
+// next load (gfx9 vmcnt counts stores), so a write-through store would add its memory latency per hop
+__device__ __forceinline__ void st_lazy(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // Lock-free union-find, hooks always go from the larger index to a smaller one, so a root is the
@@ -44,7 +46,7 @@ __device__ __forceinline__ int uf_find(int *parent, int x) {
     if (cur != x) {
         int prev = x, next;
         while (cur > (next = ld_agent(parent + cur))) {
-            st_agent(parent + prev, next);  // path halving; only ever writes an ancestor to a non-root
+            st_lazy(parent + prev, next);  // path halving; only ever writes an ancestor to a non-root
             prev = cur;
             cur = next;
         }
@@ -62,7 +64,7 @@ __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
         }
         int old = atomicCAS(parent + ra, ra, rb);  // ra > rb
         if (old == ra) return true;
-        ra = old;  // ra was no longer a root: climb
+        ra = uf_find(parent, old);  // ra was no longer a root: go to the current root (cheap loads, not CASes)
     }
     return false;
 }
@@ -72,24 +74,6 @@ __device__ __forceinline__ uint32_t hash1(uint32_t x, uint32_t r) { return x * 0
 __device__ __forceinline__ uint32_t hash2(uint32_t x, uint32_t r) {
     uint32_t h = (x ^ (x >> 15)) * 0x85EBCA6Bu + r * 0xC2B2AE35u;
     return h ^ (h >> 13);
-}
-
-// exact multiset L1 distance by a serial two-pointer merge (fallback path, one pair per lane);
-// returns early with a value > d as soon as d is exceeded.
-__device__ int exact_dist_serial(const uint32_t *A, int ka, const uint32_t *B, int kb, int d) {
-    int i = 0, j = 0, miss = 0;
-    while (i < ka && j < kb) {
-        uint32_t a = A[i], b = B[j];
-        if (a == b) {
-            i++;
-            j++;
-        } else {
-            if (++miss > d) return miss;
-            if (a < b) i++;
-            else j++;
-        }
-    }
-    return miss + (ka - i) + (kb - j);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,44 +460,80 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
 }
 
 // ------------------------------------------------------------------------------------------------
-// candidate queue: 8 shards (block % 8) so that no single counter word takes all the atomics
+// candidate queue: (row a, row b) pairs, 8 shards (block % 8) so no single counter word takes all atomics
 // ------------------------------------------------------------------------------------------------
 struct PairArgs {
     const int *indptr;
     const uint32_t *cols;
     const int *perm;
+    const int *ksorted;
+    const uint32_t *sig2;
     int *parent;
-    int2 *cand;
+    int4 *cand;   // {row a, row b, cols offset a, cols offset b}
+    int2 *candk;  // {k_a, k_b}
     int cand_cap_shard;
     int d;
+    int n;
     Counters *ctr;
 };
 
-__device__ void verify_inline(const PairArgs &a, int p, int q) {
-    int ra = a.perm[p], rb = a.perm[q];
-    int ba = a.indptr[ra], ka = a.indptr[ra + 1] - ba;
-    int bb = a.indptr[rb], kb = a.indptr[rb + 1] - bb;
-    if (exact_dist_serial(a.cols + ba, ka, a.cols + bb, kb, a.d) <= a.d) {
-        uf_union(a.parent, ra, rb);
-        atomicAdd(&a.ctr->n_edges_inline, 1ull);
+// queue record: everything k_verify needs in ONE round trip (row ids, row offsets, row lengths)
+__device__ __forceinline__ void push_cand(const PairArgs &a, int shard, int idx, int ra, int rb) {
+    if (idx >= a.cand_cap_shard) {
+        a.ctr->overflow = 1;  // dropped: the host re-runs the item range in smaller slices
+        return;
     }
-    atomicAdd(&a.ctr->n_inline, 1ull);
+    const int ba = a.indptr[ra], ea = a.indptr[ra + 1];
+    const int bb = a.indptr[rb], eb = a.indptr[rb + 1];
+    const size_t o = (size_t)shard * a.cand_cap_shard + idx;
+    a.cand[o] = make_int4(ra, rb, ba, bb);
+    a.candk[o] = make_int2(ea - ba, eb - bb);
 }
 
-__device__ __forceinline__ void push_global(const PairArgs &a, int shard, int base, int i, int2 pq) {
-    int idx = base + i;
-    if (idx < a.cand_cap_shard) a.cand[(size_t)shard * a.cand_cap_shard + idx] = pq;
-    else verify_inline(a, pq.x, pq.y);  // queue full: settle the pair right here (slow but exact)
+// Second stage of the filter, one queued first-level hit per lane (run when a block flushes its LDS
+// queue, so the dependent global loads of 64 hits overlap instead of stalling the scan loop):
+// order / bounds / exact length band, then the 128-bit second-level signature.
+__device__ __forceinline__ bool second_level(const PairArgs &a, int p, int q) {
+    if (!(q > p && q < a.n && p < a.n)) return false;
+    if (a.ksorted[q] - a.ksorted[p] > a.d) return false;
+    const uint4 x = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)p * SIG2_WORDS);
+    const uint4 y = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)q * SIG2_WORDS);
+    int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+    return c <= a.d;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_prefilter<W, R>: the all-pairs kernel.  A work item is (row tile of 256*R length-sorted rows) x
-// (chunk of <= TC columns).  Each thread keeps R row signatures (W words each) in VGPRs; column
-// signatures are wave-uniform and arrive through scalar loads (SGPRs), CB columns per batch.  Per pair:
-// W x (v_xor + v_bcnt) and half a v_min3.  Only when some lane's batch minimum is <= d does the wave
-// rescan the batch, apply the exact band / order checks, the 128-bit second-level signature, and push
-// survivors into the block's LDS queue, flushed once per work item.
-// ------------------------------------------------------------------------------------------------
+// flush `cnt` queued (p,q) hits: filter, translate to row ids, append to the shard's global queue with
+// one global atomic per wave; a full global queue raises the overflow flag (host re-runs in slices).
+__device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, int cnt, int shard) {
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (threadIdx.x >> 6) * 64; i0 < cnt; i0 += 256) {
+        const int i = i0 + lane;
+        int2 pq = make_int2(0, 0);
+        bool pass = false;
+        if (i < cnt) {
+            pq = sbuf[i];
+            pass = second_level(a, pq.x, pq.y);
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (mask == 0ull) continue;
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&a.ctr->ncand[shard], (unsigned)__popcll(mask));
+        base = __shfl(base, 0);
+        if (pass) {
+            const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+            push_cand(a, shard, idx, a.perm[pq.x], a.perm[pq.y]);
+        }
+    }
+}
+
+// LDS queue full (very dense input): append the raw first-level hit to the global queue unfiltered;
+// k_verify's exact merge decides.
+__device__ __forceinline__ void push_raw(const PairArgs &a, int shard, int p, int q) {
+    if (!(q > p && q < a.n && p < a.n)) return;
+    const int idx = (int)atomicAdd(&a.ctr->ncand[shard], 1u);
+    push_cand(a, shard, idx, a.perm[p], a.perm[q]);
+}
+
 template <int W>
 __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32_t *b) {
     uint32_t c = 0;
@@ -524,20 +544,20 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
 
 template <int W, int R>
 __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ sig1,
-                                                    const uint32_t *__restrict__ sig2,
-                                                    const int *__restrict__ ksorted, const int4 *__restrict__ work,
-                                                    int n, int shard0, int nshards, PairArgs pa) {
+                                                    const int4 *__restrict__ work, int n, int shard0, int nshards,
+                                                    int w_begin, int w_end, PairArgs pa) {
     constexpr int CB = (W == 1) ? 16 : (W == 2 ? 8 : 4);  // columns per batch: 16 SGPRs of signature
+    constexpr int NG = 4, GC = CB / NG;                    // minima per group of GC columns
     __shared__ int2 sbuf[PF_LDS_QUEUE];
-    __shared__ int scount, sbase;
+    __shared__ int scount;
     const int tid = threadIdx.x;
     const uint32_t d = (uint32_t)pa.d;
-    const int n_work = (int)pa.ctr->n_work;
+    const int n_work = min((int)pa.ctr->n_work, w_end);
     const int qshard = blockIdx.x & (CAND_SHARDS - 1);
     if (tid == 0) scount = 0;
     __syncthreads();
     unsigned long long evaluated = 0;
-    for (int w = blockIdx.x * nshards + shard0; w < n_work; w += gridDim.x * nshards) {
+    for (int w = w_begin + blockIdx.x * nshards + shard0; w < n_work; w += gridDim.x * nshards) {
         const int4 it = work[w];
         const int row0 = it.x, cbeg = it.y, cend = it.z;
         uint32_t rs[R][W];
@@ -550,55 +570,58 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
 #pragma unroll
             for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)pc * W + x];
         }
+        uint32_t cs[CB * W];
+#pragma unroll
+        for (int x = 0; x < CB * W; x++) cs[x] = sig1[(size_t)cbeg * W + x];  // wave-uniform -> s_load
         for (int q0 = cbeg; q0 < cend; q0 += CB) {
-            uint32_t cs[CB * W];
+            uint32_t nx[CB * W];
 #pragma unroll
-            for (int x = 0; x < CB * W; x++) cs[x] = sig1[(size_t)q0 * W + x];  // uniform -> s_load
-            uint32_t m = 0xFFFFu;
+            for (int x = 0; x < CB * W; x++) nx[x] = sig1[(size_t)(q0 + CB) * W + x];  // prefetch (array is padded)
+            uint32_t mg[NG];
 #pragma unroll
-            for (int j = 0; j < CB; j++) {
+            for (int g = 0; g < NG; g++) {
+                mg[g] = 0xFFFFu;
 #pragma unroll
-                for (int r = 0; r < R; r++) m = min(m, sigdist<W>(rs[r], &cs[j * W]));
-            }
-            if (__builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
-#pragma unroll 1
-                for (int j = 0; j < CB; j++) {
-                    const int q = q0 + j;
-                    uint32_t cq[W];  // re-read (uniform): dynamic indexing would push cs[] out of SGPRs
+                for (int j = g * GC; j < (g + 1) * GC; j++) {
 #pragma unroll
-                    for (int x = 0; x < W; x++) cq[x] = sig1[(size_t)q * W + x];
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (sigdist<W>(rs[r], cq) <= d) {
-                            const int p = prow[r];
-                            if (q > p && q < n && p < n && ksorted[q] - ksorted[p] <= (int)d) {
-                                const uint32_t *a2 = sig2 + (size_t)p * SIG2_WORDS, *b2 = sig2 + (size_t)q * SIG2_WORDS;
-                                uint32_t c2 = 0;
-#pragma unroll
-                                for (int x = 0; x < SIG2_WORDS; x++) c2 += __popc(a2[x] ^ b2[x]);
-                                if (c2 <= d) {
-                                    int slot = atomicAdd(&scount, 1);
-                                    if (slot < PF_LDS_QUEUE) {
-                                        sbuf[slot] = make_int2(p, q);
-                                    } else {
-                                        int g = (int)atomicAdd(&pa.ctr->ncand[qshard], 1u);
-                                        push_global(pa, qshard, g, 0, make_int2(p, q));
-                                    }
-                                }
-                            }
-                        }
-                    }
+                    for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
                 }
             }
+            const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
+            if (__builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
+                // revisit only the column groups that hit; build a per-lane bit mask of the (column,row)
+                // hits (bit = j*R + r inside the batch), then drain it in ONE place (small code)
+                unsigned long long hm = 0ull;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (__builtin_amdgcn_ballot_w64(mg[g] <= d) != 0ull) {
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int j = (g + 1) * GC - 1; j >= g * GC; j--) {
+#pragma unroll
+                            for (int r = R - 1; r >= 0; r--)
+                                bits = (bits << 1) | (sigdist<W>(rs[r], &cs[j * W]) <= d ? 1u : 0u);
+                        }
+                        hm |= (unsigned long long)bits << (g * GC * R);
+                    }
+                }
+                while (hm) {
+                    const int b = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    const int p = row0 + (b % R) * 256 + tid, q = q0 + b / R;
+                    const int slot = atomicAdd(&scount, 1);
+                    if (slot < PF_LDS_QUEUE) sbuf[slot] = make_int2(p, q);
+                    else push_raw(pa, qshard, p, q);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < CB * W; x++) cs[x] = nx[x];
         }
         evaluated += (unsigned long long)(cend - cbeg);
         __syncthreads();
         const int cnt = min(scount, PF_LDS_QUEUE);
         if (cnt > 0) {  // block-uniform
-            if (tid == 0) sbase = (int)atomicAdd(&pa.ctr->ncand[qshard], (unsigned)cnt);
-            __syncthreads();
-            const int base = sbase;
-            for (int i = tid; i < cnt; i += 256) push_global(pa, qshard, base, i, sbuf[i]);
+            flush_hits(pa, sbuf, cnt, qshard);
             __syncthreads();
             if (tid == 0) scount = 0;
             __syncthreads();
@@ -608,99 +631,152 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_verify: one wave per candidate.  The longer row (B) is staged in the wave's LDS slice by a
-// coalesced load; every lane takes one element of the shorter row (A, 64 per step), finds its
+// k_verify: exact multiset distance of every queued candidate, one 16-lane group per candidate (four
+// per wave: the work is latency-bound — dependent memory round trips per pair — so the kernel is
+// organised for pairs in flight, not lanes per pair).  The longer row (B) is staged in the group's LDS
+// slice by a coalesced load; each lane takes elements of the shorter row (A, 16 per step), finds the
 // lower bound in B by binary search and checks the (token, repeat-rank) match; the ballot's popcount
-// gives the number of A elements without a partner.  |A delta B| = kA + kB - 2*matches <= d.
+// over the group's 16 bits counts A elements without a partner.  |A delta B| = kA + kB - 2*matches.
+// A pair farther apart than d is marked (row a = -1); k_union then hooks the surviving edges, one per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap) {
-    __shared__ uint32_t sB[4][VERIFY_LDS_ROW];
-    __shared__ unsigned int blk_edges;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    if (threadIdx.x == 0) blk_edges = 0;
-    __syncthreads();
-    unsigned int my_edges = 0;
-    for (int s = 0; s < CAND_SHARDS; s++) {
-        const int cnt = min((int)pa.ctr->ncand[s], pa.cand_cap_shard);
-        const int2 *cq = pa.cand + (size_t)s * pa.cand_cap_shard;
-        for (int c = gw; c < cnt; c += nw) {
-            const int2 pq = cq[c];
-            int ra = pa.perm[pq.x], rb = pa.perm[pq.y];
-            int ba = pa.indptr[ra], ka = pa.indptr[ra + 1] - ba;
-            int bb = pa.indptr[rb], kb = pa.indptr[rb + 1] - bb;
-            if (ka > kb) {  // A = shorter row
-                int t = ba; ba = bb; bb = t;
-                t = ka; ka = kb; kb = t;
+// the 8 shard queues seen as one index space: prefix of min(ncand[s], cap)
+struct ShardMap {
+    int pre[CAND_SHARDS + 1];
+};
+__device__ __forceinline__ ShardMap shard_map(const PairArgs &pa) {
+    const uint4 lo = *reinterpret_cast<const uint4 *>(&pa.ctr->ncand[0]);
+    const uint4 hi = *reinterpret_cast<const uint4 *>(&pa.ctr->ncand[4]);
+    const unsigned c[CAND_SHARDS] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    ShardMap m;
+    m.pre[0] = 0;
+#pragma unroll
+    for (int s = 0; s < CAND_SHARDS; s++) m.pre[s + 1] = m.pre[s] + (int)min(c[s], (unsigned)pa.cand_cap_shard);
+    return m;
+}
+__device__ __forceinline__ size_t shard_slot(const ShardMap &m, const PairArgs &pa, int c) {
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < CAND_SHARDS; t++) s += (c >= m.pre[t]) ? 1 : 0;
+    int base = m.pre[0];
+#pragma unroll
+    for (int t = 1; t < CAND_SHARDS; t++) base = (c >= m.pre[t]) ? m.pre[t] : base;
+    return (size_t)s * pa.cand_cap_shard + (size_t)(c - base);
+}
+
+__global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
+    __shared__ uint32_t sB[16][VERIFY_LDS_ROW];
+    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;           // 0..15 in the block
+    const int gsh = (lane >> 4) * 16;           // bit offset of this group inside the wave ballot
+    const int gg = blockIdx.x * 16 + grp, ng = gridDim.x * 16;
+    uint32_t *myB = sB[grp];
+    const ShardMap sm = shard_map(pa);
+    const int total = sm.pre[CAND_SHARDS];
+    for (int c = gg; c < total; c += ng) {
+        const size_t slot = shard_slot(sm, pa, c);
+        const int4 rec = pa.cand[slot];
+        const int2 kk = pa.candk[slot];
+        int ba = rec.z, ka = kk.x, bb = rec.w, kb = kk.y;
+        if (ka > kb) {  // A = shorter row
+            int t = ba; ba = bb; bb = t;
+            t = ka; ka = kb; kb = t;
+        }
+        const uint32_t *A = pa.cols + ba, *B = pa.cols + bb;
+        const int allowed = (pa.d - (kb - ka)) >> 1;  // A elements allowed to stay unmatched
+        bool ok = (kb - ka) <= pa.d;
+        const bool staged = kb <= VERIFY_LDS_ROW;
+        int miss = 0;
+        for (int i0 = 0; i0 < ka; i0 += 64) {  // 64 A elements per step: 4 per lane, all loads in flight at once
+            uint32_t x[4], xp[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = i0 + e * 16 + l16;
+                x[e] = (ok && i < ka) ? A[i] : 0u;
+                xp[e] = (ok && i < ka && i > 0) ? A[i - 1] : 0xFFFFFFFFu;
             }
-            const uint32_t *A = pa.cols + ba, *B = pa.cols + bb;
-            const int allowed = (pa.d - (kb - ka)) >> 1;  // A elements allowed to stay unmatched
-            bool ok = (kb - ka) <= pa.d;
-            const bool staged = kb <= VERIFY_LDS_ROW;
-            if (ok && staged) {
-                for (int j = lane; j < kb; j += 64) sB[wave][j] = B[j];
+            if (i0 == 0) {
+                if (ok && staged)
+                    for (int j = l16; j < kb; j += 16) myB[j] = B[j];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            int miss = 0;
-            for (int i0 = 0; ok && i0 < ka; i0 += 64) {
-                const int i = i0 + lane;
-                const bool valid = i < ka;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = i0 + e * 16 + l16;
+                const bool valid = ok && i < ka;
                 bool found = false;
                 if (valid) {
-                    const uint32_t x = A[i];
                     int r = 0;
-                    while (r < i && A[i - 1 - r] == x) r++;
+                    if (xp[e] == x[e]) {  // repeated token: rank inside its run
+                        r = 1;
+                        while (r < i && A[i - 1 - r] == x[e]) r++;
+                    }
                     int lo = 0, hi = kb;  // lower bound of x in B
                     if (staged) {
                         while (lo < hi) {
                             int mid = (lo + hi) >> 1;
-                            if (sB[wave][mid] < x) lo = mid + 1;
+                            if (myB[mid] < x[e]) lo = mid + 1;
                             else hi = mid;
                         }
-                        found = (lo + r < kb) && (sB[wave][lo + r] == x);
+                        found = (lo + r < kb) && (myB[lo + r] == x[e]);
                     } else {
                         while (lo < hi) {
                             int mid = (lo + hi) >> 1;
-                            if (B[mid] < x) lo = mid + 1;
+                            if (B[mid] < x[e]) lo = mid + 1;
                             else hi = mid;
                         }
-                        found = (lo + r < kb) && (B[lo + r] == x);
+                        found = (lo + r < kb) && (B[lo + r] == x[e]);
                     }
                 }
-                miss += __popcll(__builtin_amdgcn_ballot_w64(valid && !found));
-                if (miss > allowed) ok = false;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && !found);
+                miss += __popc((unsigned)((bal >> gsh) & 0xFFFFull));
             }
-            __builtin_amdgcn_wave_barrier();
-            if (ok && lane == 0) {
-                int r0 = pa.perm[pq.x], r1 = pa.perm[pq.y];
-                uf_union(pa.parent, r0, r1);
-                my_edges++;
-                if (edges) {
-                    unsigned long long e = atomicAdd(&pa.ctr->n_edges_cap, 1ull);
-                    if (e < (unsigned long long)edge_cap) edges[e] = make_int2(min(r0, r1), max(r0, r1));
-                }
-            }
+            if (miss > allowed) ok = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!ok && l16 == 0) pa.cand[slot].x = -1;
+    }
+}
+
+// k_union: one verified edge per lane -> lock-free hook (the dependent find/CAS chains of all edges overlap)
+__global__ __launch_bounds__(256) void k_union(PairArgs pa, int2 *edges, int edge_cap) {
+    const int gt = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+    unsigned int my_edges = 0;
+    const ShardMap sm = shard_map(pa);
+    const int total = sm.pre[CAND_SHARDS];
+    for (int c = gt; c < total; c += nt) {
+        const int4 rec = pa.cand[shard_slot(sm, pa, c)];
+        if (rec.x < 0) continue;
+        uf_union(pa.parent, rec.x, rec.y);
+        my_edges++;
+        if (edges) {
+            unsigned long long e = atomicAdd(&pa.ctr->n_edges_cap, 1ull);
+            if (e < (unsigned long long)edge_cap) edges[e] = make_int2(min(rec.x, rec.y), max(rec.x, rec.y));
         }
     }
-    if (lane == 0 && my_edges) atomicAdd(&blk_edges, my_edges);
+    for (int sft = 32; sft > 0; sft >>= 1) my_edges += __shfl_xor(my_edges, sft);
+    __shared__ unsigned int blk_edges;
+    if (threadIdx.x == 0) blk_edges = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && my_edges) atomicAdd(&blk_edges, my_edges);
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long nc = 0;
-        if (blockIdx.x == 0)
-            for (int s = 0; s < CAND_SHARDS; s++) nc += pa.ctr->ncand[s];
         if (blk_edges) atomicAdd(&pa.ctr->n_edges, (unsigned long long)blk_edges);
-        if (nc) atomicAdd(&pa.ctr->n_cand_total, nc);
+        if (blockIdx.x == 0 && total) atomicAdd(&pa.ctr->n_cand_total, (unsigned long long)total);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_flatten(int *parent, int n, int *labels) {
+// (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
+__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) labels[i] = uf_find(parent, i);
+    if (i >= n) return;
+    int cur = parent[i], next;
+    while (cur > (next = parent[cur])) cur = next;
+    labels[i] = cur;
 }
 
 __global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, int n_parts, Counters *ctr) {
@@ -738,7 +814,60 @@ int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st) {
     return 0;
 }
 
-int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*6 or NULL*/) {
+static PairArgs make_pair_args(const Plan &pl) {
+    PairArgs pa;
+    pa.indptr = pl.indptr;
+    pa.cols = pl.cols;
+    pa.perm = pl.perm;
+    pa.ksorted = pl.ksorted;
+    pa.sig2 = pl.sig2;
+    pa.n = pl.n;
+    pa.parent = pl.parent;
+    pa.cand = pl.cand;
+    pa.candk = pl.candk;
+    pa.cand_cap_shard = pl.cand_cap_shard;
+    pa.d = pl.d;
+    pa.ctr = pl.ctr;
+    return pa;
+}
+
+// prefilter + verify over work items [w_begin, w_end) of this shard
+int launch_pairs(const Plan &pl, int w_begin, int w_end, hipStream_t st, hipEvent_t *ev) {
+    const int n = pl.n;
+    PairArgs pa = make_pair_args(pl);
+    const int pf_grid = pl.pf_grid;
+    switch (pl.w1) {
+        case 1:
+            hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
+                               pl.n_shards, w_begin, w_end, pa);
+            break;
+        case 2:
+            hipLaunchKernelGGL((k_prefilter<2, PF_ROWS_W2>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
+                               pl.n_shards, w_begin, w_end, pa);
+            break;
+        default:
+            hipLaunchKernelGGL((k_prefilter<4, PF_ROWS_W4>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
+                               pl.n_shards, w_begin, w_end, pa);
+            break;
+    }
+    LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_union, dim3(pl.union_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap);
+    LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return 0;
+}
+
+int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
+    hipLaunchKernelGGL(k_flatten, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels);
+    LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[4], st);
+    return 0;
+}
+
+int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/) {
     const int n = pl.n;
     const int nb1024 = (n + 1023) / 1024;
     if (ev) (void)hipEventRecord(ev[0], st);
@@ -770,39 +899,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*6 or NULL*/
     }
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    PairArgs pa;
-    pa.indptr = pl.indptr;
-    pa.cols = pl.cols;
-    pa.perm = pl.perm;
-    pa.parent = pl.parent;
-    pa.cand = pl.cand;
-    pa.cand_cap_shard = pl.cand_cap_shard;
-    pa.d = pl.d;
-    pa.ctr = pl.ctr;
-    const int pf_grid = pl.pf_grid;
-    switch (pl.w1) {
-        case 1:
-            hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.sig2, pl.ksorted,
-                               pl.work, n, pl.shard, pl.n_shards, pa);
-            break;
-        case 2:
-            hipLaunchKernelGGL((k_prefilter<2, PF_ROWS_W2>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.sig2, pl.ksorted,
-                               pl.work, n, pl.shard, pl.n_shards, pa);
-            break;
-        default:
-            hipLaunchKernelGGL((k_prefilter<4, PF_ROWS_W4>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.sig2, pl.ksorted,
-                               pl.work, n, pl.shard, pl.n_shards, pa);
-            break;
-    }
-    LAUNCH_CHECK();
-    if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap);
-    LAUNCH_CHECK();
-    if (ev) (void)hipEventRecord(ev[3], st);
-    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, pl.parent, n, pl.labels);
-    LAUNCH_CHECK();
-    if (ev) (void)hipEventRecord(ev[4], st);
-    return 0;
+    if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
+    return launch_flatten(pl, st, ev);
 }
 
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,

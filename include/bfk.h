@@ -48,7 +48,7 @@ typedef struct bfk_stats {
     int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded) */
     int64_t n_candidates;    /* pairs that passed both signature levels and were merged exactly */
     int64_t n_edges;         /* candidates with exact distance <= max_dist */
-    int64_t n_inline;        /* candidates verified inline because the candidate buffer was full */
+    int64_t n_retry_slices;  /* >0: the candidate queue overflowed and the run was redone in this many slices */
     int32_t max_row_len;     /* largest multiset size k */
     int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
     int32_t n_work_items;    /* (row tile, column chunk) items in the band */

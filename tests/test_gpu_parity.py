@@ -31,7 +31,7 @@ def test_labels_match_reference_golden(name):
     labels, st = _lib.cluster_csr(g["indptr"], g["indices"], g["max_dist"])
     assert np.array_equal(labels, g["labels"])
     assert st["n_edges"] == len(g["edges"])  # every reference edge, and only those, passed the exact merge
-    assert st["n_inline"] == 0
+    assert st["n_retry_slices"] == 0
 
 
 @pytest.mark.parametrize("name", stage_names())
