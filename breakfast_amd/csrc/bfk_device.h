@@ -5,7 +5,8 @@
 
 namespace bfk {
 
-constexpr int HIST_LDS_BINS = 2048;    // row lengths below this are histogrammed in LDS
+constexpr int F_BUCKETS = 128;         // max f (hash-bit count) buckets per row length in the (k,f) sort key
+constexpr int PLAN_LDS_BINS = 10240;   // (k,f) bins mirrored in LDS by k_rowstat / k_plan (40 KiB)
 constexpr int SIG2_WORDS = 4;          // second-level signature: 128 bits
 constexpr int CAND_SHARDS = 8;         // candidate queue shards (block % 8 ~ XCD)
 constexpr int PF_LDS_QUEUE = 1024;     // per-block LDS candidate queue entries (8 KiB)
@@ -13,7 +14,7 @@ constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane gro
 constexpr int PF_ROWS_W1 = 4;          // rows per thread in k_prefilter by signature width
 constexpr int PF_ROWS_W2 = 4;
 constexpr int PF_ROWS_W4 = 2;
-constexpr int PF_TC = 512;             // columns per work item
+constexpr unsigned ITEM_OVH_UNITS = 2;  // unit-space price of switching work items (load balance only)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
 constexpr int LONG_LDS_CAP = 15360;    // tokens of a long row staged in LDS by k_canon_long (60 KiB)
 
@@ -22,7 +23,9 @@ enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 struct Counters {
     unsigned int ncand[CAND_SHARDS];
     int err;
-    unsigned int n_work;
+    unsigned int n_work;   // work items
+    unsigned int n_units;  // total units (batches of CB columns x one row tile)
+    unsigned int pad1;
     unsigned int n_long;
     int overflow;
     unsigned long long pairs_in_band;
@@ -30,22 +33,23 @@ struct Counters {
     unsigned long long n_cand_total;
     unsigned long long n_edges;
     unsigned long long n_edges_cap;
+    unsigned long long dbg[8];  // phase stamps of k_plan (s_memrealtime, 100 MHz), printed with BFK_DEBUG=1
 };
 
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
 struct Plan {
     int n, kcap, d, w1;
-    int tr, tc;
+    int tr, cb, fb, fshift;
     int shard, n_shards;
     int pf_grid, verify_grid, union_grid;
-    int work_cap, cand_cap_shard, edge_cap, long_lds_cap;
+    int item_cap, cand_cap_shard, edge_cap, long_lds_cap;
     const int *indptr;
     const uint32_t *indices;
     uint32_t *cols;
-    int *hist, *start, *cursor;
+    int *hist, *start, *rowbin, *rowrank, *blk_item;
     int *perm, *pos, *ksorted, *parent, *longrows;
     uint32_t *sig1, *sig2;
-    int4 *work;
+    int4 *items;
     int4 *cand;
     int2 *candk;
     int2 *edges;  // NULL unless edge capture is on
@@ -55,7 +59,7 @@ struct Plan {
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
-int launch_pairs(const Plan &pl, int w_begin, int w_end, hipStream_t st, hipEvent_t *ev);
+int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEvent_t *ev);
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
                  hipStream_t st);

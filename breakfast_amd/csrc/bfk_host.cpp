@@ -161,14 +161,17 @@ struct bfk_ctx {
     // workspace
     char *d_head = nullptr;  // Counters | hist[bins]
     int64_t bins_cap = 0;
-    int *d_start = nullptr, *d_cursor = nullptr;
+    int *d_start = nullptr;
+    int fb = F_BUCKETS, fshift = 0;
     uint32_t *d_cols = nullptr;
     int64_t cols_cap = 0;
     int *d_perm = nullptr, *d_pos = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
     uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr;
     int64_t rows_cap = 0;
-    int4 *d_work = nullptr;
-    int64_t work_cap = 0;
+    int4 *d_items = nullptr;
+    int64_t item_cap = 0;
+    int *d_rowbin = nullptr, *d_rowrank = nullptr, *d_blk = nullptr;
+    int64_t blk_cap = 0;
     int4 *d_cand = nullptr;
     int2 *d_candk = nullptr;
     int64_t candk_cap = 0;
@@ -234,9 +237,9 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,    c->d_start, c->d_cursor, c->d_cols, c->d_perm,
-                    c->d_pos,      c->d_ksorted,   c->d_parent,  c->d_longrows, c->d_sig1, c->d_sig2, c->d_work,
-                    c->d_cand,     c->d_candk,     c->d_edges,     c->d_small};
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start,    c->d_cols,   c->d_perm,   c->d_pos,
+                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_items,  c->d_rowbin,
+                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -272,11 +275,6 @@ extern "C" int bfk_ctx_set_edge_capture(bfk_ctx *c, int32_t enable) {
     return BFK_OK;
 }
 
-static int64_t work_items_bound(int64_t n, int tr, int tc) {
-    int64_t T = (n + tr - 1) / tr;
-    return T * ((n + tc - 1) / tc + 2) + 16;
-}
-
 static int ctx_size_cand(bfk_ctx *c, int64_t total) {
     if (total > c->cand_cap_total || !c->d_cand || !c->d_candk) {
         if (int rc = dev_realloc(&c->d_cand, &c->cand_cap_total, total)) return rc;
@@ -289,17 +287,22 @@ static int ctx_size_cand(bfk_ctx *c, int64_t total) {
 
 static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     const int64_t n = c->n, nnz = c->nnz;
-    const int64_t bins = (int64_t)c->kcap + 4 + std::max(d_hint, 64);
+    // (k,f) sort key: F_BUCKETS f-buckets per row length; f is shifted down for very long rows
+    // fb = largest power of two <= F_BUCKETS that keeps all bins in the 60 KiB LDS mirror (1 = length only)
+    c->fb = F_BUCKETS;
+    while (c->fb > 1 && ((int64_t)c->kcap + 1) * c->fb + 1 > PLAN_LDS_BINS) c->fb >>= 1;
+    c->fshift = 0;
+    while (((int64_t)c->kcap >> c->fshift) >= c->fb && c->fshift < 31) c->fshift++;
+    const int64_t bins = ((int64_t)c->kcap + 1) * c->fb + 2;
+    if (bins > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the (k,f) bin index");
     if (bins > c->bins_cap || !c->d_head) {
         if (c->d_head) (void)hipFree(c->d_head);
         if (c->d_start) (void)hipFree(c->d_start);
-        if (c->d_cursor) (void)hipFree(c->d_cursor);
         c->d_head = nullptr;
-        c->d_start = c->d_cursor = nullptr;
+        c->d_start = nullptr;
         c->bins_cap = 0;
         size_t head = sizeof(Counters) + (size_t)bins * 4;
-        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins * 4) != hipSuccess ||
-            hipMalloc((void **)&c->d_cursor, (size_t)bins * 4) != hipSuccess)
+        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins * 4) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins;
     }
@@ -312,6 +315,8 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_rowbin, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
         cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
         if (rc) return BFK_ENOMEM;
@@ -320,12 +325,15 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         HIP_TRY(hipMemsetAsync(c->d_sig1, 0xFF, (size_t)(want * 4 + 16) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_sig2, 0xFF, (size_t)(want * SIG2_WORDS + 16) * 4, c->stream));
     }
-    // all-pairs upper bound for the smallest row tile (R=2 -> 512 rows)
-    if (int rc = dev_realloc(&c->d_work, &c->work_cap, work_items_bound(n, 256 * PF_ROWS_W4, PF_TC))) return rc;
+    {   // work items: one per (row tile, column length) pair that has a band: the k-spans of the tiles
+        // telescope, so <= (kcap+1) + T*(d+2); T for the smallest row tile (256*PF_ROWS_W4)
+        const int64_t T = (n + 256 * PF_ROWS_W4 - 1) / (256 * PF_ROWS_W4);
+        const int64_t want = (int64_t)c->kcap + 2 + T * ((int64_t)std::min(d_hint, c->kcap + 1) + 3) + 64;
+        if (int rc = dev_realloc(&c->d_items, &c->item_cap, want, 1.25)) return rc;
+    }
     {
-        // per shard: 4N pairs (8 shards -> 32N), and never less than one work item's pair slots, so that a
-        // single-item slice of the overflow recovery always fits
-        int64_t want = std::max<int64_t>((int64_t)256 * PF_ROWS_W1 * PF_TC, 4 * n + 4096);
+        // per shard: 4N pairs (8 shards -> 32N), and never less than one unit's pair slots
+        int64_t want = std::max<int64_t>((int64_t)256 * PF_ROWS_W1 * 16, 4 * n + 4096);
         if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;
@@ -393,8 +401,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     c->last_shards = n_shards;
     c->last_w1 = sig_words_for(max_dist);
     if (c->n == 0) return BFK_OK;
-    if ((int64_t)c->kcap + 4 + max_dist > c->bins_cap)
-        if (int rc = ctx_size_workspace(c, max_dist)) return rc;
+    if (int rc = ctx_size_workspace(c, max_dist)) return rc;  // no-op unless max_dist needs a longer item list
     if (c->edge_capture) {
         if (int rc = dev_realloc(&c->d_edges, &c->edge_cap, c->cand_cap_shard * CAND_SHARDS)) return rc;
     }
@@ -405,13 +412,16 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.w1 = c->last_w1;
     const int R = pl.w1 == 1 ? PF_ROWS_W1 : (pl.w1 == 2 ? PF_ROWS_W2 : PF_ROWS_W4);
     pl.tr = 256 * R;
-    pl.tc = PF_TC;
+    pl.cb = pl.w1 == 1 ? 16 : (pl.w1 == 2 ? 8 : 4);
+    pl.fb = c->fb;
+    pl.fshift = c->fshift;
     pl.shard = shard;
     pl.n_shards = n_shards;
-    pl.pf_grid = 2048;
+    pl.pf_grid = 1280;  // 256 CUs x 5 resident blocks (84 VGPRs): every block gets an equal slice of the units
     pl.verify_grid = 2048;
     pl.union_grid = 512;
-    pl.work_cap = (int)std::min<int64_t>(c->work_cap, INT32_MAX);
+    pl.item_cap = (int)std::min<int64_t>(c->item_cap, INT32_MAX);
+    if (int rc = dev_realloc(&c->d_blk, &c->blk_cap, (int64_t)n_shards * pl.pf_grid)) return rc;
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
     pl.long_lds_cap = LONG_LDS_CAP;
@@ -421,7 +431,9 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.ctr = (Counters *)c->d_head;
     pl.hist = (int *)(c->d_head + sizeof(Counters));
     pl.start = c->d_start;
-    pl.cursor = c->d_cursor;
+    pl.rowbin = c->d_rowbin;
+    pl.rowrank = c->d_rowrank;
+    pl.blk_item = c->d_blk;
     pl.perm = c->d_perm;
     pl.pos = c->d_pos;
     pl.ksorted = c->d_ksorted;
@@ -429,13 +441,13 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.longrows = c->d_longrows;
     pl.sig1 = c->d_sig1;
     pl.sig2 = c->d_sig2;
-    pl.work = c->d_work;
+    pl.items = c->d_items;
     pl.cand = c->d_cand;
     pl.candk = c->d_candk;
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
     pl.labels = (int *)d_labels_out;
     c->plan = pl;
-    HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)(c->kcap + 1) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + ((size_t)(c->kcap + 1) * c->fb + 2) * 4, c->stream));
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
     if (int e = launch_pipeline(pl, c->stream, evs))
         return fail(BFK_EHIP, std::string("kernel launch: ") + hipGetErrorString((hipError_t)e));
@@ -459,12 +471,14 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
 // already holds every edge that was verified, the dropped ones are recovered by re-running prefilter +
 // verify over slices of the work list small enough for the queue, halving a slice that still overflows.
 // Unions are idempotent, so re-verifying pairs is harmless.  Synchronous (called from bfk_ctx_sync).
-static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {
+static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  // slices are unit ranges
     Plan &pl = c->plan;
-    const int n_work = (int)h->n_work;
+    const unsigned U = h->n_units;
+    const int ulo = (int)(((unsigned long long)U * pl.shard) / pl.n_shards);
+    const int uhi = (int)(((unsigned long long)U * (pl.shard + 1)) / pl.n_shards);
     std::vector<std::pair<int, int>> todo;
-    const int step0 = std::max(1, n_work / 16);
-    for (int b = n_work; b > 0; b -= step0) todo.push_back({std::max(0, b - step0), b});
+    const int step0 = std::max(1, (uhi - ulo) / 16);
+    for (int b = uhi; b > ulo; b -= step0) todo.push_back({std::max(ulo, b - step0), b});
     h->n_edges = h->n_cand_total = h->n_edges_cap = h->pairs_filtered = 0;
     unsigned long long edges_acc = 0, cand_acc = 0, filt_acc = 0;
     while (!todo.empty()) {
@@ -521,8 +535,11 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
         if (h.err & ERR_ROWLEN) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
-        if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow");
+        if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
+        if (getenv("BFK_DEBUG"))
+            fprintf(stderr, "[bfk] k_plan phases (us): scan %.1f stat %.1f tiles %.1f blk %.1f\n", (h.dbg[1] - h.dbg[0]) / 100.0,
+                    (h.dbg[2] - h.dbg[1]) / 100.0, (h.dbg[3] - h.dbg[2]) / 100.0, (h.dbg[4] - h.dbg[3]) / 100.0);
         int64_t retry_slices = 0;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;

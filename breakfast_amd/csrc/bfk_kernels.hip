@@ -1,9 +1,9 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
 // Pipeline (one stream, no host round trip between kernels):
-//   k_hist      row lengths k_i -> histogram (LDS-aggregated), parent[i] = i
-//   k_plan      scan -> start[k] (rows sorted by length), band work list of (row tile x column chunk) items
-//   k_scatter   counting-sort scatter: perm / pos / ksorted
+//   k_rowstat   per row: length k, hash-bit count f -> (k,f) bin, rank in bin (one atomic), parent[i] = i
+//   k_plan      scan -> start[bin] (rows ordered by (k,f)); per row tile the column ranges of its (k,f) band
+//               -> work items, cut into equal unit slices for the prefilter's blocks
 //   k_canon     one wave per row: bitonic sort of the token ids in registers, duplicate ranks,
 //               two XOR-parity signatures (sum_duplicates + prefilter keys), written in length order
 //   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
@@ -94,175 +94,267 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_hist: histogram of row lengths.  Global atomics on ~50 hot bins would serialise (one word takes
-// ~90 atomics/us), so each 1024-row block aggregates in LDS and flushes one atomic per non-empty bin.
+// Sort key.  Rows are ordered by (k, f): k = multiset size, f = number of tokens whose hash bit is set
+// (quantised to FB buckets).  Both are 1-Lipschitz in the distance: a pair with |A\B| = a, |B\A| = b,
+// a + b <= d, k_B - k_A = delta >= 0 has a <= (d - delta)/2, b = a + delta and f_B - f_A in [-a, b].
+// So for a block of length-sorted rows the rows that can be within d form, per column length k', ONE
+// contiguous range of the (k', f) order — the "band" the prefilter scans.  With f ~ Binomial(k, 1/2) this
+// cuts the pairs to evaluate by ~5-8x at d = 1 compared with the reference's length-only band.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ indptr, int n, int kcap, int *hist, int *parent,
-                                                Counters *ctr) {
-    __shared__ int lh[HIST_LDS_BINS];
-    for (int b = threadIdx.x; b < HIST_LDS_BINS; b += 1024) lh[b] = 0;
+__device__ __forceinline__ uint32_t fbit(uint32_t x) { return (x * 0xB5297A4Du) >> 31; }
+
+// k_rowstat: one thread per row: k, f -> bin = k*FB + fq, and the row's rank inside its bin.
+// ~100 rows share a bin, and returning global atomics on one word serialise, so a 1024-thread block
+// ranks its 1024 rows in an LDS copy of the histogram and reserves one range per touched bin with a
+// single global atomic (bins beyond the LDS copy fall back to per-row global atomics).  parent[i] = i.
+__global__ __launch_bounds__(1024) void k_rowstat(const int *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                   int n, int kcap, int fb, int fshift, int lds_bins, int *hist,
+                                                   int *rowbin, int *rowrank, int *parent, Counters *ctr) {
+    extern __shared__ __attribute__((aligned(16))) int lh[];
+    for (int b = threadIdx.x; b < lds_bins; b += 1024) lh[b] = 0;
     __syncthreads();
-    int i = blockIdx.x * 1024 + threadIdx.x;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int bin = -1, rank = 0;
     if (i < n) {
-        int k = indptr[i + 1] - indptr[i];
-        parent[i] = i;
+        const int b = indptr[i];
+        int k = indptr[i + 1] - b;
         if (k < 0 || k > kcap) {
             atomicOr(&ctr->err, ERR_ROWLEN);
             k = k < 0 ? 0 : kcap;
         }
-        if (k < HIST_LDS_BINS) atomicAdd(&lh[k], 1);
-        else atomicAdd(&hist[k], 1);
+        const uint32_t *row = indices + b;
+        int f = 0, j = 0;
+        for (; j + 4 <= k; j += 4) f += (int)(fbit(row[j]) + fbit(row[j + 1]) + fbit(row[j + 2]) + fbit(row[j + 3]));
+        for (; j < k; j++) f += (int)fbit(row[j]);
+        bin = k * fb + min(f >> fshift, fb - 1);
+        rank = bin < lds_bins ? atomicAdd(&lh[bin], 1) : atomicAdd(&hist[bin], 1);
+        parent[i] = i;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < HIST_LDS_BINS && b <= kcap; b += 1024) {
-        int c = lh[b];
-        if (c) atomicAdd(&hist[b], c);
+    for (int b = threadIdx.x; b < lds_bins; b += 1024) {
+        const int c = lh[b];
+        if (c) lh[b] = atomicAdd(&hist[b], c);  // base of this block's range in the bin
+    }
+    __syncthreads();
+    if (i < n) {
+        rowbin[i] = bin;
+        rowrank[i] = rank + (bin < lds_bins ? lh[bin] : 0);
     }
 }
 
-// block-wide exclusive scan of one 1024-chunk held one value per thread; returns exclusive prefix,
-// *total gets the chunk sum.  tmp: 32 ints of LDS.
-__device__ __forceinline__ int block_excl_scan_1024(int v, int *tmp, int *total) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
+// block-wide exclusive scan (1024 threads, one 64-bit value each); tmp: 40 x u64 of LDS
+__device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long *tmp,
+                                                                   unsigned long long *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
     for (int s = 1; s < 64; s <<= 1) {
-        int y = __shfl_up(inc, s);
+        unsigned long long y = __shfl_up(inc, s);
         if (lane >= s) inc += y;
     }
     if (lane == 63) tmp[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        int w = lane < 16 ? tmp[lane] : 0;
-        int winc = w;
+        unsigned long long w = lane < 16 ? tmp[lane] : 0ull;
+        unsigned long long winc = w;
         for (int s = 1; s < 16; s <<= 1) {
-            int y = __shfl_up(winc, s);
+            unsigned long long y = __shfl_up(winc, s);
             if (lane >= s) winc += y;
         }
         if (lane < 16) tmp[16 + lane] = winc - w;
         if (lane == 15) tmp[32] = winc;
     }
     __syncthreads();
-    int res = inc - v + tmp[16 + wave];
+    unsigned long long res = inc - v + tmp[16 + wave];
     *total = tmp[32];
     __syncthreads();
     return res;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_plan (one block): start[] = exclusive scan of hist (bins 0..kcap), padded with N up to kcap+1+d;
-// cursor[] = copy for the scatter; then the band work list: for every row tile the column range
-// [tile row0, first position whose length exceeds k_last + d) cut into chunks of TC columns.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_plan(const int *__restrict__ hist, int n, int kcap, int d, int *start,
-                                                int *cursor, int tr, int tc, int4 *work, int work_cap, Counters *ctr) {
-    __shared__ int tmp[40];
-    __shared__ int carry_s;
-    const int nb = kcap + 1;  // bins 0..kcap
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        int b = base + threadIdx.x;
-        int v = b < nb ? hist[b] : 0;
-        int tot;
-        int ex = block_excl_scan_1024(v, tmp, &tot);
-        int carry = carry_s;
-        if (b < nb) {
-            start[b] = carry + ex;
-            cursor[b] = carry + ex;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
+struct PlanArgs {
+    int lds_bins;      // entries of start[] mirrored in LDS (dynamic shared memory)
+    const int *hist;
+    int *start;        // bins + 1
+    int4 *items;       // {row0, cbeg, cend, ustart}
+    int *blk_item;     // first item of every (virtual) block
+    Counters *ctr;
+    int n, kcap, fb, fshift, d, tr, cb, nvblocks, item_cap;
+};
+
+__device__ __forceinline__ int plan_start(const PlanArgs &a, const int *s_start, int b) {
+    return b < a.lds_bins ? s_start[b] : ld_agent(a.start + b);
+}
+
+// column range (in sorted positions) a tile of rows [row0, ..] with first/last bins (k_lo,f_lo),(k_hi,f_hi)
+// has to scan among the rows of length kp; returns false if empty
+__device__ __forceinline__ bool tile_range(const PlanArgs &a, const int *s_start, int row0, int k_lo, int f_lo, int k_hi, int f_hi, int kp,
+                                           int *cb, int *ce) {
+    int fa = 0x7fffffff, fz = -0x7fffffff;
+    const int S1 = (1 << a.fshift) - 1;
+    for (int delta = 0; delta <= a.d; delta++) {
+        const int k = kp - delta;
+        if (k < k_lo || k > k_hi) continue;
+        const int rmin = (k == k_lo) ? f_lo : 0, rmax = (k == k_hi) ? f_hi : a.fb - 1;
+        const int amax = (a.d - delta) >> 1, bmax = amax + delta;
+        fa = min(fa, rmin - ((amax + S1) >> a.fshift));
+        fz = max(fz, rmax + ((bmax + S1) >> a.fshift));
     }
-    for (int b = nb + threadIdx.x; b <= nb + d + 1; b += 1024) start[b] = n;
-    // in-band unordered pairs: sum_k c_k(c_k-1)/2 + sum_{k<k'<=k+d} c_k c_k'
-    {
-        unsigned long long acc = 0;
-        for (int k = threadIdx.x; k < nb; k += 1024) {
-            unsigned long long c = (unsigned long long)hist[k];
-            if (!c) continue;
-            unsigned long long s = 0;
-            for (int k2 = k + 1; k2 <= k + d && k2 < nb; k2++) s += (unsigned long long)hist[k2];
-            acc += c * (c - 1) / 2 + c * s;
-        }
-        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&ctr->pairs_in_band, acc);
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int T = (n + tr - 1) / tr;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        int t = base + threadIdx.x;
-        int nch = 0, cend = 0, row0 = 0;
-        if (t < T) {
-            row0 = t * tr;
-            int plast = min(n, row0 + tr) - 1;
-            // bin holding position plast: largest k with start[k] <= plast
-            int lo = 0, hi = nb - 1;
-            while (lo < hi) {
-                int mid = (lo + hi + 1) >> 1;
-                if (start[mid] <= plast) lo = mid;
-                else hi = mid - 1;
-            }
-            cend = start[min(lo + d, kcap) + 1];
-            nch = (cend - row0 + tc - 1) / tc;
-        }
-        int tot;
-        int ex = block_excl_scan_1024(nch, tmp, &tot);
-        int off = carry_s + ex;
-        if (t < T) {
-            for (int c = 0; c < nch; c++) {
-                int w = off + c;
-                if (w < work_cap) work[w] = make_int4(row0, row0 + c * tc, min(cend, row0 + (c + 1) * tc), 0);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int nw = carry_s;
-        if (nw > work_cap) {
-            atomicOr(&ctr->err, ERR_WORKCAP);
-            nw = work_cap;
-        }
-        ctr->n_work = nw;
-    }
+    if (fa > fz) return false;
+    fa = max(fa, 0);
+    fz = min(fz, a.fb - 1);
+    const int c0 = max(plan_start(a, s_start, kp * a.fb + fa), row0);  // q > p >= row0
+    const int c1 = plan_start(a, s_start, kp * a.fb + fz + 1);
+    *cb = c0;
+    *ce = c1;
+    return c1 > c0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scatter: counting-sort scatter by length (order inside a length bin is arbitrary; labels are
-// canonical in row-index space so the permutation is unobservable).  Ranks come from LDS atomics,
-// one global atomic per (block, non-empty bin) reserves the range.
+// k_plan (one block): start[] = exclusive scan of the (k,f) histogram; then for every tile of TR sorted
+// rows the column ranges it must scan (one per column length) -> work items with a running count of
+// "units" (one unit = one batch of CB columns against the tile); the units are what the prefilter's
+// blocks divide among themselves, so every block gets the same amount of work.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scatter(const int *__restrict__ indptr, int n, int kcap, int *cursor,
-                                                   int *perm, int *pos, int *ksorted) {
-    __shared__ int lh[HIST_LDS_BINS];
-    for (int b = threadIdx.x; b < HIST_LDS_BINS; b += 1024) lh[b] = 0;
+__global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int s_start[];
+    __shared__ unsigned long long tmp[40];
+#define PLAN_STAMP(i) if (threadIdx.x == 0) a.ctr->dbg[i] = wall_clock64();
+    PLAN_STAMP(0)
+    const int bins = (a.kcap + 1) * a.fb;
+    const int per = (bins + 1023) / 1024;
+    {   // scan of the histogram.  Bins below lds_bins are staged in LDS with coalesced loads (a strided
+        // per-thread walk over global memory would be ~2*per dependent round trips), scanned there, and
+        // written back coalesced; each thread owns `per` consecutive bins.
+        const int nl = min(bins, a.lds_bins);
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nl; b += 1024) s_start[b] = a.hist[b];
+        __syncthreads();
+        const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
+        unsigned long long sum = 0;
+        for (int b = b0; b < b1; b++) sum += (unsigned)(b < nl ? s_start[b] : a.hist[b]);
+        unsigned long long tot;
+        unsigned long long ex = block_excl_scan_1024(sum, tmp, &tot);
+        int run = (int)ex;
+        for (int b = b0; b < b1; b++) {
+            const int c = b < nl ? s_start[b] : a.hist[b];
+            if (b < nl) s_start[b] = run;
+            else a.start[b] = run;
+            run += c;
+        }
+        if (threadIdx.x == 0) {
+            a.start[bins] = a.n;
+            if (bins < a.lds_bins) s_start[bins] = a.n;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nl; b += 1024) a.start[b] = s_start[b];
+    }
+    __threadfence_block();
     __syncthreads();
-    int i = blockIdx.x * 1024 + threadIdx.x;
-    int k = 0, lr = 0;
-    bool in_lds = false;
-    if (i < n) {
-        k = indptr[i + 1] - indptr[i];
-        k = k < 0 ? 0 : (k > kcap ? kcap : k);
-        in_lds = k < HIST_LDS_BINS;
-        if (in_lds) lr = atomicAdd(&lh[k], 1);
+    PLAN_STAMP(1)
+    {   // statistic: unordered pairs inside the reference's length band  sum_k c_k(c_k-1)/2 + sum_{k<k'<=k+d} c_k c_k'
+        unsigned long long acc = 0;
+        for (int k = threadIdx.x; k <= a.kcap; k += 1024) {
+            const unsigned long long c =
+                (unsigned)(plan_start(a, s_start, (k + 1) * a.fb) - plan_start(a, s_start, k * a.fb));
+            if (!c) continue;
+            const int k2 = min(k + a.d, a.kcap);
+            const unsigned long long s =
+                (unsigned)(plan_start(a, s_start, (k2 + 1) * a.fb) - plan_start(a, s_start, (k + 1) * a.fb));
+            acc += c * (c - 1) / 2 + c * s;
+        }
+        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&a.ctr->pairs_in_band, acc);
+    }
+    PLAN_STAMP(2)
+    // tiles -> (tile, column length) candidates -> non-empty ranges = work items.  Flattened so that every
+    // range is evaluated by its own thread (a per-tile loop over column lengths runs at single-wave
+    // latency: ~20 us at 100k rows).
+    __shared__ int4 s_tile[1024];
+    __shared__ int s_cpre[1025];
+    const int T = (a.n + a.tr - 1) / a.tr;
+    unsigned long long carry_i = 0, carry_u = 0;
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + threadIdx.x;
+        int nk = 0;
+        if (t < T) {
+            const int row0 = t * a.tr;
+            const int plast = min(a.n, row0 + a.tr) - 1;
+            int lo = 0, hi = bins - 1;  // bin of a position p: largest b with start[b] <= p
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (plan_start(a, s_start, mid) <= row0) lo = mid;
+                else hi = mid - 1;
+            }
+            const int blo = lo;
+            hi = bins - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (plan_start(a, s_start, mid) <= plast) lo = mid;
+                else hi = mid - 1;
+            }
+            const int k_lo = blo / a.fb, k_hi = lo / a.fb;
+            s_tile[threadIdx.x] = make_int4(k_lo, blo - k_lo * a.fb, k_hi, lo - k_hi * a.fb);
+            nk = min(k_hi + a.d, a.kcap) - k_lo + 1;
+        }
+        unsigned long long totc;
+        const unsigned long long exc = block_excl_scan_1024((unsigned long long)nk, tmp, &totc);
+        s_cpre[threadIdx.x] = (int)exc;
+        if (threadIdx.x == 0) s_cpre[1024] = (int)totc;
+        __syncthreads();
+        const int ntile = min(1024, T - base), C = (int)totc;
+        for (int cbase = 0; cbase < C; cbase += 1024) {
+            const int c = cbase + threadIdx.x;
+            int row0 = 0, cb = 0, ce = 0;
+            bool has = false;
+            if (c < C) {
+                int lo = 0, hi = ntile - 1;  // tile of candidate c: largest tt with cpre[tt] <= c
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_cpre[mid] <= c) lo = mid;
+                    else hi = mid - 1;
+                }
+                const int4 ti = s_tile[lo];
+                row0 = (base + lo) * a.tr;
+                has = tile_range(a, s_start, row0, ti.x, ti.y, ti.z, ti.w, ti.x + (c - s_cpre[lo]), &cb, &ce);
+            }
+            const unsigned nun = has ? ITEM_OVH_UNITS + (unsigned)((ce - (cb & ~(a.cb - 1)) + a.cb - 1) / a.cb) : 0u;
+            unsigned long long tot_i, tot_u;
+            const unsigned long long ex_i = block_excl_scan_1024(has ? 1ull : 0ull, tmp, &tot_i);
+            const unsigned long long ex_u = block_excl_scan_1024((unsigned long long)nun, tmp, &tot_u);
+            if (has) {
+                const unsigned long long w = carry_i + ex_i;
+                if (w < (unsigned long long)a.item_cap) a.items[w] = make_int4(row0, cb, ce, (int)(unsigned)(carry_u + ex_u));
+            }
+            carry_i += tot_i;  // the scan returns the same totals to all threads
+            carry_u += tot_u;
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    PLAN_STAMP(3)
+    const int n_items = (int)min(carry_i, (unsigned long long)0x7fffffff);
+    const unsigned U = (unsigned)carry_u;
+    if (threadIdx.x == 0) {
+        if (n_items > a.item_cap || carry_u >= 0x7fffffffull) atomicOr(&a.ctr->err, ERR_WORKCAP);
+        a.ctr->n_work = (unsigned)min(n_items, a.item_cap);
+        a.ctr->n_units = U;
+    }
+    if (n_items > a.item_cap || U == 0 || carry_u >= 0x7fffffffull) return;
+    // first item of every virtual block: block vb starts at unit floor(vb * U / nvblocks)
+    for (int w = threadIdx.x; w < n_items; w += 1024) {
+        const int *ip = reinterpret_cast<const int *>(&a.items[w]);  // written by this block: bypass L1
+        const int4 it = make_int4(0, ld_agent(ip + 1), ld_agent(ip + 2), ld_agent(ip + 3));
+        const unsigned ua = (unsigned)it.w;
+        const unsigned ub = ua + ITEM_OVH_UNITS + (unsigned)((it.z - (it.y & ~(a.cb - 1)) + a.cb - 1) / a.cb);
+        unsigned vb = (unsigned)(((unsigned long long)ua * a.nvblocks + U - 1) / U);
+        while (vb < (unsigned)a.nvblocks && (unsigned)(((unsigned long long)vb * U) / a.nvblocks) < ub) {
+            a.blk_item[vb] = w;
+            vb++;
+        }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < HIST_LDS_BINS && b <= kcap; b += 1024) {
-        int c = lh[b];
-        if (c) lh[b] = atomicAdd(&cursor[b], c);
-    }
-    __syncthreads();
-    if (i < n) {
-        int p = in_lds ? lh[k] + lr : atomicAdd(&cursor[k], 1);
-        perm[p] = i;
-        pos[i] = p;
-        ksorted[p] = k;
-    }
+    PLAN_STAMP(4)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,8 +363,84 @@ __global__ __launch_bounds__(1024) void k_scatter(const int *__restrict__ indptr
 // signatures.  Writes the canonical row (sorted, repeats kept) to cols and the signatures at the row's
 // length-sorted position.
 // ------------------------------------------------------------------------------------------------
+// cross-lane exchange x[lane ^ STRIDE] without the LDS crossbar: ds_bpermute costs ~26 cycles per
+// wave-instruction per SIMD on gfx950 (tools/ubench/valu_rate.hip), a DPP move ~4, v_permlane*_swap ~8.
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
+    if constexpr (STRIDE == 1) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    } else if constexpr (STRIDE == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    } else if constexpr (STRIDE == 4) {
+        // banks 0,2 of each 16-lane row read lane+4 (row_shl:4), banks 1,3 read lane-4 (row_shr:4)
+        int y = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp(y, (int)x, 0x114, 0xF, 0xA, false);
+    } else if constexpr (STRIDE == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    } else if constexpr (STRIDE == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // {x0,x0,x2,x2}, {x1,x1,x3,x3}
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // {lo,lo}, {hi,hi}
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
+// XOR of x over the 64 lanes, valid in lane 63 (DPP prefix within rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t x) {
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8 -> lane 15 of each row
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast15 into rows 1,3
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);  // row_bcast31 into rows 2,3
+    return x;
+}
+
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_step(uint32_t (&x)[E], int lane) {
+    if constexpr (STRIDE >= 64) {
+        constexpr int es = STRIDE >> 6;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if ((e & es) == 0) {
+                const int e2 = e | es;
+                const bool asc = (((e * 64) & SIZE) == 0);
+                uint32_t lo = min(x[e], x[e2]), hi = max(x[e], x[e2]);
+                x[e] = asc ? lo : hi;
+                x[e2] = asc ? hi : lo;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t y = lane_xor<STRIDE>(x[e], lane);
+            const bool asc = ((((e * 64) + lane) & SIZE) == 0);
+            const bool lower = ((lane & STRIDE) == 0);
+            x[e] = (lower == asc) ? min(x[e], y) : max(x[e], y);
+        }
+    }
+}
+
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&x)[E], int lane) {
+    bitonic_step<E, SIZE, STRIDE>(x, lane);
+    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, (STRIDE >> 1)>(x, lane);
+}
+
+template <int E, int SIZE>
+__device__ __forceinline__ void bitonic_all(uint32_t (&x)[E], int lane) {
+    if constexpr (SIZE > 2) bitonic_all<E, (SIZE >> 1)>(x, lane);
+    bitonic_merge<E, SIZE, (SIZE >> 1)>(x, lane);
+}
+
 template <int E>
 __device__ __forceinline__ void wave_bitonic(uint32_t (&x)[E], int lane) {
+    bitonic_all<E, 64 * E>(x, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic_bpermute(uint32_t (&x)[E], int lane) {
 #pragma unroll
     for (int size = 2; size <= 64 * E; size <<= 1) {
 #pragma unroll
@@ -318,9 +486,9 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
 #pragma unroll
     for (int e = 0; e < E; e++) {
         int j = e * 64 + lane;
-        uint32_t prev = __shfl_up(x[e], 1);
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[e], 0x138, 0xF, 0xF, false);  // wave_shr:1
         if (e > 0) {
-            uint32_t tail = __shfl(x[e - 1], 63);
+            uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)x[e - 1], 63);
             if (lane == 0) prev = tail;
         }
         bool eq = (j > 0) && (j < k) && (prev == x[e]);
@@ -364,13 +532,10 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
         }
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
+    for (int w = 0; w < W1; w++) s1[w] = wave_xor_to_lane63(s1[w]);
 #pragma unroll
-        for (int w = 0; w < W1; w++) s1[w] ^= __shfl_xor(s1[w], s);
-#pragma unroll
-        for (int w = 0; w < SIG2_WORDS; w++) s2[w] ^= __shfl_xor(s2[w], s);
-    }
-    if (lane == 0) {
+    for (int w = 0; w < SIG2_WORDS; w++) s2[w] = wave_xor_to_lane63(s2[w]);
+    if (lane == 63) {
 #pragma unroll
         for (int w = 0; w < W1; w++) sig1_out[w] = s1[w];
 #pragma unroll
@@ -380,17 +545,34 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
 
 template <int W1>
 __global__ __launch_bounds__(256) void k_canon(const int *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                int n, const int *__restrict__ pos, uint32_t *__restrict__ cols,
-                                                uint32_t *__restrict__ sig1, uint32_t *__restrict__ sig2,
-                                                int *longrows, Counters *ctr) {
+                                                int n, const int *__restrict__ start, const int *__restrict__ rowbin,
+                                                const int *__restrict__ rowrank, int *__restrict__ pos,
+                                                int *__restrict__ perm, int *__restrict__ ksorted,
+                                                uint32_t *__restrict__ cols, uint32_t *__restrict__ sig1,
+                                                uint32_t *__restrict__ sig2, int *longrows, Counters *ctr) {
     __shared__ uint32_t lds_rows[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
-    for (int i = blockIdx.x * 4 + wave; i < n; i += nwaves) {
-        int b = indptr[i];
-        int k = indptr[i + 1] - b;
-        if (k < 0) k = 0;
-        int p = pos[i];
+    int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    int b = indptr[i], e = indptr[i + 1], bin = rowbin[i], rk = rowrank[i];
+    while (true) {
+        // the next row's metadata is fetched while this row is sorted (one dependent round trip fewer per row)
+        const int inext = i + nwaves;
+        int nb = 0, ne = 0, nbin = 0, nrk = 0;
+        if (inext < n) {
+            nb = indptr[inext];
+            ne = indptr[inext + 1];
+            nbin = rowbin[inext];
+            nrk = rowrank[inext];
+        }
+        const int k = max(e - b, 0);
+        const int p = start[bin] + rk;  // counting-sort position in (k, f) order
+        if (lane == 0) {
+            pos[i] = p;
+            perm[p] = i;
+            ksorted[p] = k;
+        }
         const uint32_t *src = indices + b;
         uint32_t *dst = cols + b;
         uint32_t *o1 = sig1 + (size_t)p * W1, *o2 = sig2 + (size_t)p * SIG2_WORDS;
@@ -398,6 +580,12 @@ __global__ __launch_bounds__(256) void k_canon(const int *__restrict__ indptr, c
         else if (k <= 128) canon_row<2, W1>(src, dst, k, lane, lds_rows[wave], o1, o2);
         else if (k <= 256) canon_row<4, W1>(src, dst, k, lane, lds_rows[wave], o1, o2);
         else if (lane == 0) longrows[atomicAdd(&ctr->n_long, 1u)] = i;
+        if (inext >= n) break;
+        i = inext;
+        b = nb;
+        e = ne;
+        bin = nbin;
+        rk = nrk;
     }
 }
 
@@ -504,24 +692,47 @@ __device__ __forceinline__ bool second_level(const PairArgs &a, int p, int q) {
 
 // flush `cnt` queued (p,q) hits: filter, translate to row ids, append to the shard's global queue with
 // one global atomic per wave; a full global queue raises the overflow flag (host re-runs in slices).
+// Every load that depends only on (p,q) is issued up front, so a flush costs ~3 dependent round trips.
 __device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, int cnt, int shard) {
     const int lane = threadIdx.x & 63;
     for (int i0 = (threadIdx.x >> 6) * 64; i0 < cnt; i0 += 256) {
         const int i = i0 + lane;
-        int2 pq = make_int2(0, 0);
         bool pass = false;
+        int ra = 0, rb = 0;
         if (i < cnt) {
-            pq = sbuf[i];
-            pass = second_level(a, pq.x, pq.y);
+            const int2 pq = sbuf[i];
+            const int p = pq.x, q = pq.y;
+            if (q > p && q < a.n && p < a.n) {
+                const int kp = a.ksorted[p], kq = a.ksorted[q];
+                const uint4 x = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)p * SIG2_WORDS);
+                const uint4 y = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)q * SIG2_WORDS);
+                ra = a.perm[p];
+                rb = a.perm[q];
+                const int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+                pass = (kq - kp <= a.d) && (c <= a.d);
+            }
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask == 0ull) continue;
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(&a.ctr->ncand[shard], (unsigned)__popcll(mask));
+        int ba = 0, ea = 0, bb = 0, eb = 0;
+        if (pass) {  // row extents: in flight together with the queue-slot atomic
+            ba = a.indptr[ra];
+            ea = a.indptr[ra + 1];
+            bb = a.indptr[rb];
+            eb = a.indptr[rb + 1];
+        }
         base = __shfl(base, 0);
         if (pass) {
             const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-            push_cand(a, shard, idx, a.perm[pq.x], a.perm[pq.y]);
+            if (idx < a.cand_cap_shard) {
+                const size_t o = (size_t)shard * a.cand_cap_shard + idx;
+                a.cand[o] = make_int4(ra, rb, ba, bb);
+                a.candk[o] = make_int2(ea - ba, eb - bb);
+            } else {
+                a.ctr->overflow = 1;  // dropped: the host re-runs the unit range in smaller slices
+            }
         }
     }
 }
@@ -542,38 +753,75 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
     return c;
 }
 
+// unit range of a (virtual) block: the U units are cut into nvb equal slices
+__device__ __forceinline__ unsigned unit_cut(unsigned U, unsigned vb, unsigned nvb) {
+    return (unsigned)(((unsigned long long)vb * U) / nvb);
+}
+
 template <int W, int R>
-__global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ sig1,
-                                                    const int4 *__restrict__ work, int n, int shard0, int nshards,
-                                                    int w_begin, int w_end, PairArgs pa) {
+__global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ sig1, const int4 *__restrict__ items,
+                                                    const int *__restrict__ blk_item, int n, int vb0, int nvb,
+                                                    int u_begin, int u_end, PairArgs pa) {
     constexpr int CB = (W == 1) ? 16 : (W == 2 ? 8 : 4);  // columns per batch: 16 SGPRs of signature
     constexpr int NG = 4, GC = CB / NG;                    // minima per group of GC columns
     __shared__ int2 sbuf[PF_LDS_QUEUE];
     __shared__ int scount;
     const int tid = threadIdx.x;
     const uint32_t d = (uint32_t)pa.d;
-    const int n_work = min((int)pa.ctr->n_work, w_end);
     const int qshard = blockIdx.x & (CAND_SHARDS - 1);
+    // this block's slice of the unit space, and the item it starts in
+    unsigned u0, u1;
+    int w;
+    if (blk_item) {  // normal run: slices of the whole unit space, first item precomputed by k_plan
+        const unsigned U = pa.ctr->n_units;
+        u0 = unit_cut(U, (unsigned)(vb0 + blockIdx.x), (unsigned)nvb);
+        u1 = unit_cut(U, (unsigned)(vb0 + blockIdx.x) + 1u, (unsigned)nvb);
+        if (u0 >= u1) return;
+        w = blk_item[vb0 + blockIdx.x];
+    } else {  // recovery run over [u_begin, u_end): locate the item by binary search
+        const unsigned len = (unsigned)(u_end - u_begin);
+        u0 = (unsigned)u_begin + unit_cut(len, blockIdx.x, gridDim.x);
+        u1 = (unsigned)u_begin + unit_cut(len, blockIdx.x + 1u, gridDim.x);
+        if (u0 >= u1) return;
+        int lo = 0, hi = (int)pa.ctr->n_work - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((unsigned)items[mid].w <= u0) lo = mid;
+            else hi = mid - 1;
+        }
+        w = lo;
+    }
     if (tid == 0) scount = 0;
     __syncthreads();
     unsigned long long evaluated = 0;
-    for (int w = w_begin + blockIdx.x * nshards + shard0; w < n_work; w += gridDim.x * nshards) {
-        const int4 it = work[w];
-        const int row0 = it.x, cbeg = it.y, cend = it.z;
-        uint32_t rs[R][W];
-        int prow[R];
+    uint32_t rs[R][W];
+    int cur_row0 = -1;
+    const int n_items = (int)pa.ctr->n_work;
+    int4 it = items[w];
+    while (true) {
+        const int4 nxt_it = items[min(w + 1, n_items - 1)];  // prefetch the next descriptor
+        const int row0 = it.x, ctrue = it.y, cend = it.z;
+        const int cal = ctrue & ~(CB - 1);
+        const int nb = (cend - cal + CB - 1) / CB;
+        // an item spans ITEM_OVH_UNITS + nb units: the fixed part prices the item switch for load balance
+        const unsigned ub = (unsigned)it.w + ITEM_OVH_UNITS;
+        const int first = u0 > ub ? (int)(u0 - ub) : 0;
+        const int last = u1 > ub ? (int)min((unsigned)nb, u1 - ub) : 0;
+        if (row0 != cur_row0) {
+            cur_row0 = row0;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int p = row0 + r * 256 + tid;
-            prow[r] = p;
-            int pc = p < n ? p : n - 1;
+            for (int r = 0; r < R; r++) {
+                const int p = row0 + r * 256 + tid;
+                const int pc = p < n ? p : n - 1;
 #pragma unroll
-            for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)pc * W + x];
+                for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)pc * W + x];
+            }
         }
+        const int qbeg = cal + first * CB, qend = cal + max(last, first) * CB;
         uint32_t cs[CB * W];
 #pragma unroll
-        for (int x = 0; x < CB * W; x++) cs[x] = sig1[(size_t)cbeg * W + x];  // wave-uniform -> s_load
-        for (int q0 = cbeg; q0 < cend; q0 += CB) {
+        for (int x = 0; x < CB * W; x++) cs[x] = sig1[(size_t)qbeg * W + x];  // wave-uniform -> s_load
+        for (int q0 = qbeg; q0 < qend; q0 += CB) {
             uint32_t nx[CB * W];
 #pragma unroll
             for (int x = 0; x < CB * W; x++) nx[x] = sig1[(size_t)(q0 + CB) * W + x];  // prefetch (array is padded)
@@ -609,6 +857,7 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
                     const int b = __ffsll((long long)hm) - 1;
                     hm &= hm - 1;
                     const int p = row0 + (b % R) * 256 + tid, q = q0 + b / R;
+                    if (q < ctrue || q >= cend) continue;  // alignment padding belongs to another item
                     const int slot = atomicAdd(&scount, 1);
                     if (slot < PF_LDS_QUEUE) sbuf[slot] = make_int2(p, q);
                     else push_raw(pa, qshard, p, q);
@@ -617,17 +866,16 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
 #pragma unroll
             for (int x = 0; x < CB * W; x++) cs[x] = nx[x];
         }
-        evaluated += (unsigned long long)(cend - cbeg);
-        __syncthreads();
-        const int cnt = min(scount, PF_LDS_QUEUE);
-        if (cnt > 0) {  // block-uniform
-            flush_hits(pa, sbuf, cnt, qshard);
-            __syncthreads();
-            if (tid == 0) scount = 0;
-            __syncthreads();
-        }
+        evaluated += (unsigned long long)max(last - first, 0);
+        u0 = ub + (unsigned)nb;  // end of this item in unit space
+        if (u0 >= u1 || w + 1 >= n_items) break;
+        w++;
+        it = nxt_it;
     }
-    if (tid == 0 && evaluated) atomicAdd(&pa.ctr->pairs_filtered, evaluated * (unsigned long long)(256 * R));
+    __syncthreads();
+    const int cnt = min(scount, PF_LDS_QUEUE);
+    if (cnt > 0) flush_hits(pa, sbuf, cnt, qshard);  // one flush per block; a full queue spilled through push_raw
+    if (tid == 0 && evaluated) atomicAdd(&pa.ctr->pairs_filtered, evaluated * (unsigned long long)(256 * R * CB));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -831,23 +1079,25 @@ static PairArgs make_pair_args(const Plan &pl) {
     return pa;
 }
 
-// prefilter + verify over work items [w_begin, w_end) of this shard
-int launch_pairs(const Plan &pl, int w_begin, int w_end, hipStream_t st, hipEvent_t *ev) {
+// prefilter + verify + union.  Normal run (u_end < 0): every (virtual) block takes its precomputed slice of
+// the unit space.  Recovery run: the unit range [u_begin, u_end) only.
+int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEvent_t *ev) {
     const int n = pl.n;
     PairArgs pa = make_pair_args(pl);
-    const int pf_grid = pl.pf_grid;
+    const int *blk = u_end < 0 ? pl.blk_item : nullptr;
+    const int vb0 = pl.shard * pl.pf_grid, nvb = pl.n_shards * pl.pf_grid;
     switch (pl.w1) {
         case 1:
-            hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
-                               pl.n_shards, w_begin, w_end, pa);
+            hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
+                               vb0, nvb, u_begin, u_end, pa);
             break;
         case 2:
-            hipLaunchKernelGGL((k_prefilter<2, PF_ROWS_W2>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
-                               pl.n_shards, w_begin, w_end, pa);
+            hipLaunchKernelGGL((k_prefilter<2, PF_ROWS_W2>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
+                               vb0, nvb, u_begin, u_end, pa);
             break;
         default:
-            hipLaunchKernelGGL((k_prefilter<4, PF_ROWS_W4>), dim3(pf_grid), dim3(256), 0, st, pl.sig1, pl.work, n, pl.shard,
-                               pl.n_shards, w_begin, w_end, pa);
+            hipLaunchKernelGGL((k_prefilter<4, PF_ROWS_W4>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
+                               vb0, nvb, u_begin, u_end, pa);
             break;
     }
     LAUNCH_CHECK();
@@ -869,26 +1119,40 @@ int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
 
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/) {
     const int n = pl.n;
-    const int nb1024 = (n + 1023) / 1024;
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(k_hist, dim3(nb1024), dim3(1024), 0, st, pl.indptr, n, pl.kcap, pl.hist, pl.parent, pl.ctr);
+    const int bins1 = (pl.kcap + 1) * pl.fb + 1;
+    const int lds_bins = min(bins1, PLAN_LDS_BINS);
+    hipLaunchKernelGGL(k_rowstat, dim3((n + 1023) / 1024), dim3(1024), (size_t)lds_bins * 4, st, pl.indptr, pl.indices, n,
+                       pl.kcap, pl.fb, pl.fshift, lds_bins, pl.hist, pl.rowbin, pl.rowrank, pl.parent, pl.ctr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, pl.hist, n, pl.kcap, pl.d, pl.start, pl.cursor, pl.tr, pl.tc,
-                       pl.work, pl.work_cap, pl.ctr);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scatter, dim3(nb1024), dim3(1024), 0, st, pl.indptr, n, pl.kcap, pl.cursor, pl.perm, pl.pos,
-                       pl.ksorted);
+    PlanArgs pa;
+    pa.lds_bins = lds_bins;
+    pa.hist = pl.hist;
+    pa.start = pl.start;
+    pa.items = pl.items;
+    pa.blk_item = pl.blk_item;
+    pa.ctr = pl.ctr;
+    pa.n = n;
+    pa.kcap = pl.kcap;
+    pa.fb = pl.fb;
+    pa.fshift = pl.fshift;
+    pa.d = pl.d;
+    pa.tr = pl.tr;
+    pa.cb = pl.cb;
+    pa.nvblocks = pl.n_shards * pl.pf_grid;
+    pa.item_cap = pl.item_cap;
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), (size_t)lds_bins * 4, st, pa);
     LAUNCH_CHECK();
     const int canon_blocks = min((n + 3) / 4, 256 * 16);
     const int lds_cap = pl.long_lds_cap;
     switch (pl.w1) {
-#define CANON_CASE(W)                                                                                                  \
-    case W:                                                                                                            \
-        hipLaunchKernelGGL(k_canon<W>, dim3(canon_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pos, pl.cols, \
-                           pl.sig1, pl.sig2, pl.longrows, pl.ctr);                                                     \
-        if (pl.kcap > 256)                                                                                             \
-            hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,      \
-                               pl.indices, pl.pos, pl.cols, pl.sig1, pl.sig2, pl.longrows, pl.ctr, lds_cap);            \
+#define CANON_CASE(W)                                                                                                   \
+    case W:                                                                                                             \
+        hipLaunchKernelGGL(k_canon<W>, dim3(canon_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.start, pl.rowbin, \
+                           pl.rowrank, pl.pos, pl.perm, pl.ksorted, pl.cols, pl.sig1, pl.sig2, pl.longrows, pl.ctr);    \
+        if (pl.kcap > 256)                                                                                              \
+            hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,       \
+                               pl.indices, pl.pos, pl.cols, pl.sig1, pl.sig2, pl.longrows, pl.ctr, lds_cap);             \
         break;
         CANON_CASE(1)
         CANON_CASE(2)
@@ -899,7 +1163,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     }
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
+    if (int e = launch_pairs(pl, 0, -1, st, ev)) return e;
     return launch_flatten(pl, st, ev);
 }
 
