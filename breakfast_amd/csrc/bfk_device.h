@@ -7,9 +7,9 @@ namespace bfk {
 
 constexpr int F_BUCKETS = 128;         // max f (hash-bit count) buckets per row length in the (k,f) sort key
 constexpr int PLAN_LDS_BINS = 10240;   // (k,f) bins mirrored in LDS by k_rowstat / k_plan (40 KiB)
-constexpr int SIG2_WORDS = 4;          // second-level signature: 128 bits
-constexpr int CAND_SHARDS = 8;         // candidate queue shards (block % 8 ~ XCD)
-constexpr int PF_LDS_QUEUE = 1024;     // per-block LDS candidate queue entries (8 KiB)
+constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
+constexpr int CAND_SHARDS = 64;        // candidate queue shards: returning atomics on one word serialise (~90/us)
+constexpr int PF_LDS_QUEUE = 512;      // per-wave LDS hit queue entries (4 KiB per wave), drained at half full
 constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane group in k_verify (512 B/group)
 constexpr int PF_ROWS_W1 = 4;          // rows per thread in k_prefilter by signature width
 constexpr int PF_ROWS_W2 = 4;
@@ -42,7 +42,7 @@ struct Plan {
     int tr, cb, fb, fshift;
     int shard, n_shards;
     int pf_grid, verify_grid, union_grid;
-    int item_cap, cand_cap_shard, edge_cap, long_lds_cap;
+    int item_cap, cand_cap_shard, edge_cap, long_lds_cap, dbg;
     const int *indptr;
     const uint32_t *indices;
     uint32_t *cols;
@@ -55,6 +55,7 @@ struct Plan {
     int2 *edges;  // NULL unless edge capture is on
     int *labels;
     Counters *ctr;
+    unsigned long long *dbg_t;
 };
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);

@@ -327,13 +327,14 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     }
     {   // work items: one per (row tile, column length) pair that has a band: the k-spans of the tiles
         // telescope, so <= (kcap+1) + T*(d+2); T for the smallest row tile (256*PF_ROWS_W4)
-        const int64_t T = (n + 256 * PF_ROWS_W4 - 1) / (256 * PF_ROWS_W4);
+        const int64_t T = (n + 64 * PF_ROWS_W4 - 1) / (64 * PF_ROWS_W4);
         const int64_t want = (int64_t)c->kcap + 2 + T * ((int64_t)std::min(d_hint, c->kcap + 1) + 3) + 64;
         if (int rc = dev_realloc(&c->d_items, &c->item_cap, want, 1.25)) return rc;
     }
     {
         // per shard: 4N pairs (8 shards -> 32N), and never less than one unit's pair slots
-        int64_t want = std::max<int64_t>((int64_t)256 * PF_ROWS_W1 * 16, 4 * n + 4096);
+        // total 32N pairs; every shard holds at least one unit's pair slots (64 lanes x R rows x 64 columns)
+        int64_t want = std::max<int64_t>((int64_t)64 * PF_ROWS_W1 * 64, (32 * n) / CAND_SHARDS + 1024);
         if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;
@@ -411,20 +412,28 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.d = std::min<int>(max_dist, 1 << 20);
     pl.w1 = c->last_w1;
     const int R = pl.w1 == 1 ? PF_ROWS_W1 : (pl.w1 == 2 ? PF_ROWS_W2 : PF_ROWS_W4);
-    pl.tr = 256 * R;
-    pl.cb = pl.w1 == 1 ? 16 : (pl.w1 == 2 ? 8 : 4);
+    pl.tr = 64 * R;  // a wave-tile: 64 lanes x R rows
+    pl.cb = 64 / pl.w1;  // columns per unit: one 256-byte chunk of first-level signatures
     pl.fb = c->fb;
     pl.fshift = c->fshift;
     pl.shard = shard;
     pl.n_shards = n_shards;
-    pl.pf_grid = 1280;  // 256 CUs x 5 resident blocks (84 VGPRs): every block gets an equal slice of the units
+    pl.pf_grid = 1280;  // 256 CUs x 5 resident blocks: every wave gets an equal slice of the units
+    if (const char *e = getenv("BFK_PF_GRID")) pl.pf_grid = std::max(1, atoi(e));
     pl.verify_grid = 2048;
     pl.union_grid = 512;
     pl.item_cap = (int)std::min<int64_t>(c->item_cap, INT32_MAX);
-    if (int rc = dev_realloc(&c->d_blk, &c->blk_cap, (int64_t)n_shards * pl.pf_grid)) return rc;
+    if (int rc = dev_realloc(&c->d_blk, &c->blk_cap, (int64_t)n_shards * pl.pf_grid * 4)) return rc;
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
     pl.long_lds_cap = LONG_LDS_CAP;
+    pl.dbg = getenv("BFK_PF_DEBUG") ? atoi(getenv("BFK_PF_DEBUG")) : 0;
+    pl.dbg_t = nullptr;
+    if (pl.dbg & 4) {
+        static unsigned long long *dbg_buf = nullptr;
+        if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)pl.pf_grid * 4 * 8 * 8);
+        pl.dbg_t = dbg_buf;
+    }
     pl.indptr = c->d_indptr;
     pl.indices = c->d_indices;
     pl.cols = c->d_cols;
@@ -479,14 +488,14 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
     std::vector<std::pair<int, int>> todo;
     const int step0 = std::max(1, (uhi - ulo) / 16);
     for (int b = uhi; b > ulo; b -= step0) todo.push_back({std::max(ulo, b - step0), b});
-    h->n_edges = h->n_cand_total = h->n_edges_cap = h->pairs_filtered = 0;
-    unsigned long long edges_acc = 0, cand_acc = 0, filt_acc = 0;
+    h->n_edges = h->n_cand_total = h->n_edges_cap = 0;
+    unsigned long long edges_acc = 0, cand_acc = 0;
     while (!todo.empty()) {
         auto [b, e] = todo.back();
         todo.pop_back();
         for (auto &x : h->ncand) x = 0;
         h->overflow = 0;
-        h->n_edges = h->n_cand_total = h->pairs_filtered = 0;
+        h->n_edges = h->n_cand_total = 0;
         const unsigned long long cap_mark = h->n_edges_cap;
         HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
         if (int er = launch_pairs(pl, b, e, c->stream, nullptr))
@@ -511,11 +520,9 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
         }
         edges_acc += h->n_edges;
         cand_acc += h->n_cand_total;
-        filt_acc += h->pairs_filtered;
     }
     h->n_edges = edges_acc;
     h->n_cand_total = cand_acc;
-    h->pairs_filtered = filt_acc;
     h->overflow = 0;
     HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
     if (int er = launch_flatten(pl, c->stream, nullptr))
@@ -540,6 +547,16 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (getenv("BFK_DEBUG"))
             fprintf(stderr, "[bfk] k_plan phases (us): scan %.1f stat %.1f tiles %.1f blk %.1f\n", (h.dbg[1] - h.dbg[0]) / 100.0,
                     (h.dbg[2] - h.dbg[1]) / 100.0, (h.dbg[3] - h.dbg[2]) / 100.0, (h.dbg[4] - h.dbg[3]) / 100.0);
+        if (c->plan.dbg_t) {
+            std::vector<unsigned long long> t((size_t)c->plan.pf_grid * 4 * 8);
+            (void)hipMemcpy(t.data(), c->plan.dbg_t, t.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen("gpurun_out/pf_waves.txt", "w")) {
+                for (size_t i = 0; i < t.size(); i += 8)
+                    fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i / 8, t[i], t[i + 1], t[i + 2], t[i + 3], t[i + 4],
+                            t[i + 5], t[i + 6], t[i + 7]);
+                fclose(f);
+            }
+        }
         int64_t retry_slices = 0;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
@@ -547,7 +564,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
         s.pairs_in_band = (int64_t)h.pairs_in_band;
-        s.pairs_filtered = (int64_t)h.pairs_filtered;
+        s.pairs_filtered = (int64_t)(h.pairs_filtered / (unsigned)c->last_shards);  // units are dealt evenly
         s.n_candidates = (int64_t)h.n_cand_total;
         s.n_edges = (int64_t)h.n_edges;
         s.n_retry_slices = retry_slices;

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
     // range is evaluated by its own thread (a per-tile loop over column lengths runs at single-wave
     // latency: ~20 us at 100k rows).
     __shared__ int4 s_tile[1024];
+    __shared__ int4 s_rng[1024];
     __shared__ int s_cpre[1025];
     const int T = (a.n + a.tr - 1) / a.tr;
     unsigned long long carry_i = 0, carry_u = 0;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
         const int ntile = min(1024, T - base), C = (int)totc;
         for (int cbase = 0; cbase < C; cbase += 1024) {
             const int c = cbase + threadIdx.x;
-            int row0 = 0, cb = 0, ce = 0;
+            int row0 = -1, cb = 0, ce = 0;
             bool has = false;
             if (c < C) {
                 int lo = 0, hi = ntile - 1;  // tile of candidate c: largest tt with cpre[tt] <= c
@@ -317,11 +318,29 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
                 row0 = (base + lo) * a.tr;
                 has = tile_range(a, s_start, row0, ti.x, ti.y, ti.z, ti.w, ti.x + (c - s_cpre[lo]), &cb, &ce);
             }
-            const unsigned nun = has ? ITEM_OVH_UNITS + (unsigned)((ce - (cb & ~(a.cb - 1)) + a.cb - 1) / a.cb) : 0u;
+            // Ranges of one tile that touch (sparse tails: a tile spans many lengths and each range is a whole
+            // length bin) are merged into ONE item: an item switch costs the prefilter a dependent round trip.
+            s_rng[threadIdx.x] = has ? make_int4(row0, cb, ce, 0) : make_int4(-1, 0, 0, 0);
+            __syncthreads();
+            bool head = has;
+            if (has && threadIdx.x > 0) {
+                const int4 pv = s_rng[threadIdx.x - 1];
+                if (pv.x == row0 && pv.z == cb) head = false;  // continuation of the previous range
+            }
+            if (head) {
+                int nx = threadIdx.x + 1;
+                while (nx < 1024) {
+                    const int4 nr = s_rng[nx];
+                    if (nr.x != row0 || nr.y != ce) break;
+                    ce = nr.z;
+                    nx++;
+                }
+            }
+            const unsigned nun = head ? ITEM_OVH_UNITS + (unsigned)((ce - (cb & ~(a.cb - 1)) + a.cb - 1) / a.cb) : 0u;
             unsigned long long tot_i, tot_u;
-            const unsigned long long ex_i = block_excl_scan_1024(has ? 1ull : 0ull, tmp, &tot_i);
+            const unsigned long long ex_i = block_excl_scan_1024(head ? 1ull : 0ull, tmp, &tot_i);
             const unsigned long long ex_u = block_excl_scan_1024((unsigned long long)nun, tmp, &tot_u);
-            if (has) {
+            if (head) {
                 const unsigned long long w = carry_i + ex_i;
                 if (w < (unsigned long long)a.item_cap) a.items[w] = make_int4(row0, cb, ce, (int)(unsigned)(carry_u + ex_u));
             }
@@ -339,6 +358,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
         if (n_items > a.item_cap || carry_u >= 0x7fffffffull) atomicOr(&a.ctr->err, ERR_WORKCAP);
         a.ctr->n_work = (unsigned)min(n_items, a.item_cap);
         a.ctr->n_units = U;
+        a.ctr->pairs_filtered = (carry_u - (unsigned long long)ITEM_OVH_UNITS * carry_i) * (unsigned long long)a.tr * a.cb;
     }
     if (n_items > a.item_cap || U == 0 || carry_u >= 0x7fffffffull) return;
     // first item of every virtual block: block vb starts at unit floor(vb * U / nvblocks)
@@ -522,7 +542,7 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
         int j = e * 64 + lane;
         if (j < k) {
             uint32_t b1 = hash1(x[e], r[e]) >> (32 - (5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2))));
-            uint32_t b2 = hash2(x[e], r[e]) >> (32 - 7);
+            uint32_t b2 = hash2(x[e], r[e]) >> (32 - 6);
 #pragma unroll
             for (int w = 0; w < W1; w++)
                 if ((int)(b1 >> 5) == w) s1[w] ^= 1u << (b1 & 31);
@@ -635,7 +655,7 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
             uint32_t r = 0;
             while ((int)r < j && ld_agent_u(dst + j - 1 - (int)r) == x) r++;
             uint32_t b1 = hash1(x, r) >> (32 - (5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2))));
-            uint32_t b2 = hash2(x, r) >> (32 - 7);
+            uint32_t b2 = hash2(x, r) >> (32 - 6);
             atomicXor(&s1[b1 >> 5], 1u << (b1 & 31));
             atomicXor(&s2[b2 >> 5], 1u << (b2 & 31));
         }
@@ -662,6 +682,8 @@ struct PairArgs {
     int cand_cap_shard;
     int d;
     int n;
+    unsigned long long *dbg_t;  // BFK_PF_DEBUG & 4: per-wave stamps {start, loop start, loop end, end, items}
+    int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
     Counters *ctr;
 };
 
@@ -678,24 +700,12 @@ __device__ __forceinline__ void push_cand(const PairArgs &a, int shard, int idx,
     a.candk[o] = make_int2(ea - ba, eb - bb);
 }
 
-// Second stage of the filter, one queued first-level hit per lane (run when a block flushes its LDS
-// queue, so the dependent global loads of 64 hits overlap instead of stalling the scan loop):
-// order / bounds / exact length band, then the 128-bit second-level signature.
-__device__ __forceinline__ bool second_level(const PairArgs &a, int p, int q) {
-    if (!(q > p && q < a.n && p < a.n)) return false;
-    if (a.ksorted[q] - a.ksorted[p] > a.d) return false;
-    const uint4 x = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)p * SIG2_WORDS);
-    const uint4 y = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)q * SIG2_WORDS);
-    int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
-    return c <= a.d;
-}
-
 // flush `cnt` queued (p,q) hits: filter, translate to row ids, append to the shard's global queue with
 // one global atomic per wave; a full global queue raises the overflow flag (host re-runs in slices).
 // Every load that depends only on (p,q) is issued up front, so a flush costs ~3 dependent round trips.
 __device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, int cnt, int shard) {
     const int lane = threadIdx.x & 63;
-    for (int i0 = (threadIdx.x >> 6) * 64; i0 < cnt; i0 += 256) {
+    for (int i0 = 0; i0 < cnt; i0 += 64) {  // called by ONE wave on its own queue
         const int i = i0 + lane;
         bool pass = false;
         int ra = 0, rb = 0;
@@ -704,11 +714,12 @@ __device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, 
             const int p = pq.x, q = pq.y;
             if (q > p && q < a.n && p < a.n) {
                 const int kp = a.ksorted[p], kq = a.ksorted[q];
-                const uint4 x = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)p * SIG2_WORDS);
-                const uint4 y = *reinterpret_cast<const uint4 *>(a.sig2 + (size_t)q * SIG2_WORDS);
+                static_assert(SIG2_WORDS == 2, "second-level signature is read as one 64-bit word pair");
+                const uint2 x = *reinterpret_cast<const uint2 *>(a.sig2 + (size_t)p * SIG2_WORDS);
+                const uint2 y = *reinterpret_cast<const uint2 *>(a.sig2 + (size_t)q * SIG2_WORDS);
                 ra = a.perm[p];
                 rb = a.perm[q];
-                const int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+                const int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y);
                 pass = (kq - kp <= a.d) && (c <= a.d);
             }
         }
@@ -759,29 +770,38 @@ __device__ __forceinline__ unsigned unit_cut(unsigned U, unsigned vb, unsigned n
 }
 
 template <int W, int R>
-__global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ sig1, const int4 *__restrict__ items,
+__global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict__ sig1, const int4 *__restrict__ items,
                                                     const int *__restrict__ blk_item, int n, int vb0, int nvb,
                                                     int u_begin, int u_end, PairArgs pa) {
-    constexpr int CB = (W == 1) ? 16 : (W == 2 ? 8 : 4);  // columns per batch: 16 SGPRs of signature
-    constexpr int NG = 4, GC = CB / NG;                    // minima per group of GC columns
-    __shared__ int2 sbuf[PF_LDS_QUEUE];
-    __shared__ int scount;
-    const int tid = threadIdx.x;
+    constexpr int CC = 64 / W;          // columns per unit: one 256-byte chunk of signatures (64 dwords)
+    constexpr int SB = 16 / W;          // columns per sub-batch (16 dwords): the hit-detection granularity
+    constexpr int NG = 4, GC = SB / NG; // minima per group of GC columns
+    __shared__ int2 sbuf[4][PF_LDS_QUEUE];
+    __shared__ __attribute__((aligned(16))) uint32_t scol[4][64];
+    __shared__ int scount[4];
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: tell the compiler the wave index is wave-uniform, so that everything derived from it
+    // (unit slice, item descriptors) stays in SGPRs / scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t d = (uint32_t)pa.d;
-    const int qshard = blockIdx.x & (CAND_SHARDS - 1);
-    // this block's slice of the unit space, and the item it starts in
+    const int qshard = (blockIdx.x * 4 + wave) & (CAND_SHARDS - 1);
+    // Every WAVE is its own worker: a wave-tile is 64*R consecutive (k,f)-sorted rows (R per lane), a unit
+    // is one chunk of CC columns against a wave-tile, and each wave takes an equal slice of the unit space.
     unsigned u0, u1;
     int w;
+    const unsigned long long t_start = pa.dbg_t ? wall_clock64() : 0ull;
     if (blk_item) {  // normal run: slices of the whole unit space, first item precomputed by k_plan
         const unsigned U = pa.ctr->n_units;
-        u0 = unit_cut(U, (unsigned)(vb0 + blockIdx.x), (unsigned)nvb);
-        u1 = unit_cut(U, (unsigned)(vb0 + blockIdx.x) + 1u, (unsigned)nvb);
+        const unsigned vb = (unsigned)(vb0 + blockIdx.x) * 4u + (unsigned)wave;
+        u0 = unit_cut(U, vb, (unsigned)nvb);
+        u1 = unit_cut(U, vb + 1u, (unsigned)nvb);
         if (u0 >= u1) return;
-        w = blk_item[vb0 + blockIdx.x];
+        w = blk_item[vb];
     } else {  // recovery run over [u_begin, u_end): locate the item by binary search
         const unsigned len = (unsigned)(u_end - u_begin);
-        u0 = (unsigned)u_begin + unit_cut(len, blockIdx.x, gridDim.x);
-        u1 = (unsigned)u_begin + unit_cut(len, blockIdx.x + 1u, gridDim.x);
+        const unsigned vb = blockIdx.x * 4u + (unsigned)wave;
+        u0 = (unsigned)u_begin + unit_cut(len, vb, gridDim.x * 4u);
+        u1 = (unsigned)u_begin + unit_cut(len, vb + 1u, gridDim.x * 4u);
         if (u0 >= u1) return;
         int lo = 0, hi = (int)pa.ctr->n_work - 1;
         while (lo < hi) {
@@ -791,18 +811,22 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
         }
         w = lo;
     }
-    if (tid == 0) scount = 0;
-    __syncthreads();
+    int2 *myq = sbuf[wave];
+    uint32_t *mycol = scol[wave];
+    if (lane == 0) scount[wave] = 0;
     unsigned long long evaluated = 0;
     uint32_t rs[R][W];
     int cur_row0 = -1;
     const int n_items = (int)pa.ctr->n_work;
     int4 it = items[w];
+    const unsigned long long t_loop = pa.dbg_t ? wall_clock64() : 0ull;
+    int dbg_items = 0;
     while (true) {
+        dbg_items++;
         const int4 nxt_it = items[min(w + 1, n_items - 1)];  // prefetch the next descriptor
         const int row0 = it.x, ctrue = it.y, cend = it.z;
-        const int cal = ctrue & ~(CB - 1);
-        const int nb = (cend - cal + CB - 1) / CB;
+        const int cal = ctrue & ~(CC - 1);
+        const int nb = (cend - cal + CC - 1) / CC;
         // an item spans ITEM_OVH_UNITS + nb units: the fixed part prices the item switch for load balance
         const unsigned ub = (unsigned)it.w + ITEM_OVH_UNITS;
         const int first = u0 > ub ? (int)(u0 - ub) : 0;
@@ -811,60 +835,84 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
             cur_row0 = row0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const int p = row0 + r * 256 + tid;
+                const int p = row0 + r * 64 + lane;
                 const int pc = p < n ? p : n - 1;
 #pragma unroll
                 for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)pc * W + x];
             }
         }
-        const int qbeg = cal + first * CB, qend = cal + max(last, first) * CB;
-        uint32_t cs[CB * W];
+        const int qbeg = cal + first * CC, qend = cal + max(last, first) * CC;
+        // Column signatures: one coalesced 256-byte load per chunk (the next chunk is in flight while this
+        // one is compared), parked in the wave's LDS slice and re-read as wave-uniform ds_read_b128
+        // broadcasts, so the v_xor operands are VGPRs (full rate; an SGPR operand halves it on gfx950).
+        uint32_t v = sig1[(size_t)qbeg * W + lane];
+        for (int q0 = qbeg; q0 < qend; q0 += CC) {
+            const uint32_t vn = sig1[(size_t)(q0 + CC) * W + lane];  // array is padded past n
+            mycol[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int x = 0; x < CB * W; x++) cs[x] = sig1[(size_t)qbeg * W + x];  // wave-uniform -> s_load
-        for (int q0 = qbeg; q0 < qend; q0 += CB) {
-            uint32_t nx[CB * W];
+            for (int sb = 0; sb < CC / SB; sb++) {
+                uint32_t cs[16];
 #pragma unroll
-            for (int x = 0; x < CB * W; x++) nx[x] = sig1[(size_t)(q0 + CB) * W + x];  // prefetch (array is padded)
-            uint32_t mg[NG];
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                mg[g] = 0xFFFFu;
-#pragma unroll
-                for (int j = g * GC; j < (g + 1) * GC; j++) {
-#pragma unroll
-                    for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
+                for (int x4 = 0; x4 < 4; x4++) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(&mycol[sb * 16 + x4 * 4]);
+                    cs[x4 * 4 + 0] = t.x;
+                    cs[x4 * 4 + 1] = t.y;
+                    cs[x4 * 4 + 2] = t.z;
+                    cs[x4 * 4 + 3] = t.w;
                 }
-            }
-            const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
-            if (__builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
-                // revisit only the column groups that hit; build a per-lane bit mask of the (column,row)
-                // hits (bit = j*R + r inside the batch), then drain it in ONE place (small code)
-                unsigned long long hm = 0ull;
+                uint32_t mg[NG];
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
-                    if (__builtin_amdgcn_ballot_w64(mg[g] <= d) != 0ull) {
-                        uint32_t bits = 0;
+                    mg[g] = 0xFFFFu;
 #pragma unroll
-                        for (int j = (g + 1) * GC - 1; j >= g * GC; j--) {
+                    for (int j = g * GC; j < (g + 1) * GC; j++) {
 #pragma unroll
-                            for (int r = R - 1; r >= 0; r--)
-                                bits = (bits << 1) | (sigdist<W>(rs[r], &cs[j * W]) <= d ? 1u : 0u);
-                        }
-                        hm |= (unsigned long long)bits << (g * GC * R);
+                        for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
                     }
                 }
-                while (hm) {
-                    const int b = __ffsll((long long)hm) - 1;
-                    hm &= hm - 1;
-                    const int p = row0 + (b % R) * 256 + tid, q = q0 + b / R;
-                    if (q < ctrue || q >= cend) continue;  // alignment padding belongs to another item
-                    const int slot = atomicAdd(&scount, 1);
-                    if (slot < PF_LDS_QUEUE) sbuf[slot] = make_int2(p, q);
-                    else push_raw(pa, qshard, p, q);
+                const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
+                if (!(pa.dbg & 2) && __builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
+                    // revisit only the column groups that hit; build a per-lane bit mask of the (column,row)
+                    // hits (bit = j*R + r inside the sub-batch), then drain it in ONE place (small code)
+                    unsigned long long hm = 0ull;
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        if (__builtin_amdgcn_ballot_w64(mg[g] <= d) != 0ull) {
+                            uint32_t bits = 0;
+#pragma unroll
+                            for (int j = (g + 1) * GC - 1; j >= g * GC; j--) {
+#pragma unroll
+                                for (int r = R - 1; r >= 0; r--)
+                                    bits = (bits << 1) | (sigdist<W>(rs[r], &cs[j * W]) <= d ? 1u : 0u);
+                            }
+                            hm |= (unsigned long long)bits << (g * GC * R);
+                        }
+                    }
+                    while (hm) {
+                        const int b = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int p = row0 + (b % R) * 64 + lane, q = q0 + sb * SB + b / R;
+                        if (q < ctrue || q >= cend) continue;  // alignment padding belongs to another item
+                        const int slot = atomicAdd(&scount[wave], 1);
+                        if (slot < PF_LDS_QUEUE) myq[slot] = make_int2(p, q);
+                        else push_raw(pa, qshard, p, q);  // queue full (very dense input): unfiltered, exact later
+                    }
                 }
             }
-#pragma unroll
-            for (int x = 0; x < CB * W; x++) cs[x] = nx[x];
+            v = vn;
+            // the hit queue is per wave, so it can be drained without a block barrier: keep it below half
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int level = scount[wave];
+            if (level > PF_LDS_QUEUE / 2) {
+                flush_hits(pa, myq, min(level, PF_LDS_QUEUE), qshard);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) scount[wave] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         evaluated += (unsigned long long)max(last - first, 0);
         u0 = ub + (unsigned)nb;  // end of this item in unit space
@@ -872,10 +920,27 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
         w++;
         it = nxt_it;
     }
-    __syncthreads();
-    const int cnt = min(scount, PF_LDS_QUEUE);
-    if (cnt > 0) flush_hits(pa, sbuf, cnt, qshard);  // one flush per block; a full queue spilled through push_raw
-    if (tid == 0 && evaluated) atomicAdd(&pa.ctr->pairs_filtered, evaluated * (unsigned long long)(256 * R * CB));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long t_main = pa.dbg_t ? wall_clock64() : 0ull;
+    const int cnt = min(scount[wave], PF_LDS_QUEUE);
+    if (cnt > 0 && !(pa.dbg & 1)) flush_hits(pa, myq, cnt, qshard);  // one flush per wave
+    if (pa.dbg_t && lane == 0) {
+        unsigned long long *o = pa.dbg_t + (size_t)(blockIdx.x * 4 + wave) * 8;
+        o[0] = t_start;
+        o[1] = t_loop;
+        o[2] = t_main;
+        o[3] = wall_clock64();
+        o[4] = (unsigned long long)dbg_items;
+        o[5] = (unsigned long long)cnt;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[6] = xcc;
+        o[7] = evaluated;
+    }
+    // (no per-wave statistics atomics here: 5120 adds to one word serialise to ~50 us; k_plan counts the units)
+    (void)evaluated;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -887,28 +952,29 @@ __global__ __launch_bounds__(256) void k_prefilter(const uint32_t *__restrict__ 
 // over the group's 16 bits counts A elements without a partner.  |A delta B| = kA + kB - 2*matches.
 // A pair farther apart than d is marked (row a = -1); k_union then hooks the surviving edges, one per lane.
 // ------------------------------------------------------------------------------------------------
-// the 8 shard queues seen as one index space: prefix of min(ncand[s], cap)
-struct ShardMap {
-    int pre[CAND_SHARDS + 1];
-};
-__device__ __forceinline__ ShardMap shard_map(const PairArgs &pa) {
-    const uint4 lo = *reinterpret_cast<const uint4 *>(&pa.ctr->ncand[0]);
-    const uint4 hi = *reinterpret_cast<const uint4 *>(&pa.ctr->ncand[4]);
-    const unsigned c[CAND_SHARDS] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    ShardMap m;
-    m.pre[0] = 0;
-#pragma unroll
-    for (int s = 0; s < CAND_SHARDS; s++) m.pre[s + 1] = m.pre[s] + (int)min(c[s], (unsigned)pa.cand_cap_shard);
-    return m;
+// the shard queues seen as one index space: prefix of min(ncand[s], cap), built once per block in LDS
+__device__ __forceinline__ void shard_prefix(const PairArgs &pa, int *pre /*CAND_SHARDS+1, LDS*/) {
+    if (threadIdx.x < 64) {
+        static_assert(CAND_SHARDS == 64, "one shard counter per lane of the first wave");
+        const int c = (int)min(pa.ctr->ncand[threadIdx.x], (unsigned)pa.cand_cap_shard);
+        int inc = c;
+        for (int s = 1; s < 64; s <<= 1) {
+            const int y = __shfl_up(inc, s);
+            if ((int)threadIdx.x >= s) inc += y;
+        }
+        pre[threadIdx.x + 1] = inc;
+        if (threadIdx.x == 0) pre[0] = 0;
+    }
+    __syncthreads();
 }
-__device__ __forceinline__ size_t shard_slot(const ShardMap &m, const PairArgs &pa, int c) {
-    int s = 0;
-#pragma unroll
-    for (int t = 1; t < CAND_SHARDS; t++) s += (c >= m.pre[t]) ? 1 : 0;
-    int base = m.pre[0];
-#pragma unroll
-    for (int t = 1; t < CAND_SHARDS; t++) base = (c >= m.pre[t]) ? m.pre[t] : base;
-    return (size_t)s * pa.cand_cap_shard + (size_t)(c - base);
+__device__ __forceinline__ size_t shard_slot(const int *pre, const PairArgs &pa, int c) {
+    int lo = 0, hi = CAND_SHARDS - 1;  // largest s with pre[s] <= c
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= c) lo = mid;
+        else hi = mid - 1;
+    }
+    return (size_t)lo * pa.cand_cap_shard + (size_t)(c - pre[lo]);
 }
 
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
@@ -918,10 +984,11 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
     const int gsh = (lane >> 4) * 16;           // bit offset of this group inside the wave ballot
     const int gg = blockIdx.x * 16 + grp, ng = gridDim.x * 16;
     uint32_t *myB = sB[grp];
-    const ShardMap sm = shard_map(pa);
-    const int total = sm.pre[CAND_SHARDS];
+    __shared__ int spre[CAND_SHARDS + 1];
+    shard_prefix(pa, spre);
+    const int total = spre[CAND_SHARDS];
     for (int c = gg; c < total; c += ng) {
-        const size_t slot = shard_slot(sm, pa, c);
+        const size_t slot = shard_slot(spre, pa, c);
         const int4 rec = pa.cand[slot];
         const int2 kk = pa.candk[slot];
         int ba = rec.z, ka = kk.x, bb = rec.w, kb = kk.y;
@@ -991,10 +1058,11 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
 __global__ __launch_bounds__(256) void k_union(PairArgs pa, int2 *edges, int edge_cap) {
     const int gt = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
     unsigned int my_edges = 0;
-    const ShardMap sm = shard_map(pa);
-    const int total = sm.pre[CAND_SHARDS];
+    __shared__ int spre[CAND_SHARDS + 1];
+    shard_prefix(pa, spre);
+    const int total = spre[CAND_SHARDS];
     for (int c = gt; c < total; c += nt) {
-        const int4 rec = pa.cand[shard_slot(sm, pa, c)];
+        const int4 rec = pa.cand[shard_slot(spre, pa, c)];
         if (rec.x < 0) continue;
         uf_union(pa.parent, rec.x, rec.y);
         my_edges++;
@@ -1070,6 +1138,8 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.ksorted = pl.ksorted;
     pa.sig2 = pl.sig2;
     pa.n = pl.n;
+    pa.dbg = pl.dbg;
+    pa.dbg_t = pl.dbg_t;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
     pa.candk = pl.candk;
@@ -1085,7 +1155,7 @@ int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEven
     const int n = pl.n;
     PairArgs pa = make_pair_args(pl);
     const int *blk = u_end < 0 ? pl.blk_item : nullptr;
-    const int vb0 = pl.shard * pl.pf_grid, nvb = pl.n_shards * pl.pf_grid;
+    const int vb0 = pl.shard * pl.pf_grid, nvb = pl.n_shards * pl.pf_grid * 4;  // workers are waves
     switch (pl.w1) {
         case 1:
             hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
@@ -1139,7 +1209,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     pa.d = pl.d;
     pa.tr = pl.tr;
     pa.cb = pl.cb;
-    pa.nvblocks = pl.n_shards * pl.pf_grid;
+    pa.nvblocks = pl.n_shards * pl.pf_grid * 4;
     pa.item_cap = pl.item_cap;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), (size_t)lds_bins * 4, st, pa);
     LAUNCH_CHECK();
