@@ -53,6 +53,18 @@ def algorithmic_bytes(k: np.ndarray, d: int, nnz: int):
     return b_alg, merged_pairs, resolved
 
 
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(indptr, indices, d, n_u, target_s=15.0):
     """The oracle (CPU restatement of the reference: band loop + two-pointer merges + graph) timed on the
     host cores on a bounded sample: S query rows x all columns (the reference's select_ind shape,
@@ -60,7 +72,7 @@ def cpu_baseline(indptr, indices, d, n_u, target_s=15.0):
     pairs those S query rows account for.  bench-only use of oracle/ (never the measured product)."""
     from oracle import ref_port as orc
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     rng = np.random.default_rng(0)
     probe = np.sort(rng.choice(n_u, size=min(n_u, 64 * cores), replace=False)).astype(np.int64)
     t0 = time.perf_counter()
@@ -163,6 +175,11 @@ def main():
         w = st["sig_words"]
         ops_per_pair = 2 * w + 0.5
         valu = st["pairs_filtered"] * ops_per_pair / t_pf if t_pf > 0 else None
+        # measured issue cost on gfx950 (tools/ubench/valu_rate.hip, cycles per wave-instruction per SIMD @2.4 GHz):
+        # v_xor (VGPR operands) 2.6, v_bcnt 4.3, v_min3 4.4 per two slots
+        cyc_per_slot = w * (2.6 + 4.3) + 2.2
+        slots_ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
+        slots_rate = st["pairs_filtered"] / t_pf if t_pf > 0 else None
         out = {
             "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step)",
             "value": resolved * a.steps / elapsed,
@@ -200,7 +217,9 @@ def main():
                         "VALU-issue bound and frac > 1 means operand reuse, not HBM over-subscription",
                 "valu": {"lane_ops_per_s": valu, "peak": VALU_PEAK_LANEOPS,
                          "frac": valu / VALU_PEAK_LANEOPS if valu else None,
-                         "ops_per_pair": ops_per_pair, "pair_slots": st["pairs_filtered"]},
+                         "ops_per_pair": ops_per_pair, "pair_slots": st["pairs_filtered"],
+                         "pair_slots_per_s": slots_rate, "measured_issue_ceiling_slots_per_s": slots_ceiling,
+                         "frac_of_measured_ceiling": slots_rate / slots_ceiling if slots_rate else None},
             },
             "phases_ms": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
             "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges",
