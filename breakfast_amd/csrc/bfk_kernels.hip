@@ -778,7 +778,6 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
     constexpr int NG = 4, GC = SB / NG; // minima per group of GC columns
     __shared__ int2 sbuf[4][PF_LDS_QUEUE];
     __shared__ __attribute__((aligned(16))) uint32_t scol[4][64];
-    __shared__ int scount[4];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave index is wave-uniform, so that everything derived from it
     // (unit slice, item descriptors) stays in SGPRs / scalar loads
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
     }
     int2 *myq = sbuf[wave];
     uint32_t *mycol = scol[wave];
-    if (lane == 0) scount[wave] = 0;
+    int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
     unsigned long long evaluated = 0;
     uint32_t rs[R][W];
     int cur_row0 = -1;
@@ -876,7 +875,8 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
                 const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
                 if (!(pa.dbg & 2) && __builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
                     // revisit only the column groups that hit; build a per-lane bit mask of the (column,row)
-                    // hits (bit = j*R + r inside the sub-batch), then drain it in ONE place (small code)
+                    // hits (bit = j*R + r inside the sub-batch), then drain it in ONE place (small code).
+                    // (Doing this on the scalar unit via v_readlane was tried: one SALU per CU makes it 5x slower.)
                     unsigned long long hm = 0ull;
 #pragma unroll
                     for (int g = 0; g < NG; g++) {
@@ -891,27 +891,43 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
                             hm |= (unsigned long long)bits << (g * GC * R);
                         }
                     }
-                    while (hm) {
-                        const int b = __ffsll((long long)hm) - 1;
-                        hm &= hm - 1;
-                        const int p = row0 + (b % R) * 64 + lane, q = q0 + sb * SB + b / R;
-                        if (q < ctrue || q >= cend) continue;  // alignment padding belongs to another item
-                        const int slot = atomicAdd(&scount[wave], 1);
-                        if (slot < PF_LDS_QUEUE) myq[slot] = make_int2(p, q);
-                        else push_raw(pa, qshard, p, q);  // queue full (very dense input): unfiltered, exact later
+                    // the queue is private to the wave: slots come from a ballot prefix, the fill level is a
+                    // wave-uniform register (no LDS atomic)
+                    while (true) {
+                        int b = -1;
+                        if (hm) {
+                            b = __ffsll((long long)hm) - 1;
+                            hm &= hm - 1;
+                            const int q = q0 + sb * SB + b / R;
+                            if (q < ctrue || q >= cend) b = -1;  // alignment padding belongs to another item
+                        }
+                        const unsigned long long act = __builtin_amdgcn_ballot_w64(b >= 0);
+                        if (act == 0ull && __builtin_amdgcn_ballot_w64(hm != 0ull) == 0ull) break;
+                        const int na = __popcll(act);
+                        if (qn + na > PF_LDS_QUEUE) {  // would overflow inside one chunk (very dense input): drain now
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            flush_hits(pa, myq, qn, qshard);
+                            __builtin_amdgcn_wave_barrier();
+                            qn = 0;
+                        }
+                        if (b >= 0)
+                            myq[qn + __popcll(act & ((1ull << lane) - 1ull))] =
+                                make_int2(row0 + (b % R) * 64 + lane, q0 + sb * SB + b / R);
+                        qn += na;
                     }
                 }
             }
             v = vn;
             // the hit queue is per wave, so it can be drained without a block barrier: keep it below half
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int level = scount[wave];
-            if (level > PF_LDS_QUEUE / 2) {
-                flush_hits(pa, myq, min(level, PF_LDS_QUEUE), qshard);
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) scount[wave] = 0;
+            if (qn > PF_LDS_QUEUE / 2) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                flush_hits(pa, myq, qn, qshard);
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
             }
         }
         evaluated += (unsigned long long)max(last - first, 0);
@@ -924,7 +940,7 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned long long t_main = pa.dbg_t ? wall_clock64() : 0ull;
-    const int cnt = min(scount[wave], PF_LDS_QUEUE);
+    const int cnt = qn;
     if (cnt > 0 && !(pa.dbg & 1)) flush_hits(pa, myq, cnt, qshard);  // one flush per wave
     if (pa.dbg_t && lane == 0) {
         unsigned long long *o = pa.dbg_t + (size_t)(blockIdx.x * 4 + wave) * 8;
