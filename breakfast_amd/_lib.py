@@ -46,6 +46,7 @@ EXPORTS = {
     "bfk_cluster_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_i32p, C.POINTER(Stats)]),
     "bfk_neighbours_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, C.POINTER(c_i64p),
                                      C.POINTER(c_i32p)]),
+    "bfk_labels_from_lists": (C.c_int, [C.c_int64, c_i64p, c_i32p, C.c_int64, c_i32p]),
     "bfk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "bfk_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bfk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -148,6 +149,19 @@ def neighbours_csr(indptr, indices, max_dist: int, select_ind=None):
     lib.bfk_free(op)
     lib.bfk_free(oi)
     return nbr_indptr, nbr_indices
+
+
+def labels_from_lists(n_rows: int, lists):
+    """bfk_labels_from_lists: components of a list of index arrays (each list united as a path)."""
+    lib = load()
+    off = np.zeros(len(lists) + 1, dtype=np.int64)
+    if len(lists):
+        np.cumsum(np.fromiter((len(x) for x in lists), dtype=np.int64, count=len(lists)), out=off[1:])
+    flat = (np.concatenate([np.asarray(x, dtype=np.int32) for x in lists]) if off[-1] else np.zeros(1, np.int32))
+    flat = np.ascontiguousarray(flat, dtype=np.int32)
+    labels = np.empty(max(n_rows, 1), dtype=np.int32)
+    _check(lib.bfk_labels_from_lists(int(n_rows), _p64(off), _p32(flat), len(lists), _p32(labels)))
+    return labels[:n_rows]
 
 
 class Context:

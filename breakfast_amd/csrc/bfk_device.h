@@ -62,6 +62,8 @@ int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEvent_t *ev);
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);
+int launch_lists(int *parent, int n, const long long *off, const int *flat, long long total, int n_lists, int *labels,
+                 Counters *ctr, hipStream_t st);
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
                  hipStream_t st);
 

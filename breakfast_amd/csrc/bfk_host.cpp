@@ -751,3 +751,48 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
     *nbr_indices_out = oi;
     return BFK_OK;
 }
+
+// ================================================================================================
+// cache path: components of a set of neighbour lists (each list is united as a path)
+// ================================================================================================
+extern "C" int bfk_labels_from_lists(int64_t n_rows, const int64_t *list_indptr, const int32_t *list_indices,
+                                     int64_t n_lists, int32_t *labels_out) {
+    if (n_rows < 0 || n_lists < 0 || (n_lists > 0 && (!list_indptr || list_indptr[0] != 0)) || (n_rows > 0 && !labels_out))
+        return fail(BFK_EARG, "bad arguments");
+    if (n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS || n_lists > INT32_MAX) return fail(BFK_EARG, "too many rows/lists");
+    const int64_t total = n_lists > 0 ? list_indptr[n_lists] : 0;
+    if (total < 0 || (total > 0 && !list_indices)) return fail(BFK_EARG, "bad list arrays");
+    if (n_rows == 0) return BFK_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;
+    void *d_off = nullptr, *d_flat = nullptr, *d_par = nullptr, *d_lab = nullptr, *d_ctr = nullptr;
+    int rc = BFK_OK;
+    auto cleanup = [&]() {
+        for (void *p : {d_off, d_flat, d_par, d_lab, d_ctr})
+            if (p) (void)hipFree(p);
+    };
+    if (hipMalloc(&d_off, (size_t)(n_lists + 1) * 8) != hipSuccess || hipMalloc(&d_flat, (size_t)std::max<int64_t>(total, 1) * 4) != hipSuccess ||
+        hipMalloc(&d_par, (size_t)n_rows * 4) != hipSuccess || hipMalloc(&d_lab, (size_t)n_rows * 4) != hipSuccess ||
+        hipMalloc(&d_ctr, sizeof(Counters)) != hipSuccess) {
+        cleanup();
+        return fail(BFK_ENOMEM, "hipMalloc failed");
+    }
+    hipError_t e = hipMemsetAsync(d_ctr, 0, sizeof(Counters), c->stream);
+    if (e == hipSuccess && n_lists > 0) e = hipMemcpyAsync(d_off, list_indptr, (size_t)(n_lists + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && total > 0) e = hipMemcpyAsync(d_flat, list_indices, (size_t)total * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        if (int le = launch_lists((int *)d_par, (int)n_rows, (const long long *)d_off, (const int *)d_flat, total, (int)n_lists,
+                                  (int *)d_lab, (Counters *)d_ctr, c->stream))
+            e = (hipError_t)le;
+    }
+    Counters h{};
+    if (e == hipSuccess) e = hipMemcpyAsync(labels_out, d_lab, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(BFK_EHIP, std::string("labels_from_lists: ") + hipGetErrorString(e));
+    else if (h.err & ERR_LABEL) rc = fail(BFK_EARG, "list index out of range");
+    cleanup();
+    return rc;
+}

@@ -1124,6 +1124,32 @@ __global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, in
     }
 }
 
+// cache path: every neighbour list is a path (a,b),(b,c),... (reference _to_edges, breakfast.py:103-113)
+__global__ void k_union_lists(int *parent, const long long *__restrict__ off, const int *__restrict__ flat,
+                              long long total, int n_lists, int n, Counters *ctr) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    // list of element e: largest l with off[l] <= e
+    int lo = 0, hi = n_lists - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= e) lo = mid;
+        else hi = mid - 1;
+    }
+    if (e == off[lo]) return;  // first element of its list: no edge to a predecessor
+    const int a = flat[e - 1], b = flat[e];
+    if (a < 0 || a >= n || b < 0 || b >= n) {
+        atomicOr(&ctr->err, ERR_LABEL);
+        return;
+    }
+    if (a != b) uf_union(parent, a, b);
+}
+
+__global__ void k_init_parent(int *parent, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+
 __global__ void k_changed(const int *__restrict__ labels, const int *__restrict__ ref, int n, int *changed) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool c = i < n && labels[i] != ref[i];
@@ -1251,6 +1277,21 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     if (ev) (void)hipEventRecord(ev[1], st);
     if (int e = launch_pairs(pl, 0, -1, st, ev)) return e;
     return launch_flatten(pl, st, ev);
+}
+
+int launch_lists(int *parent, int n, const long long *off, const int *flat, long long total, int n_lists, int *labels,
+                 Counters *ctr, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_init_parent, dim3((n + 255) / 256), dim3(256), 0, st, parent, n);
+    LAUNCH_CHECK();
+    if (total > 0 && n_lists > 0) {
+        hipLaunchKernelGGL(k_union_lists, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, off, flat, total,
+                           n_lists, n, ctr);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,

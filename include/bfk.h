@@ -95,6 +95,13 @@ int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices, int64_t n_
                        const int64_t *select_ind, int64_t n_select, int64_t **nbr_indptr_out,
                        int32_t **nbr_indices_out);
 
+/* ---- cache path: components of neighbour lists ----------------------------------------------------
+ * Replaces _to_graph/_to_edges + connected_components (breakfast.py:93-113, :325-326) when the neighbour
+ * lists come (partly) from a cache (src/breakfast/cache.py): every list is united as a path
+ * (a,b),(b,c),...; rows in no list stay singletons.  labels_out[i] = smallest row index of i's component. */
+int bfk_labels_from_lists(int64_t n_rows, const int64_t *list_indptr, const int32_t *list_indices, int64_t n_lists,
+                          int32_t *labels_out);
+
 /* ---- resident context: device buffers, one ctx per GPU ---------------------------------------------
  * The same path with the CSR resident in HBM and launches enqueued on a caller-supplied HIP stream
  * (e.g. torch.cuda.current_stream().cuda_stream); used by bench.py and by the one-process-per-GPU

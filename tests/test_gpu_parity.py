@@ -249,3 +249,90 @@ def test_properties_at_100k_d2_and_indels():
                                               n_threads=16):
                 want |= set(l.tolist())
         assert set(idx[ptr[s]: ptr[s + 1]].tolist()) == want
+
+
+# ---- incremental cache (reference tests/test_caching.py) --------------------------------------------
+CACHE_INPUTS = ["AddedSeqs", "DisorderedOnly", "AddedAndDisorderedSeqs", "DeletedSingleSeq", "DeletedProfile",
+                "ModifiedSeqs", "MultipleTests", "NoChanges"]
+
+
+def _run_cli(args):
+    res = click.testing.CliRunner().invoke(console.main, args)
+    assert res.exit_code == 0, (res.output, res.exception)
+    return res
+
+
+@pytest.fixture
+def own_cache(tmp_path, monkeypatch):
+    monkeypatch.chdir(FIX)
+    cache = tmp_path / "cache_dir" / "cache"  # parent directory is created on demand (test_caching.py:106-125)
+    _run_cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "init"), "--output-cache", str(cache),
+              "--max-dist", "1"])
+    assert cache.exists()
+    assert (tmp_path / "init" / "clusters.tsv").read_text() == json.loads(
+        (GOLD / "cli_runs.json").read_text())["dist1"]["clusters_tsv"]
+    return cache
+
+
+@pytest.mark.parametrize("which", ["own", "reference"])
+@pytest.mark.parametrize("idx,name", list(enumerate(CACHE_INPUTS, 1)))
+def test_cache_scenarios(idx, name, which, own_cache, cli_runs, tmp_path, monkeypatch):
+    """the 8 cache scenarios of the reference, with a cache written by this build and with one written by the
+    reference itself (same pickle format): clusters.tsv equals what the reference produced"""
+    monkeypatch.chdir(FIX)
+    cache = own_cache if which == "own" else GOLD / "ref_cache_testfile_d1.pkl.gz"
+    inp = f"testfile_caching{idx:02d}_{name}.tsv"
+    _run_cli(["--input-file", inp, "--outdir", str(tmp_path / "out"), "--input-cache", str(cache), "--max-dist", "1"])
+    got = (tmp_path / "out" / "clusters.tsv").read_text()
+    assert got == cli_runs[f"cache_caching{idx:02d}"]["clusters_tsv"]
+    exp = pd.read_table(f"expected_clusters_caching{idx:02d}_dist1.tsv", sep="\t")
+    assert exp.equals(pd.read_table(tmp_path / "out" / "clusters.tsv", sep="\t"))
+
+
+def test_cache_content_matches_reference(own_cache, cli_runs):
+    import gzip
+    import pickle
+
+    with gzip.open(own_cache, "rb") as f:
+        c = pickle.load(f)
+    ref = cli_runs["cache_init"]
+    assert c["max_dist"] == ref["max_dist"]
+    assert [list(map(int, x)) for x in c["neigh"]] == ref["neigh"]  # same lists in the same order
+    assert [list(t) for t in c["meta"]["id"]] == ref["meta_id"] and list(c["meta"]["feature"]) == ref["meta_feature"]
+
+
+def test_cache_other_max_dist_falls_back(own_cache, cli_runs, tmp_path, monkeypatch):
+    monkeypatch.chdir(FIX)
+    res = _run_cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "o"), "--input-cache", str(own_cache),
+                    "--max-dist", "2", "--min-cluster-size", "3"])
+    assert "differnt max-dist" in res.output
+    assert (tmp_path / "o" / "clusters.tsv").read_text() == cli_runs["dist2_mcs3"]["clusters_tsv"]
+
+
+def test_labels_from_lists():
+    lab = _lib.labels_from_lists(7, [np.array([3, 1]), np.array([5]), np.array([6, 2, 1])])
+    assert lab.tolist() == [0, 1, 1, 1, 4, 5, 1]
+    assert _lib.labels_from_lists(3, []).tolist() == [0, 1, 2]
+    with pytest.raises(_lib.BfkError):
+        _lib.labels_from_lists(3, [np.array([0, 9])])
+
+
+def test_cache_incremental_on_synthetic(tmp_path):
+    """grow a 3000-profile input to 4000 through the cache: same clusters.tsv as a fresh run"""
+    from breakfast_amd.synth import generate_profiles
+
+    rows = generate_profiles(4000)
+
+    def write(path, n):
+        with open(path, "w") as f:
+            f.write("accession\tdna_profile\n")
+            for i in range(n):
+                f.write(f"seq{i:07d}\t{rows[i]}\n")
+
+    write(tmp_path / "a.tsv", 3000)
+    write(tmp_path / "b.tsv", 4000)
+    cache = tmp_path / "c.pkl.gz"
+    _run_cli(["--input-file", str(tmp_path / "a.tsv"), "--outdir", str(tmp_path / "oa"), "--output-cache", str(cache)])
+    _run_cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "ob"), "--input-cache", str(cache)])
+    _run_cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "fresh")])
+    assert (tmp_path / "ob" / "clusters.tsv").read_bytes() == (tmp_path / "fresh" / "clusters.tsv").read_bytes()

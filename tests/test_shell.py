@@ -131,3 +131,29 @@ def test_cluster_identical_features_min_size():
         out = breakfast.cluster(meta, " ", 0, 2, None, None)
     assert out["cluster_id"].tolist()[0] == 1 and pd.isna(out["cluster_id"].tolist()[1])
     assert out["cluster_id"].tolist()[2] == 2
+
+
+def test_cache_host_logic(tmp_path):
+    """map_features / update_neighbours / save+load (no GPU): rows are matched by feature string, deleted rows
+    drop out of cached lists, new rows come back in the order the reference visits them"""
+    from breakfast_amd import cache as ca
+
+    c2n, new_rows = ca.map_features(["A", "B", "C", "D"], ["C", "zz", "A", "E", "D"])
+    assert c2n.tolist() == [2, -1, 0, 4] and new_rows.tolist() == [3, 1]  # 'E' < 'zz'
+    neigh = ca.update_neighbours([np.array([0, 1]), np.array([1]), np.array([2, 3, 0])], c2n)
+    assert [x.tolist() for x in neigh] == [[2], [0, 4, 2]]
+    meta = pd.DataFrame({"id": [("a",), ("b", "c")], "feature": ["X", "Y"], "n_features": [1, 1]})
+    with redirect_stdout(io.StringIO()):
+        ca.save(tmp_path / "d" / "c.gz", [np.array([0, 1])], meta, 2)
+        got = ca.load(tmp_path / "d" / "c.gz", 2)
+        assert got["max_dist"] == 2 and list(got["meta"].columns) == ["id", "feature"]
+        with pytest.raises(ca.CacheMismatch):
+            ca.load(tmp_path / "d" / "c.gz", 1)
+
+
+def test_reference_cache_file_is_readable():
+    from breakfast_amd import cache as ca
+
+    with redirect_stdout(io.StringIO()):
+        c = ca.load(GOLD / "ref_cache_testfile_d1.pkl.gz", 1)
+    assert len(c["neigh"]) == 5 and list(c["meta"].columns) == ["id", "feature"]

@@ -111,6 +111,7 @@ def g1_fixtures():
             res = run_ref_cli(["--input-file", "testfile.tsv", "--outdir", td, "--output-cache", str(cache),
                                "--max-dist", "1"])
             assert res.exit_code == 0
+            shutil.copyfile(cache, GOLD / "ref_cache_testfile_d1.pkl.gz")  # a cache written BY THE REFERENCE
             with gzip.open(cache, "rb") as f:
                 c = pickle.load(f)
             runs["cache_init"] = {
