@@ -23,9 +23,9 @@ enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 struct Counters {
     unsigned int ncand[CAND_SHARDS];
     int err;
+    int err_rows;  // set by k_canon (row longer than at bind time); cleared by the host only
     unsigned int n_work;   // work items
     unsigned int n_units;  // total units (batches of CB columns x one row tile)
-    unsigned int pad1;
     unsigned int n_long;
     int overflow;
     unsigned long long pairs_in_band;
@@ -47,8 +47,8 @@ struct Plan {
     const uint32_t *indices;
     uint32_t *cols;
     int *hist, *start, *rowbin, *rowrank, *blk_item;
-    int *perm, *pos, *ksorted, *parent, *longrows;
-    uint32_t *sig1, *sig2;
+    int *perm, *ksorted, *parent, *longrows;
+    uint32_t *sig1, *sig2, *sigu1, *sigu2;
     int4 *items;
     int4 *cand;
     int2 *candk;

@@ -165,8 +165,9 @@ struct bfk_ctx {
     int fb = F_BUCKETS, fshift = 0;
     uint32_t *d_cols = nullptr;
     int64_t cols_cap = 0;
-    int *d_perm = nullptr, *d_pos = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
-    uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr;
+    int *d_perm = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
+    uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
+    bool need_zero = true;  // head (counters + histogram) must be memset before the next run
     int64_t rows_cap = 0;
     int4 *d_items = nullptr;
     int64_t item_cap = 0;
@@ -237,9 +238,9 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start,    c->d_cols,   c->d_perm,   c->d_pos,
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start,    c->d_cols,   c->d_perm,   c->d_sigu1,
                     c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_items,  c->d_rowbin,
-                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small};
+                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -305,13 +306,13 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins * 4) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins;
+        c->need_zero = true;
     }
     if (int rc = dev_realloc(&c->d_cols, &c->cols_cap, nnz + 1, 1.0)) return rc;
     if (n + SIG_PAD_ROWS > c->rows_cap) {
         int64_t cap = 0, want = n + SIG_PAD_ROWS;
         int rc = 0;
         cap = 0; rc |= dev_realloc(&c->d_perm, &cap, want);
-        cap = 0; rc |= dev_realloc(&c->d_pos, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
@@ -319,6 +320,8 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
         cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
+        cap = 0; rc |= dev_realloc(&c->d_sigu1, &cap, want * 4);
+        cap = 0; rc |= dev_realloc(&c->d_sigu2, &cap, want * SIG2_WORDS);
         if (rc) return BFK_ENOMEM;
         c->rows_cap = want;
         // padded signature rows are read (never trusted): give them defined contents once
@@ -358,6 +361,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->nnz = nnz32;
     c->kcap = h[0];
     c->ran = false;
+    c->need_zero = true;  // bins are laid out by kcap
     return ctx_size_workspace(c, 0);
 }
 
@@ -444,19 +448,23 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.rowrank = c->d_rowrank;
     pl.blk_item = c->d_blk;
     pl.perm = c->d_perm;
-    pl.pos = c->d_pos;
     pl.ksorted = c->d_ksorted;
     pl.parent = c->d_parent;
     pl.longrows = c->d_longrows;
     pl.sig1 = c->d_sig1;
     pl.sig2 = c->d_sig2;
+    pl.sigu1 = c->d_sigu1;
+    pl.sigu2 = c->d_sigu2;
     pl.items = c->d_items;
     pl.cand = c->d_cand;
     pl.candk = c->d_candk;
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
     pl.labels = (int *)d_labels_out;
     c->plan = pl;
-    HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + ((size_t)(c->kcap + 1) * c->fb + 2) * 4, c->stream));
+    if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
+        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + ((size_t)(c->kcap + 1) * c->fb + 2) * 4, c->stream));
+        c->need_zero = false;
+    }
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
     if (int e = launch_pipeline(pl, c->stream, evs))
         return fail(BFK_EHIP, std::string("kernel launch: ") + hipGetErrorString((hipError_t)e));
@@ -541,7 +549,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
     if (c->ran && c->n > 0) {
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
-        if (h.err & ERR_ROWLEN) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
+        if (h.err || h.err_rows) c->need_zero = true;
+        if (h.err_rows) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
         if (getenv("BFK_DEBUG"))

@@ -1,11 +1,12 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
 // Pipeline (one stream, no host round trip between kernels):
-//   k_rowstat   per row: length k, hash-bit count f -> (k,f) bin, rank in bin (one atomic), parent[i] = i
 //   k_plan      scan -> start[bin] (rows ordered by (k,f)); per row tile the column ranges of its (k,f) band
 //               -> work items, cut into equal unit slices for the prefilter's blocks
-//   k_canon     one wave per row: bitonic sort of the token ids in registers, duplicate ranks,
-//               two XOR-parity signatures (sum_duplicates + prefilter keys), written in length order
+//   k_canon     one wave per row: sort key bin (k, f), bitonic sort of the token ids in registers, duplicate
+//               ranks, two XOR-parity signatures; parent[i] = i
+//   k_rowrank   (k,f) histogram + rank of every row inside its bin (LDS-aggregated atomics)
+//   k_place     counting-sort scatter of row ids / lengths / signatures into (k,f) order
 //   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
 //   k_prefilter THE dominant kernel: all in-band pairs, popcount(sig_p ^ sig_q) <= d  (necessary
 //               condition for |A delta B| <= d); survivors pass a 128-bit second level and are queued
@@ -103,45 +104,6 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fbit(uint32_t x) { return (x * 0xB5297A4Du) >> 31; }
 
-// k_rowstat: one thread per row: k, f -> bin = k*FB + fq, and the row's rank inside its bin.
-// ~100 rows share a bin, and returning global atomics on one word serialise, so a 1024-thread block
-// ranks its 1024 rows in an LDS copy of the histogram and reserves one range per touched bin with a
-// single global atomic (bins beyond the LDS copy fall back to per-row global atomics).  parent[i] = i.
-__global__ __launch_bounds__(1024) void k_rowstat(const int *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                   int n, int kcap, int fb, int fshift, int lds_bins, int *hist,
-                                                   int *rowbin, int *rowrank, int *parent, Counters *ctr) {
-    extern __shared__ __attribute__((aligned(16))) int lh[];
-    for (int b = threadIdx.x; b < lds_bins; b += 1024) lh[b] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int bin = -1, rank = 0;
-    if (i < n) {
-        const int b = indptr[i];
-        int k = indptr[i + 1] - b;
-        if (k < 0 || k > kcap) {
-            atomicOr(&ctr->err, ERR_ROWLEN);
-            k = k < 0 ? 0 : kcap;
-        }
-        const uint32_t *row = indices + b;
-        int f = 0, j = 0;
-        for (; j + 4 <= k; j += 4) f += (int)(fbit(row[j]) + fbit(row[j + 1]) + fbit(row[j + 2]) + fbit(row[j + 3]));
-        for (; j < k; j++) f += (int)fbit(row[j]);
-        bin = k * fb + min(f >> fshift, fb - 1);
-        rank = bin < lds_bins ? atomicAdd(&lh[bin], 1) : atomicAdd(&hist[bin], 1);
-        parent[i] = i;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < lds_bins; b += 1024) {
-        const int c = lh[b];
-        if (c) lh[b] = atomicAdd(&hist[b], c);  // base of this block's range in the bin
-    }
-    __syncthreads();
-    if (i < n) {
-        rowbin[i] = bin;
-        rowrank[i] = rank + (bin < lds_bins ? lh[bin] : 0);
-    }
-}
-
 // block-wide exclusive scan (1024 threads, one 64-bit value each); tmp: 40 x u64 of LDS
 __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long *tmp,
                                                                    unsigned long long *total) {
@@ -172,7 +134,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long
 
 struct PlanArgs {
     int lds_bins;      // entries of start[] mirrored in LDS (dynamic shared memory)
-    const int *hist;
+    int *hist;
     int *start;        // bins + 1
     int4 *items;       // {row0, cbeg, cend, ustart}
     int *blk_item;     // first item of every (virtual) block
@@ -226,7 +188,17 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
         // written back coalesced; each thread owns `per` consecutive bins.
         const int nl = min(bins, a.lds_bins);
 #pragma unroll 4
-        for (int b = threadIdx.x; b < nl; b += 1024) s_start[b] = a.hist[b];
+        for (int b = threadIdx.x; b < nl; b += 1024) {
+            s_start[b] = a.hist[b];
+            a.hist[b] = 0;  // leave the histogram clean for the next step (no per-step memset)
+        }
+        if (threadIdx.x < CAND_SHARDS) a.ctr->ncand[threadIdx.x] = 0;
+        if (threadIdx.x == 64) {
+            a.ctr->err = 0;
+            a.ctr->overflow = 0;
+            a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
+            a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = a.ctr->pairs_in_band = 0;
+        }
         __syncthreads();
         const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
         unsigned long long sum = 0;
@@ -236,8 +208,12 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
         int run = (int)ex;
         for (int b = b0; b < b1; b++) {
             const int c = b < nl ? s_start[b] : a.hist[b];
-            if (b < nl) s_start[b] = run;
-            else a.start[b] = run;
+            if (b < nl) {
+                s_start[b] = run;
+            } else {
+                a.start[b] = run;
+                a.hist[b] = 0;
+            }
             run += c;
         }
         if (threadIdx.x == 0) {
@@ -361,16 +337,34 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
         a.ctr->pairs_filtered = (carry_u - (unsigned long long)ITEM_OVH_UNITS * carry_i) * (unsigned long long)a.tr * a.cb;
     }
     if (n_items > a.item_cap || U == 0 || carry_u >= 0x7fffffffull) return;
-    // first item of every virtual block: block vb starts at unit floor(vb * U / nvblocks)
-    for (int w = threadIdx.x; w < n_items; w += 1024) {
-        const int *ip = reinterpret_cast<const int *>(&a.items[w]);  // written by this block: bypass L1
-        const int4 it = make_int4(0, ld_agent(ip + 1), ld_agent(ip + 2), ld_agent(ip + 3));
-        const unsigned ua = (unsigned)it.w;
-        const unsigned ub = ua + ITEM_OVH_UNITS + (unsigned)((it.z - (it.y & ~(a.cb - 1)) + a.cb - 1) / a.cb);
-        unsigned vb = (unsigned)(((unsigned long long)ua * a.nvblocks + U - 1) / U);
-        while (vb < (unsigned)a.nvblocks && (unsigned)(((unsigned long long)vb * U) / a.nvblocks) < ub) {
-            a.blk_item[vb] = w;
-            vb++;
+    // first item of every worker: worker vb starts at unit floor(vb * U / nvblocks).  The items' unit offsets are
+    // staged in LDS (re-using s_rng) and every worker binary-searches them; beyond 4096 items fall back to
+    // walking the items.
+    int *s_ust = reinterpret_cast<int *>(s_rng);
+    if (n_items <= 4096) {
+        for (int w = threadIdx.x; w < n_items; w += 1024) s_ust[w] = ld_agent(reinterpret_cast<const int *>(&a.items[w]) + 3);
+        __syncthreads();
+        for (int vb = threadIdx.x; vb < a.nvblocks; vb += 1024) {
+            const unsigned u0 = (unsigned)(((unsigned long long)vb * U) / (unsigned)a.nvblocks);
+            int lo = 0, hi = n_items - 1;  // largest w with ustart[w] <= u0
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((unsigned)s_ust[mid] <= u0) lo = mid;
+                else hi = mid - 1;
+            }
+            a.blk_item[vb] = lo;
+        }
+    } else {
+        for (int w = threadIdx.x; w < n_items; w += 1024) {
+            const int *ip = reinterpret_cast<const int *>(&a.items[w]);  // written by this block: bypass L1
+            const int4 it = make_int4(0, ld_agent(ip + 1), ld_agent(ip + 2), ld_agent(ip + 3));
+            const unsigned ua = (unsigned)it.w;
+            const unsigned ub = ua + ITEM_OVH_UNITS + (unsigned)((it.z - (it.y & ~(a.cb - 1)) + a.cb - 1) / a.cb);
+            unsigned vb = (unsigned)(((unsigned long long)ua * a.nvblocks + U - 1) / U);
+            while (vb < (unsigned)a.nvblocks && (unsigned)(((unsigned long long)vb * U) / a.nvblocks) < ub) {
+                a.blk_item[vb] = w;
+                vb++;
+            }
         }
     }
     __syncthreads();
@@ -490,15 +484,25 @@ __device__ __forceinline__ void wave_bitonic_bpermute(uint32_t (&x)[E], int lane
     }
 }
 
+// the row's sort key: bin = k*FB + (f >> fshift)
+struct RowKeyArgs {
+    int *hist, *rowbin, *rowrank;
+    int fb, fshift;
+};
+
 template <int E, int W1>
 __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int k,
-                                          int lane, uint32_t *lds_row, uint32_t *sig1_out, uint32_t *sig2_out) {
+                                          int lane, uint32_t *lds_row, uint32_t *sig1_out, uint32_t *sig2_out,
+                                          const RowKeyArgs &rk, int row) {
     uint32_t x[E];
+    int f = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         int j = e * 64 + lane;
         x[e] = j < k ? src[j] : 0xFFFFFFFFu;
+        f += __popcll(__builtin_amdgcn_ballot_w64(j < k && fbit(x[e]) != 0u));
     }
+    const int bin = k * rk.fb + min(f >> rk.fshift, rk.fb - 1);
     wave_bitonic<E>(x, lane);
     // repeat rank r_j = number of equal predecessors (0 unless the multiset row repeats a token)
     uint32_t r[E];
@@ -561,51 +565,45 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
 #pragma unroll
         for (int w = 0; w < SIG2_WORDS; w++) sig2_out[w] = s2[w];
     }
+    if (lane == 0) rk.rowbin[row] = bin;  // ranked by k_rowrank (a returning atomic here would stall the wave)
 }
 
 template <int W1>
 __global__ __launch_bounds__(256) void k_canon(const int *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                int n, const int *__restrict__ start, const int *__restrict__ rowbin,
-                                                const int *__restrict__ rowrank, int *__restrict__ pos,
-                                                int *__restrict__ perm, int *__restrict__ ksorted,
-                                                uint32_t *__restrict__ cols, uint32_t *__restrict__ sig1,
-                                                uint32_t *__restrict__ sig2, int *longrows, Counters *ctr) {
+                                                int n, int kcap, RowKeyArgs rk, int *__restrict__ parent,
+                                                uint32_t *__restrict__ cols, uint32_t *__restrict__ sigu1,
+                                                uint32_t *__restrict__ sigu2, int *longrows, Counters *ctr) {
     __shared__ uint32_t lds_rows[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
     int i = blockIdx.x * 4 + wave;
     if (i >= n) return;
-    int b = indptr[i], e = indptr[i + 1], bin = rowbin[i], rk = rowrank[i];
+    int b = indptr[i], e = indptr[i + 1];
     while (true) {
-        // the next row's metadata is fetched while this row is sorted (one dependent round trip fewer per row)
+        // the next row's extent is fetched while this row is sorted (one dependent round trip fewer per row)
         const int inext = i + nwaves;
-        int nb = 0, ne = 0, nbin = 0, nrk = 0;
+        int nb = 0, ne = 0;
         if (inext < n) {
             nb = indptr[inext];
             ne = indptr[inext + 1];
-            nbin = rowbin[inext];
-            nrk = rowrank[inext];
         }
-        const int k = max(e - b, 0);
-        const int p = start[bin] + rk;  // counting-sort position in (k, f) order
-        if (lane == 0) {
-            pos[i] = p;
-            perm[p] = i;
-            ksorted[p] = k;
+        int k = e - b;
+        if (k < 0 || k > kcap) {
+            if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
+            k = k < 0 ? 0 : kcap;
         }
+        if (lane == 0) parent[i] = i;
         const uint32_t *src = indices + b;
         uint32_t *dst = cols + b;
-        uint32_t *o1 = sig1 + (size_t)p * W1, *o2 = sig2 + (size_t)p * SIG2_WORDS;
-        if (k <= 64) canon_row<1, W1>(src, dst, k, lane, lds_rows[wave], o1, o2);
-        else if (k <= 128) canon_row<2, W1>(src, dst, k, lane, lds_rows[wave], o1, o2);
-        else if (k <= 256) canon_row<4, W1>(src, dst, k, lane, lds_rows[wave], o1, o2);
+        uint32_t *o1 = sigu1 + (size_t)i * W1, *o2 = sigu2 + (size_t)i * SIG2_WORDS;  // row order; k_place sorts
+        if (k <= 64) canon_row<1, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
+        else if (k <= 128) canon_row<2, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
+        else if (k <= 256) canon_row<4, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
         else if (lane == 0) longrows[atomicAdd(&ctr->n_long, 1u)] = i;
         if (inext >= n) break;
         i = inext;
         b = nb;
         e = ne;
-        bin = nbin;
-        rk = nrk;
     }
 }
 
@@ -613,27 +611,31 @@ __global__ __launch_bounds__(256) void k_canon(const int *__restrict__ indptr, c
 // the row is staged in dynamic LDS when it fits (up to 32768 tokens = 128 KiB of the CU's 160 KiB).
 template <int W1>
 __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indptr,
-                                                     const uint32_t *__restrict__ indices, const int *__restrict__ pos,
-                                                     uint32_t *cols, uint32_t *sig1, uint32_t *sig2,
+                                                     const uint32_t *__restrict__ indices, int kcap, RowKeyArgs rk,
+                                                     uint32_t *cols, uint32_t *sigu1, uint32_t *sigu2,
                                                      const int *__restrict__ longrows, const Counters *ctr,
                                                      int lds_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t row_lds[];
     __shared__ uint32_t s1[4], s2[SIG2_WORDS];
+    __shared__ int sf;
     const int nlong = (int)ctr->n_long;
     for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
         int i = longrows[li];
         int b = indptr[i];
-        int k = indptr[i + 1] - b;
+        int k = min(indptr[i + 1] - b, kcap);
         const uint32_t *src = indices + b;
         uint32_t *dst = cols + b;
         const bool staged = k <= lds_cap;
         if (threadIdx.x < 4) s1[threadIdx.x] = 0;
         if (threadIdx.x < SIG2_WORDS) s2[threadIdx.x] = 0;
+        if (threadIdx.x == 0) sf = 0;
         if (staged)
             for (int j = threadIdx.x; j < k; j += 256) row_lds[j] = src[j];
         __syncthreads();
+        int fl = 0;
         for (int j = threadIdx.x; j < k; j += 256) {
             uint32_t x = staged ? row_lds[j] : src[j];
+            fl += (int)fbit(x);
             int rank = 0;
             if (staged) {
                 for (int m = 0; m < k; m++) {
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
             }
             __hip_atomic_store(dst + rank, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (fl) atomicAdd(&sf, fl);
         __threadfence_block();
         __syncthreads();
         for (int j = threadIdx.x; j < k; j += 256) {
@@ -660,11 +663,56 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
             atomicXor(&s2[b2 >> 5], 1u << (b2 & 31));
         }
         __syncthreads();
-        int p = pos[i];
-        if (threadIdx.x < W1) sig1[(size_t)p * W1 + threadIdx.x] = s1[threadIdx.x];
-        if (threadIdx.x < SIG2_WORDS) sig2[(size_t)p * SIG2_WORDS + threadIdx.x] = s2[threadIdx.x];
+        if (threadIdx.x < W1) sigu1[(size_t)i * W1 + threadIdx.x] = s1[threadIdx.x];
+        if (threadIdx.x < SIG2_WORDS) sigu2[(size_t)i * SIG2_WORDS + threadIdx.x] = s2[threadIdx.x];
+        if (threadIdx.x == 0) rk.rowbin[i] = k * rk.fb + min(sf >> rk.fshift, rk.fb - 1);
         __syncthreads();
     }
+}
+
+// k_rowrank: histogram of the (k,f) bins and every row's rank inside its bin.  ~170 rows share a bin at 100k
+// rows and returning global atomics on one word serialise, so a 1024-thread block ranks its 1024 rows in an
+// LDS copy of the histogram and reserves one range per touched bin with a single global atomic (bins beyond
+// the LDS copy fall back to per-row global atomics).
+__global__ __launch_bounds__(1024) void k_rowrank(const int *__restrict__ rowbin, int n, int lds_bins, int *hist,
+                                                   int *__restrict__ rowrank) {
+    extern __shared__ __attribute__((aligned(16))) int lh[];
+    for (int b = threadIdx.x; b < lds_bins; b += 1024) lh[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int bin = 0, rank = 0;
+    if (i < n) {
+        bin = rowbin[i];
+        rank = bin < lds_bins ? atomicAdd(&lh[bin], 1) : atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < lds_bins; b += 1024) {
+        const int c = lh[b];
+        if (c) lh[b] = atomicAdd(&hist[b], c);  // base of this block's range in the bin
+    }
+    __syncthreads();
+    if (i < n) rowrank[i] = rank + (bin < lds_bins ? lh[bin] : 0);
+}
+
+// k_place: counting-sort scatter.  Row i goes to sorted position start[bin] + rank; its length and its two
+// signatures move with it (the prefilter reads signatures in sorted order, coalesced).
+template <int W1>
+__global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap,
+                                                const int *__restrict__ start, const int *__restrict__ rowbin,
+                                                const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
+                                                const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
+                                                int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
+                                                uint32_t *__restrict__ sig2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = start[rowbin[i]] + rowrank[i];
+    const int k = indptr[i + 1] - indptr[i];
+    perm[p] = i;
+    ksorted[p] = k < 0 ? 0 : (k > kcap ? kcap : k);
+#pragma unroll
+    for (int w = 0; w < W1; w++) sig1[(size_t)p * W1 + w] = sigu1[(size_t)i * W1 + w];
+#pragma unroll
+    for (int w = 0; w < SIG2_WORDS; w++) sig2[(size_t)p * SIG2_WORDS + w] = sigu2[(size_t)i * SIG2_WORDS + w];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1234,9 +1282,14 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     if (ev) (void)hipEventRecord(ev[0], st);
     const int bins1 = (pl.kcap + 1) * pl.fb + 1;
     const int lds_bins = min(bins1, PLAN_LDS_BINS);
-    hipLaunchKernelGGL(k_rowstat, dim3((n + 1023) / 1024), dim3(1024), (size_t)lds_bins * 4, st, pl.indptr, pl.indices, n,
-                       pl.kcap, pl.fb, pl.fshift, lds_bins, pl.hist, pl.rowbin, pl.rowrank, pl.parent, pl.ctr);
-    LAUNCH_CHECK();
+    RowKeyArgs rk;
+    rk.hist = pl.hist;
+    rk.rowbin = pl.rowbin;
+    rk.rowrank = pl.rowrank;
+    rk.fb = pl.fb;
+    rk.fshift = pl.fshift;
+    const int canon_blocks = min((n + 3) / 4, 256 * 16);
+    const int lds_cap = pl.long_lds_cap;
     PlanArgs pa;
     pa.lds_bins = lds_bins;
     pa.hist = pl.hist;
@@ -1253,23 +1306,24 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     pa.cb = pl.cb;
     pa.nvblocks = pl.n_shards * pl.pf_grid * 4;
     pa.item_cap = pl.item_cap;
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), (size_t)lds_bins * 4, st, pa);
-    LAUNCH_CHECK();
-    const int canon_blocks = min((n + 3) / 4, 256 * 16);
-    const int lds_cap = pl.long_lds_cap;
     switch (pl.w1) {
-#define CANON_CASE(W)                                                                                                   \
-    case W:                                                                                                             \
-        hipLaunchKernelGGL(k_canon<W>, dim3(canon_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.start, pl.rowbin, \
-                           pl.rowrank, pl.pos, pl.perm, pl.ksorted, pl.cols, pl.sig1, pl.sig2, pl.longrows, pl.ctr);    \
-        if (pl.kcap > 256)                                                                                              \
-            hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,       \
-                               pl.indices, pl.pos, pl.cols, pl.sig1, pl.sig2, pl.longrows, pl.ctr, lds_cap);             \
+#define PREP_CASE(W)                                                                                                      \
+    case W:                                                                                                               \
+        hipLaunchKernelGGL(k_canon<W>, dim3(canon_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.kcap, rk,        \
+                           pl.parent, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr);                                   \
+        if (pl.kcap > 256)                                                                                                \
+            hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,         \
+                               pl.indices, pl.kcap, rk, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr, lds_cap);        \
+        hipLaunchKernelGGL(k_rowrank, dim3((n + 1023) / 1024), dim3(1024), (size_t)lds_bins * 4, st, pl.rowbin, n,        \
+                           lds_bins, pl.hist, pl.rowrank);                                                                \
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), (size_t)lds_bins * 4, st, pa);                                    \
+        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.start,           \
+                           pl.rowbin, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2);              \
         break;
-        CANON_CASE(1)
-        CANON_CASE(2)
-        CANON_CASE(4)
-#undef CANON_CASE
+        PREP_CASE(1)
+        PREP_CASE(2)
+        PREP_CASE(4)
+#undef PREP_CASE
         default:
             return -1;
     }
