@@ -5,8 +5,8 @@
 
 namespace bfk {
 
-constexpr int F_BUCKETS = 128;         // max f (hash-bit count) buckets per row length in the (k,f) sort key
-constexpr int PLAN_LDS_BINS = 10240;   // (k,f) bins mirrored in LDS by k_rowstat / k_plan (40 KiB)
+constexpr int KEY_BUCKETS = 32;        // f / g buckets per row length in the (k,f,g) sort key (window around k/2)
+constexpr int KEY_MAX_BINS3 = 1 << 24; // cap on (kmax+1)*fb*gb counters (64 MiB); buckets are halved beyond it
 constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
 constexpr int CAND_SHARDS = 64;        // candidate queue shards: returning atomics on one word serialise (~90/us)
 constexpr int PF_LDS_QUEUE = 512;      // per-wave LDS hit queue entries (4 KiB per wave), drained at half full
@@ -39,14 +39,14 @@ struct Counters {
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
 struct Plan {
     int n, kcap, d, w1;
-    int tr, cb, fb, fshift;
+    int tr, cb, fb, gb;
     int shard, n_shards;
     int pf_grid, verify_grid, union_grid;
     int item_cap, cand_cap_shard, edge_cap, long_lds_cap, dbg;
     const int *indptr;
     const uint32_t *indices;
     uint32_t *cols;
-    int *hist, *start, *rowbin, *rowrank, *blk_item;
+    int *hist3, *sub3, *start, *rowkey, *rowrank, *keysorted, *blk_item;
     int *perm, *ksorted, *parent, *longrows;
     uint32_t *sig1, *sig2, *sigu1, *sigu2;
     int4 *items;

@@ -161,8 +161,9 @@ struct bfk_ctx {
     // workspace
     char *d_head = nullptr;  // Counters | hist[bins]
     int64_t bins_cap = 0;
-    int *d_start = nullptr;
-    int fb = F_BUCKETS, fshift = 0;
+    int *d_start = nullptr, *d_sub3 = nullptr, *d_keysorted = nullptr;
+    int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
+    int64_t bins3 = 0;
     uint32_t *d_cols = nullptr;
     int64_t cols_cap = 0;
     int *d_perm = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
@@ -171,7 +172,7 @@ struct bfk_ctx {
     int64_t rows_cap = 0;
     int4 *d_items = nullptr;
     int64_t item_cap = 0;
-    int *d_rowbin = nullptr, *d_rowrank = nullptr, *d_blk = nullptr;
+    int *d_rowkey = nullptr, *d_rowrank = nullptr, *d_blk = nullptr;
     int64_t blk_cap = 0;
     int4 *d_cand = nullptr;
     int2 *d_candk = nullptr;
@@ -239,8 +240,9 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start,    c->d_cols,   c->d_perm,   c->d_sigu1,
-                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_items,  c->d_rowbin,
-                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2};
+                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_items,  c->d_rowkey,
+                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
+                    c->d_sub3,     c->d_keysorted};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -288,24 +290,25 @@ static int ctx_size_cand(bfk_ctx *c, int64_t total) {
 
 static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     const int64_t n = c->n, nnz = c->nnz;
-    // (k,f) sort key: F_BUCKETS f-buckets per row length; f is shifted down for very long rows
-    // fb = largest power of two <= F_BUCKETS that keeps all bins in the 60 KiB LDS mirror (1 = length only)
-    c->fb = F_BUCKETS;
-    while (c->fb > 1 && ((int64_t)c->kcap + 1) * c->fb + 1 > PLAN_LDS_BINS) c->fb >>= 1;
-    c->fshift = 0;
-    while (((int64_t)c->kcap >> c->fshift) >= c->fb && c->fshift < 31) c->fshift++;
-    const int64_t bins = ((int64_t)c->kcap + 1) * c->fb + 2;
-    if (bins > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the (k,f) bin index");
-    if (bins > c->bins_cap || !c->d_head) {
-        if (c->d_head) (void)hipFree(c->d_head);
-        if (c->d_start) (void)hipFree(c->d_start);
+    // (k,f,g) sort key: KEY_BUCKETS f- and g-buckets per row length, halved (g first) for very long rows
+    c->fb = c->gb = KEY_BUCKETS;
+    while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->gb > 1) c->gb >>= 1;
+    while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->fb > 1) c->fb >>= 1;
+    const int64_t bins2 = ((int64_t)c->kcap + 1) * c->fb + 2;
+    const int64_t bins3 = ((int64_t)c->kcap + 1) * c->fb * c->gb + 2;
+    if (bins3 > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the sort-key index");
+    c->bins3 = bins3;
+    if (bins3 > c->bins_cap || !c->d_head) {
+        for (void *q : {(void *)c->d_head, (void *)c->d_start, (void *)c->d_sub3})
+            if (q) (void)hipFree(q);
         c->d_head = nullptr;
-        c->d_start = nullptr;
+        c->d_start = c->d_sub3 = nullptr;
         c->bins_cap = 0;
-        size_t head = sizeof(Counters) + (size_t)bins * 4;
-        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins * 4) != hipSuccess)
+        size_t head = sizeof(Counters) + (size_t)bins3 * 4;
+        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins2 * 4) != hipSuccess ||
+            hipMalloc((void **)&c->d_sub3, (size_t)bins3 * 4) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
-        c->bins_cap = bins;
+        c->bins_cap = bins3;
         c->need_zero = true;
     }
     if (int rc = dev_realloc(&c->d_cols, &c->cols_cap, nnz + 1, 1.0)) return rc;
@@ -316,7 +319,8 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
-        cap = 0; rc |= dev_realloc(&c->d_rowbin, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_rowkey, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_keysorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
         cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
@@ -331,7 +335,9 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     {   // work items: one per (row tile, column length) pair that has a band: the k-spans of the tiles
         // telescope, so <= (kcap+1) + T*(d+2); T for the smallest row tile (256*PF_ROWS_W4)
         const int64_t T = (n + 64 * PF_ROWS_W4 - 1) / (64 * PF_ROWS_W4);
-        const int64_t want = (int64_t)c->kcap + 2 + T * ((int64_t)std::min(d_hint, c->kcap + 1) + 3) + 64;
+        const int64_t dd = std::min<int64_t>(d_hint, c->kcap + 1);
+        const int64_t per_tile = std::max<int64_t>(dd + 3, (dd + 1) * (dd + 1) <= 64 ? (dd + 1) * (dd + 1) : 0);
+        const int64_t want = (int64_t)c->kcap + 2 + T * per_tile + 64;
         if (int rc = dev_realloc(&c->d_items, &c->item_cap, want, 1.25)) return rc;
     }
     {
@@ -419,7 +425,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.tr = 64 * R;  // a wave-tile: 64 lanes x R rows
     pl.cb = 64 / pl.w1;  // columns per unit: one 256-byte chunk of first-level signatures
     pl.fb = c->fb;
-    pl.fshift = c->fshift;
+    pl.gb = c->gb;
     pl.shard = shard;
     pl.n_shards = n_shards;
     pl.pf_grid = 1280;  // 256 CUs x 5 resident blocks: every wave gets an equal slice of the units
@@ -442,9 +448,11 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.indices = c->d_indices;
     pl.cols = c->d_cols;
     pl.ctr = (Counters *)c->d_head;
-    pl.hist = (int *)(c->d_head + sizeof(Counters));
+    pl.hist3 = (int *)(c->d_head + sizeof(Counters));
+    pl.sub3 = c->d_sub3;
+    pl.keysorted = c->d_keysorted;
     pl.start = c->d_start;
-    pl.rowbin = c->d_rowbin;
+    pl.rowkey = c->d_rowkey;
     pl.rowrank = c->d_rowrank;
     pl.blk_item = c->d_blk;
     pl.perm = c->d_perm;
@@ -462,7 +470,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.labels = (int *)d_labels_out;
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
-        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + ((size_t)(c->kcap + 1) * c->fb + 2) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->bins3 * 4, c->stream));
         c->need_zero = false;
     }
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
@@ -554,8 +562,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
         if (getenv("BFK_DEBUG"))
-            fprintf(stderr, "[bfk] k_plan phases (us): scan %.1f stat %.1f tiles %.1f blk %.1f\n", (h.dbg[1] - h.dbg[0]) / 100.0,
-                    (h.dbg[2] - h.dbg[1]) / 100.0, (h.dbg[3] - h.dbg[2]) / 100.0, (h.dbg[4] - h.dbg[3]) / 100.0);
+            fprintf(stderr, "[bfk] plan phases (us): k_scan %.1f | k_tiles: ranges %.1f workers %.1f\n", (h.dbg[1] - h.dbg[0]) / 100.0,
+                    (h.dbg[3] - h.dbg[2]) / 100.0, (h.dbg[4] - h.dbg[3]) / 100.0);
         if (c->plan.dbg_t) {
             std::vector<unsigned long long> t((size_t)c->plan.pf_grid * 4 * 8);
             (void)hipMemcpy(t.data(), c->plan.dbg_t, t.size() * 8, hipMemcpyDeviceToHost);

@@ -1,11 +1,11 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
 // Pipeline (one stream, no host round trip between kernels):
-//   k_plan      scan -> start[bin] (rows ordered by (k,f)); per row tile the column ranges of its (k,f) band
-//               -> work items, cut into equal unit slices for the prefilter's blocks
 //   k_canon     one wave per row: sort key bin (k, f), bitonic sort of the token ids in registers, duplicate
 //               ranks, two XOR-parity signatures; parent[i] = i
-//   k_rowrank   (k,f) histogram + rank of every row inside its bin (LDS-aggregated atomics)
+//   k_rowrank   (k,f,g) histogram + rank of every row inside its key
+//   k_scan      start[] of the (k,f) bins, prefix of the g sub-bins; re-zeroes histogram and counters
+//   k_tiles     per wave-tile the column ranges of its (k,f,g) band -> work items, cut into equal unit slices
 //   k_place     counting-sort scatter of row ids / lengths / signatures into (k,f) order
 //   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
 //   k_prefilter THE dominant kernel: all in-band pairs, popcount(sig_p ^ sig_q) <= d  (necessary
@@ -95,14 +95,35 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sort key.  Rows are ordered by (k, f): k = multiset size, f = number of tokens whose hash bit is set
-// (quantised to FB buckets).  Both are 1-Lipschitz in the distance: a pair with |A\B| = a, |B\A| = b,
-// a + b <= d, k_B - k_A = delta >= 0 has a <= (d - delta)/2, b = a + delta and f_B - f_A in [-a, b].
-// So for a block of length-sorted rows the rows that can be within d form, per column length k', ONE
-// contiguous range of the (k', f) order — the "band" the prefilter scans.  With f ~ Binomial(k, 1/2) this
-// cuts the pairs to evaluate by ~5-8x at d = 1 compared with the reference's length-only band.
+// Sort key.  Rows are ordered by (k, f, g): k = multiset size, f and g = number of tokens whose first /
+// second hash bit is set.  All three are 1-Lipschitz in the distance: a pair with |A\B| = a, |B\A| = b,
+// a + b <= d, k_B - k_A = delta >= 0 has a <= (d - delta)/2, b = a + delta, and f_B - f_A, g_B - g_A in
+// [-a, b].  So for a run of consecutive sorted rows the rows that can be within d form, per column length
+// k' and per column f', ONE contiguous range of the (k, f, g) order — the "band" the prefilter scans.
+// (The reference bands by length only: np.isclose(n, q, atol=d), breakfast.py:250.)  f, g ~ Binomial(k, 1/2)
+// (sigma ~ 3 at k = 40), so each of the two keys cuts the pair slots by ~2.5x at d = 1.
+// f and g are stored as buckets: v - (k/2 - nb/2) clamped to [0, nb) (a window centred on the mean).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fbit(uint32_t x) { return (x * 0xB5297A4Du) >> 31; }
+__device__ __forceinline__ uint32_t gbit(uint32_t x) { return ((x ^ (x >> 11)) * 0x2C1B3C6Du) >> 31; }
+
+struct KeyCfg {
+    int fb, gb;  // buckets per row length for f and g (powers of two; 1 = key unused)
+};
+__device__ __forceinline__ int key_center(int k, int nb) { return (k >> 1) - (nb >> 1); }
+__device__ __forceinline__ int key_bucket(int v, int k, int nb) { return min(max(v - key_center(k, nb), 0), nb - 1); }
+__device__ __forceinline__ int key3_of(const KeyCfg &c, int k, int f, int g) {
+    return (k * c.fb + key_bucket(f, k, c.fb)) * c.gb + key_bucket(g, k, c.gb);
+}
+
+// bucket range [lo, hi] a column of length kp can have in one key, given the rows' bucket range [rlo, rhi]
+// at length k = kp - delta (delta >= 0): raw difference in [-amax, bmax], the window moves by s = c(kp) - c(k),
+// and a clamped end bucket stands for an open interval.
+__device__ __forceinline__ void key_band(int rlo, int rhi, int k, int kp, int amax, int bmax, int nb, int *lo, int *hi) {
+    const int s = key_center(kp, nb) - key_center(k, nb);
+    *lo = (rlo <= 0) ? 0 : max(rlo - amax - s, 0);
+    *hi = (rhi >= nb - 1) ? nb - 1 : min(rhi + bmax - s, nb - 1);
+}
 
 // block-wide exclusive scan (1024 threads, one 64-bit value each); tmp: 40 x u64 of LDS
 __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long *tmp,
@@ -133,148 +154,112 @@ __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long
 }
 
 struct PlanArgs {
-    int lds_bins;      // entries of start[] mirrored in LDS (dynamic shared memory)
-    int *hist;
-    int *start;        // bins + 1
+    int *hist3;        // (kcap+1)*fb*gb counters, re-zeroed by k_scan
+    int *sub3;         // exclusive prefix of hist3 inside every (k,f) bin
+    int *start;        // (kcap+1)*fb + 1: first sorted position of every (k,f) bin
+    const int *keysorted;  // key3 of the row at every sorted position (k_tiles)
     int4 *items;       // {row0, cbeg, cend, ustart}
-    int *blk_item;     // first item of every (virtual) block
+    int *blk_item;     // first item of every worker
     Counters *ctr;
-    int n, kcap, fb, fshift, d, tr, cb, nvblocks, item_cap;
+    KeyCfg key;
+    int n, kcap, d, tr, cb, nvblocks, item_cap;
 };
 
-__device__ __forceinline__ int plan_start(const PlanArgs &a, const int *s_start, int b) {
-    return b < a.lds_bins ? s_start[b] : ld_agent(a.start + b);
-}
-
-// column range (in sorted positions) a tile of rows [row0, ..] with first/last bins (k_lo,f_lo),(k_hi,f_hi)
-// has to scan among the rows of length kp; returns false if empty
-__device__ __forceinline__ bool tile_range(const PlanArgs &a, const int *s_start, int row0, int k_lo, int f_lo, int k_hi, int f_hi, int kp,
-                                           int *cb, int *ce) {
-    int fa = 0x7fffffff, fz = -0x7fffffff;
-    const int S1 = (1 << a.fshift) - 1;
-    for (int delta = 0; delta <= a.d; delta++) {
-        const int k = kp - delta;
-        if (k < k_lo || k > k_hi) continue;
-        const int rmin = (k == k_lo) ? f_lo : 0, rmax = (k == k_hi) ? f_hi : a.fb - 1;
-        const int amax = (a.d - delta) >> 1, bmax = amax + delta;
-        fa = min(fa, rmin - ((amax + S1) >> a.fshift));
-        fz = max(fz, rmax + ((bmax + S1) >> a.fshift));
-    }
-    if (fa > fz) return false;
-    fa = max(fa, 0);
-    fz = min(fz, a.fb - 1);
-    const int c0 = max(plan_start(a, s_start, kp * a.fb + fa), row0);  // q > p >= row0
-    const int c1 = plan_start(a, s_start, kp * a.fb + fz + 1);
-    *cb = c0;
-    *ce = c1;
-    return c1 > c0;
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_plan (one block): start[] = exclusive scan of the (k,f) histogram; then for every tile of TR sorted
-// rows the column ranges it must scan (one per column length) -> work items with a running count of
-// "units" (one unit = one batch of CB columns against the tile); the units are what the prefilter's
-// blocks divide among themselves, so every block gets the same amount of work.
+// k_scan (one block): per (k,f) bin the exclusive prefix of its g sub-bins (sub3) and, across bins, the
+// exclusive scan of the bin totals (start).  Re-zeroes the histogram and the per-step counters, so a step
+// needs no memset.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int s_start[];
+__global__ __launch_bounds__(1024) void k_scan(PlanArgs a) {
     __shared__ unsigned long long tmp[40];
 #define PLAN_STAMP(i) if (threadIdx.x == 0) a.ctr->dbg[i] = wall_clock64();
     PLAN_STAMP(0)
-    const int bins = (a.kcap + 1) * a.fb;
+    const int bins = (a.kcap + 1) * a.key.fb, gb = a.key.gb;
     const int per = (bins + 1023) / 1024;
-    {   // scan of the histogram.  Bins below lds_bins are staged in LDS with coalesced loads (a strided
-        // per-thread walk over global memory would be ~2*per dependent round trips), scanned there, and
-        // written back coalesced; each thread owns `per` consecutive bins.
-        const int nl = min(bins, a.lds_bins);
-#pragma unroll 4
-        for (int b = threadIdx.x; b < nl; b += 1024) {
-            s_start[b] = a.hist[b];
-            a.hist[b] = 0;  // leave the histogram clean for the next step (no per-step memset)
-        }
-        if (threadIdx.x < CAND_SHARDS) a.ctr->ncand[threadIdx.x] = 0;
-        if (threadIdx.x == 64) {
-            a.ctr->err = 0;
-            a.ctr->overflow = 0;
-            a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
-            a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = a.ctr->pairs_in_band = 0;
-        }
-        __syncthreads();
-        const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
-        unsigned long long sum = 0;
-        for (int b = b0; b < b1; b++) sum += (unsigned)(b < nl ? s_start[b] : a.hist[b]);
-        unsigned long long tot;
-        unsigned long long ex = block_excl_scan_1024(sum, tmp, &tot);
-        int run = (int)ex;
-        for (int b = b0; b < b1; b++) {
-            const int c = b < nl ? s_start[b] : a.hist[b];
-            if (b < nl) {
-                s_start[b] = run;
-            } else {
-                a.start[b] = run;
-                a.hist[b] = 0;
-            }
+    if (threadIdx.x < CAND_SHARDS) a.ctr->ncand[threadIdx.x] = 0;
+    if (threadIdx.x == 64) {
+        a.ctr->err = 0;
+        a.ctr->overflow = 0;
+        a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
+        a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
+    }
+    const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; b++) {
+        int run = 0;
+        for (int g = 0; g < gb; g++) {
+            const int c = a.hist3[(size_t)b * gb + g];
+            a.sub3[(size_t)b * gb + g] = run;
+            a.hist3[(size_t)b * gb + g] = 0;
             run += c;
         }
-        if (threadIdx.x == 0) {
-            a.start[bins] = a.n;
-            if (bins < a.lds_bins) s_start[bins] = a.n;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int b = threadIdx.x; b < nl; b += 1024) a.start[b] = s_start[b];
+        a.start[b] = run;  // bin total for now
+        sum += (unsigned)run;
     }
-    __threadfence_block();
-    __syncthreads();
+    unsigned long long tot;
+    const unsigned long long ex = block_excl_scan_1024(sum, tmp, &tot);
+    int run = (int)ex;
+    for (int b = b0; b < b1; b++) {
+        const int c = a.start[b];
+        a.start[b] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) a.start[bins] = a.n;
     PLAN_STAMP(1)
+}
+
+// first sorted position of key (bin2, g); g == gb means the end of the bin
+__device__ __forceinline__ int start3(const PlanArgs &a, int bin2, int g) {
+    return g >= a.key.gb ? a.start[bin2 + 1] : a.start[bin2] + a.sub3[(size_t)bin2 * a.key.gb + g];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tiles (one block, after k_place): for every wave-tile of TR sorted rows the column ranges it must scan.
+// A tile inside ONE (k,f) bin (the heavy case: ~1000 rows per bin at 100k rows) gets one range per column
+// (k', f') with the g band of its own rows; a tile that spans bins gets one range per column length with
+// the full f band of its rows.  Candidates are flattened (one thread each), touching ranges of a tile are
+// merged, and the ranges become work items with a running count of "units" (one unit = one chunk of CB
+// columns against the tile, plus a fixed price per item); the units are what the prefilter's waves divide
+// among themselves, so every wave gets the same amount of work.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tiles(PlanArgs a) {
+    __shared__ unsigned long long tmp[40];
+    __shared__ int4 s_tile[1024];   // {key3 of first row, key3 of last row, n candidates, single-bin flag}
+    __shared__ int4 s_rng[1024];
+    __shared__ int s_cpre[1025];
+    PLAN_STAMP(2)
+    const int fb = a.key.fb, gb = a.key.gb, d = a.d, d1 = a.d + 1;
     {   // statistic: unordered pairs inside the reference's length band  sum_k c_k(c_k-1)/2 + sum_{k<k'<=k+d} c_k c_k'
         unsigned long long acc = 0;
         for (int k = threadIdx.x; k <= a.kcap; k += 1024) {
-            const unsigned long long c =
-                (unsigned)(plan_start(a, s_start, (k + 1) * a.fb) - plan_start(a, s_start, k * a.fb));
+            const unsigned long long c = (unsigned)(a.start[(k + 1) * fb] - a.start[k * fb]);
             if (!c) continue;
-            const int k2 = min(k + a.d, a.kcap);
-            const unsigned long long s =
-                (unsigned)(plan_start(a, s_start, (k2 + 1) * a.fb) - plan_start(a, s_start, (k + 1) * a.fb));
+            const int k2 = min(k + d, a.kcap);
+            const unsigned long long s = (unsigned)(a.start[(k2 + 1) * fb] - a.start[(k + 1) * fb]);
             acc += c * (c - 1) / 2 + c * s;
         }
         for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+        if (threadIdx.x == 0) a.ctr->pairs_in_band = 0;
+        __syncthreads();
         if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&a.ctr->pairs_in_band, acc);
     }
-    PLAN_STAMP(2)
-    // tiles -> (tile, column length) candidates -> non-empty ranges = work items.  Flattened so that every
-    // range is evaluated by its own thread (a per-tile loop over column lengths runs at single-wave
-    // latency: ~20 us at 100k rows).
-    __shared__ int4 s_tile[1024];
-    __shared__ int4 s_rng[1024];
-    __shared__ int s_cpre[1025];
     const int T = (a.n + a.tr - 1) / a.tr;
     unsigned long long carry_i = 0, carry_u = 0;
     for (int base = 0; base < T; base += 1024) {
         const int t = base + threadIdx.x;
-        int nk = 0;
+        int nc = 0;
         if (t < T) {
             const int row0 = t * a.tr;
             const int plast = min(a.n, row0 + a.tr) - 1;
-            int lo = 0, hi = bins - 1;  // bin of a position p: largest b with start[b] <= p
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (plan_start(a, s_start, mid) <= row0) lo = mid;
-                else hi = mid - 1;
-            }
-            const int blo = lo;
-            hi = bins - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (plan_start(a, s_start, mid) <= plast) lo = mid;
-                else hi = mid - 1;
-            }
-            const int k_lo = blo / a.fb, k_hi = lo / a.fb;
-            s_tile[threadIdx.x] = make_int4(k_lo, blo - k_lo * a.fb, k_hi, lo - k_hi * a.fb);
-            nk = min(k_hi + a.d, a.kcap) - k_lo + 1;
+            const int key_lo = a.keysorted[row0], key_hi = a.keysorted[plast];
+            const int bin_lo = key_lo / gb, bin_hi = key_hi / gb;
+            const int k_lo = bin_lo / fb, k_hi = bin_hi / fb;
+            const bool single = bin_lo == bin_hi && d1 * d1 <= 64;  // large d: one range per column length
+            nc = single ? d1 * d1 : (min(k_hi + d, a.kcap) - k_lo + 1);
+            s_tile[threadIdx.x] = make_int4(key_lo, key_hi, nc, single ? 1 : 0);
         }
         unsigned long long totc;
-        const unsigned long long exc = block_excl_scan_1024((unsigned long long)nk, tmp, &totc);
+        const unsigned long long exc = block_excl_scan_1024((unsigned long long)nc, tmp, &totc);
         s_cpre[threadIdx.x] = (int)exc;
         if (threadIdx.x == 0) s_cpre[1024] = (int)totc;
         __syncthreads();
@@ -291,11 +276,46 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
                     else hi = mid - 1;
                 }
                 const int4 ti = s_tile[lo];
+                const int ci = c - s_cpre[lo];
                 row0 = (base + lo) * a.tr;
-                has = tile_range(a, s_start, row0, ti.x, ti.y, ti.z, ti.w, ti.x + (c - s_cpre[lo]), &cb, &ce);
+                const int bin_lo = ti.x / gb, bin_hi = ti.y / gb;
+                const int k_lo = bin_lo / fb, f_lo = bin_lo % fb, k_hi = bin_hi / fb, f_hi = bin_hi % fb;
+                if (ti.w) {  // tile inside one (k,f) bin: candidate = (column length, column f bucket)
+                    const int kp = k_lo + ci / d1, delta = ci / d1;
+                    if (kp <= a.kcap) {
+                        const int amax = (d - delta) >> 1, bmax = amax + delta;
+                        int fa, fz, ga, gz;
+                        key_band(f_lo, f_lo, k_lo, kp, amax, bmax, fb, &fa, &fz);
+                        key_band(ti.x % gb, ti.y % gb, k_lo, kp, amax, bmax, gb, &ga, &gz);
+                        const int fp = fa + ci % d1;
+                        if (fp <= fz && ga <= gz) {
+                            cb = max(start3(a, kp * fb + fp, ga), row0);  // q > p >= row0
+                            ce = start3(a, kp * fb + fp, gz + 1);
+                            has = ce > cb;
+                        }
+                    }
+                } else {  // tile spans bins: candidate = column length, full f band of the tile's rows, all g
+                    const int kp = k_lo + ci;
+                    int fa = 0x7fffffff, fz = -1;
+                    for (int delta = 0; delta <= d; delta++) {
+                        const int k = kp - delta;
+                        if (k < k_lo || k > k_hi) continue;
+                        const int rlo = (k == k_lo) ? f_lo : 0, rhi = (k == k_hi) ? f_hi : fb - 1;
+                        const int amax = (d - delta) >> 1, bmax = amax + delta;
+                        int x, y;
+                        key_band(rlo, rhi, k, kp, amax, bmax, fb, &x, &y);
+                        fa = min(fa, x);
+                        fz = max(fz, y);
+                    }
+                    if (fa <= fz) {
+                        cb = max(a.start[kp * fb + fa], row0);
+                        ce = a.start[kp * fb + fz + 1];
+                        has = ce > cb;
+                    }
+                }
             }
-            // Ranges of one tile that touch (sparse tails: a tile spans many lengths and each range is a whole
-            // length bin) are merged into ONE item: an item switch costs the prefilter a dependent round trip.
+            // Ranges of one tile that touch are merged into ONE item: an item switch costs the prefilter a
+            // dependent round trip.
             s_rng[threadIdx.x] = has ? make_int4(row0, cb, ce, 0) : make_int4(-1, 0, 0, 0);
             __syncthreads();
             bool head = has;
@@ -338,8 +358,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs a) {
     }
     if (n_items > a.item_cap || U == 0 || carry_u >= 0x7fffffffull) return;
     // first item of every worker: worker vb starts at unit floor(vb * U / nvblocks).  The items' unit offsets are
-    // staged in LDS (re-using s_rng) and every worker binary-searches them; beyond 4096 items fall back to
-    // walking the items.
+    // staged in LDS (re-using s_rng) and every worker binary-searches them; beyond 4096 items walk the items.
     int *s_ust = reinterpret_cast<int *>(s_rng);
     if (n_items <= 4096) {
         for (int w = threadIdx.x; w < n_items; w += 1024) s_ust[w] = ld_agent(reinterpret_cast<const int *>(&a.items[w]) + 3);
@@ -484,10 +503,10 @@ __device__ __forceinline__ void wave_bitonic_bpermute(uint32_t (&x)[E], int lane
     }
 }
 
-// the row's sort key: bin = k*FB + (f >> fshift)
+// the row's sort key (k, f, g) -> key3
 struct RowKeyArgs {
-    int *hist, *rowbin, *rowrank;
-    int fb, fshift;
+    int *rowkey;
+    KeyCfg key;
 };
 
 template <int E, int W1>
@@ -495,14 +514,15 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
                                           int lane, uint32_t *lds_row, uint32_t *sig1_out, uint32_t *sig2_out,
                                           const RowKeyArgs &rk, int row) {
     uint32_t x[E];
-    int f = 0;
+    int f = 0, g = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         int j = e * 64 + lane;
         x[e] = j < k ? src[j] : 0xFFFFFFFFu;
         f += __popcll(__builtin_amdgcn_ballot_w64(j < k && fbit(x[e]) != 0u));
+        g += __popcll(__builtin_amdgcn_ballot_w64(j < k && gbit(x[e]) != 0u));
     }
-    const int bin = k * rk.fb + min(f >> rk.fshift, rk.fb - 1);
+    const int key3 = key3_of(rk.key, k, f, g);
     wave_bitonic<E>(x, lane);
     // repeat rank r_j = number of equal predecessors (0 unless the multiset row repeats a token)
     uint32_t r[E];
@@ -565,7 +585,7 @@ __device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint
 #pragma unroll
         for (int w = 0; w < SIG2_WORDS; w++) sig2_out[w] = s2[w];
     }
-    if (lane == 0) rk.rowbin[row] = bin;  // ranked by k_rowrank (a returning atomic here would stall the wave)
+    if (lane == 0) rk.rowkey[row] = key3;  // ranked by k_rowrank (a returning atomic here would stall the wave)
 }
 
 template <int W1>
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
                                                      int lds_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t row_lds[];
     __shared__ uint32_t s1[4], s2[SIG2_WORDS];
-    __shared__ int sf;
+    __shared__ int sf, sg;
     const int nlong = (int)ctr->n_long;
     for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
         int i = longrows[li];
@@ -628,14 +648,15 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
         const bool staged = k <= lds_cap;
         if (threadIdx.x < 4) s1[threadIdx.x] = 0;
         if (threadIdx.x < SIG2_WORDS) s2[threadIdx.x] = 0;
-        if (threadIdx.x == 0) sf = 0;
+        if (threadIdx.x == 0) sf = sg = 0;
         if (staged)
             for (int j = threadIdx.x; j < k; j += 256) row_lds[j] = src[j];
         __syncthreads();
-        int fl = 0;
+        int fl = 0, gl = 0;
         for (int j = threadIdx.x; j < k; j += 256) {
             uint32_t x = staged ? row_lds[j] : src[j];
             fl += (int)fbit(x);
+            gl += (int)gbit(x);
             int rank = 0;
             if (staged) {
                 for (int m = 0; m < k; m++) {
@@ -651,6 +672,7 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
             __hip_atomic_store(dst + rank, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (fl) atomicAdd(&sf, fl);
+        if (gl) atomicAdd(&sg, gl);
         __threadfence_block();
         __syncthreads();
         for (int j = threadIdx.x; j < k; j += 256) {
@@ -665,50 +687,38 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
         __syncthreads();
         if (threadIdx.x < W1) sigu1[(size_t)i * W1 + threadIdx.x] = s1[threadIdx.x];
         if (threadIdx.x < SIG2_WORDS) sigu2[(size_t)i * SIG2_WORDS + threadIdx.x] = s2[threadIdx.x];
-        if (threadIdx.x == 0) rk.rowbin[i] = k * rk.fb + min(sf >> rk.fshift, rk.fb - 1);
+        if (threadIdx.x == 0) rk.rowkey[i] = key3_of(rk.key, k, sf, sg);
         __syncthreads();
     }
 }
 
-// k_rowrank: histogram of the (k,f) bins and every row's rank inside its bin.  ~170 rows share a bin at 100k
-// rows and returning global atomics on one word serialise, so a 1024-thread block ranks its 1024 rows in an
-// LDS copy of the histogram and reserves one range per touched bin with a single global atomic (bins beyond
-// the LDS copy fall back to per-row global atomics).
-__global__ __launch_bounds__(1024) void k_rowrank(const int *__restrict__ rowbin, int n, int lds_bins, int *hist,
-                                                   int *__restrict__ rowrank) {
-    extern __shared__ __attribute__((aligned(16))) int lh[];
-    for (int b = threadIdx.x; b < lds_bins; b += 1024) lh[b] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int bin = 0, rank = 0;
-    if (i < n) {
-        bin = rowbin[i];
-        rank = bin < lds_bins ? atomicAdd(&lh[bin], 1) : atomicAdd(&hist[bin], 1);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < lds_bins; b += 1024) {
-        const int c = lh[b];
-        if (c) lh[b] = atomicAdd(&hist[b], c);  // base of this block's range in the bin
-    }
-    __syncthreads();
-    if (i < n) rowrank[i] = rank + (bin < lds_bins ? lh[bin] : 0);
+// k_rowrank: histogram of the (k,f,g) keys and every row's rank inside its key: one returning atomic per row.
+// (With the g sub-bins only ~13 rows share a counter at 100k rows, so the word-level serialisation that forced
+// an LDS-aggregated version for (k,f) bins is gone.)
+__global__ __launch_bounds__(256) void k_rowrank(const int *__restrict__ rowkey, int n, int *hist3,
+                                                  int *__restrict__ rowrank) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rowrank[i] = atomicAdd(&hist3[rowkey[i]], 1);
 }
 
-// k_place: counting-sort scatter.  Row i goes to sorted position start[bin] + rank; its length and its two
-// signatures move with it (the prefilter reads signatures in sorted order, coalesced).
+// k_place: counting-sort scatter.  Row i goes to sorted position start[bin] + sub3[key] + rank; its key, its
+// length and its two signatures move with it (the prefilter reads signatures in sorted order, coalesced).
 template <int W1>
-__global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap,
-                                                const int *__restrict__ start, const int *__restrict__ rowbin,
-                                                const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
-                                                const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
-                                                int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
+__global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap, int gb,
+                                                const int *__restrict__ start, const int *__restrict__ sub3,
+                                                const int *__restrict__ rowkey, const int *__restrict__ rowrank,
+                                                const uint32_t *__restrict__ sigu1, const uint32_t *__restrict__ sigu2,
+                                                int *__restrict__ perm, int *__restrict__ ksorted,
+                                                int *__restrict__ keysorted, uint32_t *__restrict__ sig1,
                                                 uint32_t *__restrict__ sig2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int p = start[rowbin[i]] + rowrank[i];
+    const int key = rowkey[i];
+    const int p = start[key / gb] + sub3[key] + rowrank[i];
     const int k = indptr[i + 1] - indptr[i];
     perm[p] = i;
     ksorted[p] = k < 0 ? 0 : (k > kcap ? kcap : k);
+    keysorted[p] = key;
 #pragma unroll
     for (int w = 0; w < W1; w++) sig1[(size_t)p * W1 + w] = sigu1[(size_t)i * W1 + w];
 #pragma unroll
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
     unsigned u0, u1;
     int w;
     const unsigned long long t_start = pa.dbg_t ? wall_clock64() : 0ull;
-    if (blk_item) {  // normal run: slices of the whole unit space, first item precomputed by k_plan
+    if (blk_item) {  // normal run: slices of the whole unit space, first item precomputed by k_tiles
         const unsigned U = pa.ctr->n_units;
         const unsigned vb = (unsigned)(vb0 + blockIdx.x) * 4u + (unsigned)wave;
         u0 = unit_cut(U, vb, (unsigned)nvb);
@@ -1003,7 +1013,7 @@ __global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict
         o[6] = xcc;
         o[7] = evaluated;
     }
-    // (no per-wave statistics atomics here: 5120 adds to one word serialise to ~50 us; k_plan counts the units)
+    // (no per-wave statistics atomics here: 5120 adds to one word serialise to ~50 us; k_tiles counts the units)
     (void)evaluated;
 }
 
@@ -1280,27 +1290,23 @@ int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/) {
     const int n = pl.n;
     if (ev) (void)hipEventRecord(ev[0], st);
-    const int bins1 = (pl.kcap + 1) * pl.fb + 1;
-    const int lds_bins = min(bins1, PLAN_LDS_BINS);
     RowKeyArgs rk;
-    rk.hist = pl.hist;
-    rk.rowbin = pl.rowbin;
-    rk.rowrank = pl.rowrank;
-    rk.fb = pl.fb;
-    rk.fshift = pl.fshift;
+    rk.rowkey = pl.rowkey;
+    rk.key.fb = pl.fb;
+    rk.key.gb = pl.gb;
     const int canon_blocks = min((n + 3) / 4, 256 * 16);
     const int lds_cap = pl.long_lds_cap;
     PlanArgs pa;
-    pa.lds_bins = lds_bins;
-    pa.hist = pl.hist;
+    pa.hist3 = pl.hist3;
+    pa.sub3 = pl.sub3;
     pa.start = pl.start;
+    pa.keysorted = pl.keysorted;
     pa.items = pl.items;
     pa.blk_item = pl.blk_item;
     pa.ctr = pl.ctr;
+    pa.key = rk.key;
     pa.n = n;
     pa.kcap = pl.kcap;
-    pa.fb = pl.fb;
-    pa.fshift = pl.fshift;
     pa.d = pl.d;
     pa.tr = pl.tr;
     pa.cb = pl.cb;
@@ -1314,11 +1320,12 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         if (pl.kcap > 256)                                                                                                \
             hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,         \
                                pl.indices, pl.kcap, rk, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr, lds_cap);        \
-        hipLaunchKernelGGL(k_rowrank, dim3((n + 1023) / 1024), dim3(1024), (size_t)lds_bins * 4, st, pl.rowbin, n,        \
-                           lds_bins, pl.hist, pl.rowrank);                                                                \
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), (size_t)lds_bins * 4, st, pa);                                    \
-        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.start,           \
-                           pl.rowbin, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2);              \
+        hipLaunchKernelGGL(k_rowrank, dim3((n + 255) / 256), dim3(256), 0, st, pl.rowkey, n, pl.hist3, pl.rowrank);        \
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, pa);                                                       \
+        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.gb, pl.start,    \
+                           pl.sub3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.keysorted, pl.sig1, \
+                           pl.sig2);                                                                                      \
+        hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, pa);                                                      \
         break;
         PREP_CASE(1)
         PREP_CASE(2)
