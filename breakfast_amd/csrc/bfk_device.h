@@ -5,16 +5,13 @@
 
 namespace bfk {
 
-constexpr int KEY_BUCKETS = 32;        // f / g buckets per row length in the (k,f,g) sort key (window around k/2)
+constexpr int KEY_BUCKETS = 16;        // f / g buckets per row length in the (k,f,g) sort key (window around k/2)
 constexpr int KEY_MAX_BINS3 = 1 << 24; // cap on (kmax+1)*fb*gb counters (64 MiB); buckets are halved beyond it
 constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
 constexpr int CAND_SHARDS = 64;        // candidate queue shards: returning atomics on one word serialise (~90/us)
+constexpr int PF_WAVES = 2;            // waves per prefilter block = waves sharing one tile
 constexpr int PF_LDS_QUEUE = 512;      // per-wave LDS hit queue entries (4 KiB per wave), drained at half full
 constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane group in k_verify (512 B/group)
-constexpr int PF_ROWS_W1 = 4;          // rows per thread in k_prefilter by signature width
-constexpr int PF_ROWS_W2 = 4;
-constexpr int PF_ROWS_W4 = 2;
-constexpr unsigned ITEM_OVH_UNITS = 2;  // unit-space price of switching work items (load balance only)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
 constexpr int LONG_LDS_CAP = 15360;    // tokens of a long row staged in LDS by k_canon_long (60 KiB)
 
@@ -24,8 +21,8 @@ struct Counters {
     unsigned int ncand[CAND_SHARDS];
     int err;
     int err_rows;  // set by k_canon (row longer than at bind time); cleared by the host only
-    unsigned int n_work;   // work items
-    unsigned int n_units;  // total units (batches of CB columns x one row tile)
+    unsigned int n_work;   // tiles
+    unsigned int ticket;   // arrival order of the k_cells blocks
     unsigned int n_long;
     int overflow;
     unsigned long long pairs_in_band;
@@ -39,17 +36,18 @@ struct Counters {
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
 struct Plan {
     int n, kcap, d, w1;
-    int tr, cb, fb, gb;
+    int rows_per_lane, fb, gb;
     int shard, n_shards;
-    int pf_grid, verify_grid, union_grid;
-    int item_cap, cand_cap_shard, edge_cap, long_lds_cap, dbg;
+    int verify_grid, union_grid;
+    int tile_cap, cand_cap_shard, edge_cap, long_lds_cap, dbg;
     const int *indptr;
     const uint32_t *indices;
     uint32_t *cols;
-    int *hist3, *sub3, *start, *rowkey, *rowrank, *keysorted, *blk_item;
+    int *hist3, *start3, *rowkey, *rowrank, *tile_slots;
+    unsigned long long *chain;
     int *perm, *ksorted, *parent, *longrows;
     uint32_t *sig1, *sig2, *sigu1, *sigu2;
-    int4 *items;
+    int4 *tiles;
     int4 *cand;
     int2 *candk;
     int2 *edges;  // NULL unless edge capture is on
@@ -60,7 +58,7 @@ struct Plan {
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
-int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEvent_t *ev);
+int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev);
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_lists(int *parent, int n, const long long *off, const int *flat, long long total, int n_lists, int *labels,
                  Counters *ctr, hipStream_t st);

@@ -161,7 +161,8 @@ struct bfk_ctx {
     // workspace
     char *d_head = nullptr;  // Counters | hist[bins]
     int64_t bins_cap = 0;
-    int *d_start = nullptr, *d_sub3 = nullptr, *d_keysorted = nullptr;
+    int *d_start3 = nullptr, *d_tile_slots = nullptr;
+    unsigned long long *d_chain = nullptr;
     int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
     int64_t bins3 = 0;
     uint32_t *d_cols = nullptr;
@@ -170,10 +171,10 @@ struct bfk_ctx {
     uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
     bool need_zero = true;  // head (counters + histogram) must be memset before the next run
     int64_t rows_cap = 0;
-    int4 *d_items = nullptr;
-    int64_t item_cap = 0;
-    int *d_rowkey = nullptr, *d_rowrank = nullptr, *d_blk = nullptr;
-    int64_t blk_cap = 0;
+    int4 *d_tiles = nullptr;
+    int64_t tile_cap = 0, tile_slots_cap = 0;
+    int rows_per_lane = 1;
+    int *d_rowkey = nullptr, *d_rowrank = nullptr;
     int4 *d_cand = nullptr;
     int2 *d_candk = nullptr;
     int64_t candk_cap = 0;
@@ -239,10 +240,10 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start,    c->d_cols,   c->d_perm,   c->d_sigu1,
-                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_items,  c->d_rowkey,
-                    c->d_rowrank,  c->d_blk,       c->d_cand,   c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
-                    c->d_sub3,     c->d_keysorted};
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_cols,   c->d_perm,   c->d_sigu1,
+                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
+                    c->d_rowrank,  c->d_tile_slots, c->d_cand,  c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
+                    c->d_chain};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -294,19 +295,19 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     c->fb = c->gb = KEY_BUCKETS;
     while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->gb > 1) c->gb >>= 1;
     while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->fb > 1) c->fb >>= 1;
-    const int64_t bins2 = ((int64_t)c->kcap + 1) * c->fb + 2;
     const int64_t bins3 = ((int64_t)c->kcap + 1) * c->fb * c->gb + 2;
     if (bins3 > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the sort-key index");
     c->bins3 = bins3;
     if (bins3 > c->bins_cap || !c->d_head) {
-        for (void *q : {(void *)c->d_head, (void *)c->d_start, (void *)c->d_sub3})
+        for (void *q : {(void *)c->d_head, (void *)c->d_start3, (void *)c->d_chain})
             if (q) (void)hipFree(q);
         c->d_head = nullptr;
-        c->d_start = c->d_sub3 = nullptr;
+        c->d_start3 = nullptr;
+        c->d_chain = nullptr;
         c->bins_cap = 0;
         size_t head = sizeof(Counters) + (size_t)bins3 * 4;
-        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start, (size_t)bins2 * 4) != hipSuccess ||
-            hipMalloc((void **)&c->d_sub3, (size_t)bins3 * 4) != hipSuccess)
+        if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start3, (size_t)bins3 * 4) != hipSuccess ||
+            hipMalloc((void **)&c->d_chain, (size_t)(bins3 / 8192 + 2) * 8) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins3;
         c->need_zero = true;
@@ -320,7 +321,6 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowkey, &cap, want);
-        cap = 0; rc |= dev_realloc(&c->d_keysorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
         cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
@@ -332,18 +332,19 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         HIP_TRY(hipMemsetAsync(c->d_sig1, 0xFF, (size_t)(want * 4 + 16) * 4, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_sig2, 0xFF, (size_t)(want * SIG2_WORDS + 16) * 4, c->stream));
     }
-    {   // work items: one per (row tile, column length) pair that has a band: the k-spans of the tiles
-        // telescope, so <= (kcap+1) + T*(d+2); T for the smallest row tile (256*PF_ROWS_W4)
-        const int64_t T = (n + 64 * PF_ROWS_W4 - 1) / (64 * PF_ROWS_W4);
-        const int64_t dd = std::min<int64_t>(d_hint, c->kcap + 1);
-        const int64_t per_tile = std::max<int64_t>(dd + 3, (dd + 1) * (dd + 1) <= 64 ? (dd + 1) * (dd + 1) : 0);
-        const int64_t want = (int64_t)c->kcap + 2 + T * per_tile + 64;
-        if (int rc = dev_realloc(&c->d_items, &c->item_cap, want, 1.25)) return rc;
+    {   // rows per lane of the prefilter tile: cells hold ~N/(lengths x f x g buckets) rows, a tile never crosses
+        // a cell, so small inputs use 64-row tiles and only very large ones 256-row tiles
+        c->rows_per_lane = n < (2 << 20) ? 1 : (n < (8 << 20) ? 2 : 4);
+        if (const char *e = getenv("BFK_PF_ROWS")) c->rows_per_lane = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+        // tiles: one per non-empty cell plus one per full tile of rows
+        const int64_t want = std::min<int64_t>(bins3, n) + n / (64 * c->rows_per_lane) + 16;
+        if (int rc = dev_realloc(&c->d_tiles, &c->tile_cap, want, 1.0)) return rc;
+        if (int rc = dev_realloc(&c->d_tile_slots, &c->tile_slots_cap, c->tile_cap * PF_WAVES, 1.0)) return rc;
     }
     {
         // per shard: 4N pairs (8 shards -> 32N), and never less than one unit's pair slots
         // total 32N pairs; every shard holds at least one unit's pair slots (64 lanes x R rows x 64 columns)
-        int64_t want = std::max<int64_t>((int64_t)64 * PF_ROWS_W1 * 64, (32 * n) / CAND_SHARDS + 1024);
+        int64_t want = std::max<int64_t>((int64_t)64 * 4 * 64, (32 * n) / CAND_SHARDS + 1024);
         if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;
@@ -421,19 +422,14 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.kcap = c->kcap;
     pl.d = std::min<int>(max_dist, 1 << 20);
     pl.w1 = c->last_w1;
-    const int R = pl.w1 == 1 ? PF_ROWS_W1 : (pl.w1 == 2 ? PF_ROWS_W2 : PF_ROWS_W4);
-    pl.tr = 64 * R;  // a wave-tile: 64 lanes x R rows
-    pl.cb = 64 / pl.w1;  // columns per unit: one 256-byte chunk of first-level signatures
+    pl.rows_per_lane = c->rows_per_lane;
     pl.fb = c->fb;
     pl.gb = c->gb;
     pl.shard = shard;
     pl.n_shards = n_shards;
-    pl.pf_grid = 1280;  // 256 CUs x 5 resident blocks: every wave gets an equal slice of the units
-    if (const char *e = getenv("BFK_PF_GRID")) pl.pf_grid = std::max(1, atoi(e));
     pl.verify_grid = 2048;
     pl.union_grid = 512;
-    pl.item_cap = (int)std::min<int64_t>(c->item_cap, INT32_MAX);
-    if (int rc = dev_realloc(&c->d_blk, &c->blk_cap, (int64_t)n_shards * pl.pf_grid * 4)) return rc;
+    pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
     pl.long_lds_cap = LONG_LDS_CAP;
@@ -441,7 +437,13 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.dbg_t = nullptr;
     if (pl.dbg & 4) {
         static unsigned long long *dbg_buf = nullptr;
-        if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, (size_t)pl.pf_grid * 4 * 8 * 8);
+        static int64_t dbg_cap = 0;
+        if (dbg_cap < c->tile_cap) {
+            if (dbg_buf) (void)hipFree(dbg_buf);
+            (void)hipMalloc((void **)&dbg_buf, (size_t)c->tile_cap * PF_WAVES * 8 * 8);
+            dbg_cap = c->tile_cap;
+        }
+        (void)hipMemsetAsync(dbg_buf, 0, (size_t)c->tile_cap * PF_WAVES * 8 * 8, c->stream);
         pl.dbg_t = dbg_buf;
     }
     pl.indptr = c->d_indptr;
@@ -449,12 +451,11 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.cols = c->d_cols;
     pl.ctr = (Counters *)c->d_head;
     pl.hist3 = (int *)(c->d_head + sizeof(Counters));
-    pl.sub3 = c->d_sub3;
-    pl.keysorted = c->d_keysorted;
-    pl.start = c->d_start;
+    pl.start3 = c->d_start3;
     pl.rowkey = c->d_rowkey;
     pl.rowrank = c->d_rowrank;
-    pl.blk_item = c->d_blk;
+    pl.tile_slots = c->d_tile_slots;
+    pl.chain = c->d_chain;
     pl.perm = c->d_perm;
     pl.ksorted = c->d_ksorted;
     pl.parent = c->d_parent;
@@ -463,7 +464,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.sig2 = c->d_sig2;
     pl.sigu1 = c->d_sigu1;
     pl.sigu2 = c->d_sigu2;
-    pl.items = c->d_items;
+    pl.tiles = c->d_tiles;
     pl.cand = c->d_cand;
     pl.candk = c->d_candk;
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
@@ -471,6 +472,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
         HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->bins3 * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_chain, 0, (size_t)(c->bins3 / 8192 + 2) * 8, c->stream));
         c->need_zero = false;
     }
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
@@ -498,9 +500,7 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
 // Unions are idempotent, so re-verifying pairs is harmless.  Synchronous (called from bfk_ctx_sync).
 static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  // slices are unit ranges
     Plan &pl = c->plan;
-    const unsigned U = h->n_units;
-    const int ulo = (int)(((unsigned long long)U * pl.shard) / pl.n_shards);
-    const int uhi = (int)(((unsigned long long)U * (pl.shard + 1)) / pl.n_shards);
+    const int ulo = 0, uhi = (int)h->n_work;  // tile index range (every shard walks its own stride of it)
     std::vector<std::pair<int, int>> todo;
     const int step0 = std::max(1, (uhi - ulo) / 16);
     for (int b = uhi; b > ulo; b -= step0) todo.push_back({std::max(ulo, b - step0), b});
@@ -562,10 +562,9 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
         if (getenv("BFK_DEBUG"))
-            fprintf(stderr, "[bfk] plan phases (us): k_scan %.1f | k_tiles: ranges %.1f workers %.1f\n", (h.dbg[1] - h.dbg[0]) / 100.0,
-                    (h.dbg[3] - h.dbg[2]) / 100.0, (h.dbg[4] - h.dbg[3]) / 100.0);
+            fprintf(stderr, "[bfk] k_cells %.1f us, %u tiles\n", (h.dbg[1] - h.dbg[0]) / 100.0, h.n_work);
         if (c->plan.dbg_t) {
-            std::vector<unsigned long long> t((size_t)c->plan.pf_grid * 4 * 8);
+            std::vector<unsigned long long> t((size_t)h.n_work * PF_WAVES * 8);
             (void)hipMemcpy(t.data(), c->plan.dbg_t, t.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = fopen("gpurun_out/pf_waves.txt", "w")) {
                 for (size_t i = 0; i < t.size(); i += 8)
@@ -581,7 +580,14 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
         s.pairs_in_band = (int64_t)h.pairs_in_band;
-        s.pairs_filtered = (int64_t)(h.pairs_filtered / (unsigned)c->last_shards);  // units are dealt evenly
+        {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
+            std::vector<int> ts((size_t)h.n_work * PF_WAVES);
+            if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
+            int64_t acc = 0;
+            for (size_t t = (size_t)c->plan.shard; t < (size_t)h.n_work; t += (size_t)c->plan.n_shards)
+                for (int w = 0; w < PF_WAVES; w++) acc += ts[t * PF_WAVES + w];
+            s.pairs_filtered = acc;
+        }
         s.n_candidates = (int64_t)h.n_cand_total;
         s.n_edges = (int64_t)h.n_edges;
         s.n_retry_slices = retry_slices;

@@ -4,8 +4,7 @@
 //   k_canon     one wave per row: sort key bin (k, f), bitonic sort of the token ids in registers, duplicate
 //               ranks, two XOR-parity signatures; parent[i] = i
 //   k_rowrank   (k,f,g) histogram + rank of every row inside its key
-//   k_scan      start[] of the (k,f) bins, prefix of the g sub-bins; re-zeroes histogram and counters
-//   k_tiles     per wave-tile the column ranges of its (k,f,g) band -> work items, cut into equal unit slices
+//   k_cells     scan of the (k,f,g) cell counters -> start3, tile list (tiles never cross cells); re-zeroes state
 //   k_place     counting-sort scatter of row ids / lengths / signatures into (k,f) order
 //   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
 //   k_prefilter THE dominant kernel: all in-band pairs, popcount(sig_p ^ sig_q) <= d  (necessary
@@ -21,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 namespace bfk {
 
@@ -153,241 +154,106 @@ __device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long
     return res;
 }
 
-struct PlanArgs {
-    int *hist3;        // (kcap+1)*fb*gb counters, re-zeroed by k_scan
-    int *sub3;         // exclusive prefix of hist3 inside every (k,f) bin
-    int *start;        // (kcap+1)*fb + 1: first sorted position of every (k,f) bin
-    const int *keysorted;  // key3 of the row at every sorted position (k_tiles)
-    int4 *items;       // {row0, cbeg, cend, ustart}
-    int *blk_item;     // first item of every worker
+struct CellArgs {
+    int *hist3;     // (kcap+1)*fb*gb cell counters, re-zeroed here
+    int *start3;    // cells + 1: first sorted position of every (k,f,g) cell
+    int4 *tiles;    // {first sorted row, rows, cell key, 0}: tiles never cross a cell boundary
+    unsigned long long *chain;  // one hand-off word per block of k_cells (zero between steps)
     Counters *ctr;
-    KeyCfg key;
-    int n, kcap, d, tr, cb, nvblocks, item_cap;
+    int n, cells, tr, tile_cap;
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_scan (one block): per (k,f) bin the exclusive prefix of its g sub-bins (sub3) and, across bins, the
-// exclusive scan of the bin totals (start).  Re-zeroes the histogram and the per-step counters, so a step
-// needs no memset.
+// k_cells: exclusive scan of the (k,f,g) cell counters -> start3, and the tile list: every non-empty cell is
+// cut into tiles of at most TR rows (a tile never crosses a cell boundary, so its band is as tight as the
+// sort key allows).  One block per 8192 cells; a block's base offset comes from its predecessor through a
+// chained hand-off (one 64-bit word per block: value + 1, published with an agent-scope release, polled with
+// relaxed loads then acquired — all blocks are co-resident: <= cells/8192 <= 2048).  The histogram and the
+// per-step counters are re-zeroed, so a step needs no memset; the hand-off words are re-zeroed by the last
+// block for the next step.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(PlanArgs a) {
+__global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
     __shared__ unsigned long long tmp[40];
+    __shared__ int s_cnt[8192];
+    __shared__ unsigned long long s_base;
+    __shared__ int s_bid;
+    // logical block order = order of arrival (HIP promises nothing about dispatch order): a block only ever
+    // waits for a block that has already started
+    if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.ctr->ticket, 1u);
+    __syncthreads();
+    const int bid = s_bid;
 #define PLAN_STAMP(i) if (threadIdx.x == 0) a.ctr->dbg[i] = wall_clock64();
-    PLAN_STAMP(0)
-    const int bins = (a.kcap + 1) * a.key.fb, gb = a.key.gb;
-    const int per = (bins + 1023) / 1024;
-    if (threadIdx.x < CAND_SHARDS) a.ctr->ncand[threadIdx.x] = 0;
-    if (threadIdx.x == 64) {
-        a.ctr->err = 0;
-        a.ctr->overflow = 0;
-        a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
-        a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
-    }
-    const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
-    unsigned long long sum = 0;
-    for (int b = b0; b < b1; b++) {
-        int run = 0;
-        for (int g = 0; g < gb; g++) {
-            const int c = a.hist3[(size_t)b * gb + g];
-            a.sub3[(size_t)b * gb + g] = run;
-            a.hist3[(size_t)b * gb + g] = 0;
-            run += c;
+    if (bid == 0) PLAN_STAMP(0)
+    if (bid == 0) {
+        if (threadIdx.x < CAND_SHARDS) a.ctr->ncand[threadIdx.x] = 0;
+        if (threadIdx.x == 64) {
+            a.ctr->err = 0;
+            a.ctr->overflow = 0;
+            a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
+            a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
         }
-        a.start[b] = run;  // bin total for now
-        sum += (unsigned)run;
+    }
+    const int base = bid * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = base + j * 1024 + threadIdx.x;
+        int v = 0;
+        if (c < a.cells) {
+            v = a.hist3[c];
+            a.hist3[c] = 0;
+        }
+        s_cnt[j * 1024 + threadIdx.x] = v;
+    }
+    __syncthreads();
+    int cnt[8];
+    unsigned long long sum = 0;  // tiles in the high word, rows in the low word
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        cnt[j] = s_cnt[threadIdx.x * 8 + j];
+        sum += ((unsigned long long)((cnt[j] + a.tr - 1) / a.tr) << 32) | (unsigned)cnt[j];
     }
     unsigned long long tot;
     const unsigned long long ex = block_excl_scan_1024(sum, tmp, &tot);
-    int run = (int)ex;
-    for (int b = b0; b < b1; b++) {
-        const int c = a.start[b];
-        a.start[b] = run;
-        run += c;
-    }
-    if (threadIdx.x == 0) a.start[bins] = a.n;
-    PLAN_STAMP(1)
-}
-
-// first sorted position of key (bin2, g); g == gb means the end of the bin
-__device__ __forceinline__ int start3(const PlanArgs &a, int bin2, int g) {
-    return g >= a.key.gb ? a.start[bin2 + 1] : a.start[bin2] + a.sub3[(size_t)bin2 * a.key.gb + g];
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_tiles (one block, after k_place): for every wave-tile of TR sorted rows the column ranges it must scan.
-// A tile inside ONE (k,f) bin (the heavy case: ~1000 rows per bin at 100k rows) gets one range per column
-// (k', f') with the g band of its own rows; a tile that spans bins gets one range per column length with
-// the full f band of its rows.  Candidates are flattened (one thread each), touching ranges of a tile are
-// merged, and the ranges become work items with a running count of "units" (one unit = one chunk of CB
-// columns against the tile, plus a fixed price per item); the units are what the prefilter's waves divide
-// among themselves, so every wave gets the same amount of work.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tiles(PlanArgs a) {
-    __shared__ unsigned long long tmp[40];
-    __shared__ int4 s_tile[1024];   // {key3 of first row, key3 of last row, n candidates, single-bin flag}
-    __shared__ int4 s_rng[1024];
-    __shared__ int s_cpre[1025];
-    PLAN_STAMP(2)
-    const int fb = a.key.fb, gb = a.key.gb, d = a.d, d1 = a.d + 1;
-    {   // statistic: unordered pairs inside the reference's length band  sum_k c_k(c_k-1)/2 + sum_{k<k'<=k+d} c_k c_k'
-        unsigned long long acc = 0;
-        for (int k = threadIdx.x; k <= a.kcap; k += 1024) {
-            const unsigned long long c = (unsigned)(a.start[(k + 1) * fb] - a.start[k * fb]);
-            if (!c) continue;
-            const int k2 = min(k + d, a.kcap);
-            const unsigned long long s = (unsigned)(a.start[(k2 + 1) * fb] - a.start[(k + 1) * fb]);
-            acc += c * (c - 1) / 2 + c * s;
-        }
-        for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-        if (threadIdx.x == 0) a.ctr->pairs_in_band = 0;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&a.ctr->pairs_in_band, acc);
-    }
-    const int T = (a.n + a.tr - 1) / a.tr;
-    unsigned long long carry_i = 0, carry_u = 0;
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + threadIdx.x;
-        int nc = 0;
-        if (t < T) {
-            const int row0 = t * a.tr;
-            const int plast = min(a.n, row0 + a.tr) - 1;
-            const int key_lo = a.keysorted[row0], key_hi = a.keysorted[plast];
-            const int bin_lo = key_lo / gb, bin_hi = key_hi / gb;
-            const int k_lo = bin_lo / fb, k_hi = bin_hi / fb;
-            const bool single = bin_lo == bin_hi && d1 * d1 <= 64;  // large d: one range per column length
-            nc = single ? d1 * d1 : (min(k_hi + d, a.kcap) - k_lo + 1);
-            s_tile[threadIdx.x] = make_int4(key_lo, key_hi, nc, single ? 1 : 0);
-        }
-        unsigned long long totc;
-        const unsigned long long exc = block_excl_scan_1024((unsigned long long)nc, tmp, &totc);
-        s_cpre[threadIdx.x] = (int)exc;
-        if (threadIdx.x == 0) s_cpre[1024] = (int)totc;
-        __syncthreads();
-        const int ntile = min(1024, T - base), C = (int)totc;
-        for (int cbase = 0; cbase < C; cbase += 1024) {
-            const int c = cbase + threadIdx.x;
-            int row0 = -1, cb = 0, ce = 0;
-            bool has = false;
-            if (c < C) {
-                int lo = 0, hi = ntile - 1;  // tile of candidate c: largest tt with cpre[tt] <= c
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (s_cpre[mid] <= c) lo = mid;
-                    else hi = mid - 1;
-                }
-                const int4 ti = s_tile[lo];
-                const int ci = c - s_cpre[lo];
-                row0 = (base + lo) * a.tr;
-                const int bin_lo = ti.x / gb, bin_hi = ti.y / gb;
-                const int k_lo = bin_lo / fb, f_lo = bin_lo % fb, k_hi = bin_hi / fb, f_hi = bin_hi % fb;
-                if (ti.w) {  // tile inside one (k,f) bin: candidate = (column length, column f bucket)
-                    const int kp = k_lo + ci / d1, delta = ci / d1;
-                    if (kp <= a.kcap) {
-                        const int amax = (d - delta) >> 1, bmax = amax + delta;
-                        int fa, fz, ga, gz;
-                        key_band(f_lo, f_lo, k_lo, kp, amax, bmax, fb, &fa, &fz);
-                        key_band(ti.x % gb, ti.y % gb, k_lo, kp, amax, bmax, gb, &ga, &gz);
-                        const int fp = fa + ci % d1;
-                        if (fp <= fz && ga <= gz) {
-                            cb = max(start3(a, kp * fb + fp, ga), row0);  // q > p >= row0
-                            ce = start3(a, kp * fb + fp, gz + 1);
-                            has = ce > cb;
-                        }
-                    }
-                } else {  // tile spans bins: candidate = column length, full f band of the tile's rows, all g
-                    const int kp = k_lo + ci;
-                    int fa = 0x7fffffff, fz = -1;
-                    for (int delta = 0; delta <= d; delta++) {
-                        const int k = kp - delta;
-                        if (k < k_lo || k > k_hi) continue;
-                        const int rlo = (k == k_lo) ? f_lo : 0, rhi = (k == k_hi) ? f_hi : fb - 1;
-                        const int amax = (d - delta) >> 1, bmax = amax + delta;
-                        int x, y;
-                        key_band(rlo, rhi, k, kp, amax, bmax, fb, &x, &y);
-                        fa = min(fa, x);
-                        fz = max(fz, y);
-                    }
-                    if (fa <= fz) {
-                        cb = max(a.start[kp * fb + fa], row0);
-                        ce = a.start[kp * fb + fz + 1];
-                        has = ce > cb;
-                    }
-                }
-            }
-            // Ranges of one tile that touch are merged into ONE item: an item switch costs the prefilter a
-            // dependent round trip.
-            s_rng[threadIdx.x] = has ? make_int4(row0, cb, ce, 0) : make_int4(-1, 0, 0, 0);
-            __syncthreads();
-            bool head = has;
-            if (has && threadIdx.x > 0) {
-                const int4 pv = s_rng[threadIdx.x - 1];
-                if (pv.x == row0 && pv.z == cb) head = false;  // continuation of the previous range
-            }
-            if (head) {
-                int nx = threadIdx.x + 1;
-                while (nx < 1024) {
-                    const int4 nr = s_rng[nx];
-                    if (nr.x != row0 || nr.y != ce) break;
-                    ce = nr.z;
-                    nx++;
-                }
-            }
-            const unsigned nun = head ? ITEM_OVH_UNITS + (unsigned)((ce - (cb & ~(a.cb - 1)) + a.cb - 1) / a.cb) : 0u;
-            unsigned long long tot_i, tot_u;
-            const unsigned long long ex_i = block_excl_scan_1024(head ? 1ull : 0ull, tmp, &tot_i);
-            const unsigned long long ex_u = block_excl_scan_1024((unsigned long long)nun, tmp, &tot_u);
-            if (head) {
-                const unsigned long long w = carry_i + ex_i;
-                if (w < (unsigned long long)a.item_cap) a.items[w] = make_int4(row0, cb, ce, (int)(unsigned)(carry_u + ex_u));
-            }
-            carry_i += tot_i;  // the scan returns the same totals to all threads
-            carry_u += tot_u;
-        }
-        __syncthreads();
-    }
-    __threadfence_block();
-    __syncthreads();
-    PLAN_STAMP(3)
-    const int n_items = (int)min(carry_i, (unsigned long long)0x7fffffff);
-    const unsigned U = (unsigned)carry_u;
     if (threadIdx.x == 0) {
-        if (n_items > a.item_cap || carry_u >= 0x7fffffffull) atomicOr(&a.ctr->err, ERR_WORKCAP);
-        a.ctr->n_work = (unsigned)min(n_items, a.item_cap);
-        a.ctr->n_units = U;
-        a.ctr->pairs_filtered = (carry_u - (unsigned long long)ITEM_OVH_UNITS * carry_i) * (unsigned long long)a.tr * a.cb;
-    }
-    if (n_items > a.item_cap || U == 0 || carry_u >= 0x7fffffffull) return;
-    // first item of every worker: worker vb starts at unit floor(vb * U / nvblocks).  The items' unit offsets are
-    // staged in LDS (re-using s_rng) and every worker binary-searches them; beyond 4096 items walk the items.
-    int *s_ust = reinterpret_cast<int *>(s_rng);
-    if (n_items <= 4096) {
-        for (int w = threadIdx.x; w < n_items; w += 1024) s_ust[w] = ld_agent(reinterpret_cast<const int *>(&a.items[w]) + 3);
-        __syncthreads();
-        for (int vb = threadIdx.x; vb < a.nvblocks; vb += 1024) {
-            const unsigned u0 = (unsigned)(((unsigned long long)vb * U) / (unsigned)a.nvblocks);
-            int lo = 0, hi = n_items - 1;  // largest w with ustart[w] <= u0
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if ((unsigned)s_ust[mid] <= u0) lo = mid;
-                else hi = mid - 1;
+        unsigned long long before = 0;
+        if (bid > 0) {
+            unsigned long long v;
+            int spins = 0;
+            while ((v = __hip_atomic_load(&a.chain[bid - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {  // never expected: bound the spin
+                    atomicOr(&a.ctr->err, ERR_WORKCAP);
+                    break;
+                }
             }
-            a.blk_item[vb] = lo;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            before = v - 1ull;
+            a.chain[bid - 1] = 0ull;  // consumed: clean for the next step
         }
-    } else {
-        for (int w = threadIdx.x; w < n_items; w += 1024) {
-            const int *ip = reinterpret_cast<const int *>(&a.items[w]);  // written by this block: bypass L1
-            const int4 it = make_int4(0, ld_agent(ip + 1), ld_agent(ip + 2), ld_agent(ip + 3));
-            const unsigned ua = (unsigned)it.w;
-            const unsigned ub = ua + ITEM_OVH_UNITS + (unsigned)((it.z - (it.y & ~(a.cb - 1)) + a.cb - 1) / a.cb);
-            unsigned vb = (unsigned)(((unsigned long long)ua * a.nvblocks + U - 1) / U);
-            while (vb < (unsigned)a.nvblocks && (unsigned)(((unsigned long long)vb * U) / a.nvblocks) < ub) {
-                a.blk_item[vb] = w;
-                vb++;
-            }
+        s_base = before;
+        if (bid + 1 < (int)gridDim.x) {
+            __hip_atomic_store(&a.chain[bid], before + tot + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            a.ctr->ticket = 0;  // every block has taken its ticket: clean for the next step
+            a.start3[a.cells] = a.n;
+            const unsigned nt = (unsigned)((before + tot) >> 32);
+            if (nt > (unsigned)a.tile_cap) atomicOr(&a.ctr->err, ERR_WORKCAP);
+            a.ctr->n_work = min(nt, (unsigned)a.tile_cap);
         }
     }
     __syncthreads();
-    PLAN_STAMP(4)
+    unsigned long long run = s_base + ex;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = base + threadIdx.x * 8 + j;
+        const int pos = (int)(unsigned)(run & 0xffffffffull);
+        int t = (int)(run >> 32);
+        if (c < a.cells) a.start3[c] = pos;
+        for (int r0 = 0; r0 < cnt[j]; r0 += a.tr, t++)
+            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(a.tr, cnt[j] - r0), c, 0);
+        run += ((unsigned long long)((cnt[j] + a.tr - 1) / a.tr) << 32) | (unsigned)cnt[j];
+    }
+    if (bid + 1 == (int)gridDim.x) PLAN_STAMP(1)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -692,33 +558,55 @@ __global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indp
     }
 }
 
-// k_rowrank: histogram of the (k,f,g) keys and every row's rank inside its key: one returning atomic per row.
-// (With the g sub-bins only ~13 rows share a counter at 100k rows, so the word-level serialisation that forced
-// an LDS-aggregated version for (k,f) bins is gone.)
-__global__ __launch_bounds__(256) void k_rowrank(const int *__restrict__ rowkey, int n, int *hist3,
-                                                  int *__restrict__ rowrank) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) rowrank[i] = atomicAdd(&hist3[rowkey[i]], 1);
+// k_rowrank: histogram of the (k,f,g) cells and every row's rank inside its cell.  Hub cells (e.g. the
+// children of a common ancestor: thousands of rows in 4 cells) make per-row returning atomics serialise, so a
+// 1024-row block first aggregates its rows in an LDS hash table keyed by cell (open addressing, 2048 slots)
+// and then reserves one range per distinct cell with a single global atomic.
+__global__ __launch_bounds__(1024) void k_rowrank(const int *__restrict__ rowkey, int n, int *hist3,
+                                                   int *__restrict__ rowrank) {
+    constexpr int SLOTS = 2048;
+    __shared__ int s_key[SLOTS], s_cnt[SLOTS];
+    for (int t = threadIdx.x; t < SLOTS; t += 1024) {
+        s_key[t] = -1;
+        s_cnt[t] = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int slot = 0, lr = 0;
+    if (i < n) {
+        const int key = rowkey[i];
+        slot = (int)(((uint32_t)key * 0x9E3779B1u) >> 21);  // 11 bits
+        while (true) {
+            const int old = atomicCAS(&s_key[slot], -1, key);
+            if (old == -1 || old == key) break;
+            slot = (slot + 1) & (SLOTS - 1);
+        }
+        lr = atomicAdd(&s_cnt[slot], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SLOTS; t += 1024) {
+        const int c = s_cnt[t];
+        if (c) s_cnt[t] = atomicAdd(&hist3[s_key[t]], c);  // base of this block's range in the cell
+    }
+    __syncthreads();
+    if (i < n) rowrank[i] = s_cnt[slot] + lr;
 }
 
-// k_place: counting-sort scatter.  Row i goes to sorted position start[bin] + sub3[key] + rank; its key, its
-// length and its two signatures move with it (the prefilter reads signatures in sorted order, coalesced).
+// k_place: counting-sort scatter.  Row i goes to sorted position start3[key] + rank; its length and its two
+// signatures move with it (the prefilter reads signatures in sorted order, coalesced).
 template <int W1>
-__global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap, int gb,
-                                                const int *__restrict__ start, const int *__restrict__ sub3,
-                                                const int *__restrict__ rowkey, const int *__restrict__ rowrank,
-                                                const uint32_t *__restrict__ sigu1, const uint32_t *__restrict__ sigu2,
-                                                int *__restrict__ perm, int *__restrict__ ksorted,
-                                                int *__restrict__ keysorted, uint32_t *__restrict__ sig1,
+__global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap,
+                                                const int *__restrict__ start3, const int *__restrict__ rowkey,
+                                                const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
+                                                const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
+                                                int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
                                                 uint32_t *__restrict__ sig2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int key = rowkey[i];
-    const int p = start[key / gb] + sub3[key] + rowrank[i];
+    const int p = start3[rowkey[i]] + rowrank[i];
     const int k = indptr[i + 1] - indptr[i];
     perm[p] = i;
     ksorted[p] = k < 0 ? 0 : (k > kcap ? kcap : k);
-    keysorted[p] = key;
 #pragma unroll
     for (int w = 0; w < W1; w++) sig1[(size_t)p * W1 + w] = sigu1[(size_t)i * W1 + w];
 #pragma unroll
@@ -740,7 +628,6 @@ struct PairArgs {
     int cand_cap_shard;
     int d;
     int n;
-    unsigned long long *dbg_t;  // BFK_PF_DEBUG & 4: per-wave stamps {start, loop start, loop end, end, items}
     int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
     Counters *ctr;
 };
@@ -806,14 +693,6 @@ __device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, 
     }
 }
 
-// LDS queue full (very dense input): append the raw first-level hit to the global queue unfiltered;
-// k_verify's exact merge decides.
-__device__ __forceinline__ void push_raw(const PairArgs &a, int shard, int p, int q) {
-    if (!(q > p && q < a.n && p < a.n)) return;
-    const int idx = (int)atomicAdd(&a.ctr->ncand[shard], 1u);
-    push_cand(a, shard, idx, a.perm[p], a.perm[q]);
-}
-
 template <int W>
 __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32_t *b) {
     uint32_t c = 0;
@@ -822,199 +701,239 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
     return c;
 }
 
-// unit range of a (virtual) block: the U units are cut into nvb equal slices
-__device__ __forceinline__ unsigned unit_cut(unsigned U, unsigned vb, unsigned nvb) {
-    return (unsigned)(((unsigned long long)vb * U) / nvb);
-}
+struct BandArgs {
+    unsigned long long *dbg_t;  // BFK_PF_DEBUG & 4: per-wave stamps
+    const int *start3;
+    const int4 *tiles;
+    int *tile_slots;  // per tile: pair slots evaluated (statistics, summed by the host)
+    KeyCfg key;
+    int kcap, d;
+};
 
+// ------------------------------------------------------------------------------------------------
+// k_prefilter<W, R>: the all-pairs kernel.  One WAVE per tile.  A tile is up to 64*R sorted rows of ONE
+// (k,f,g) cell, R per lane, signatures in VGPRs.  The columns that can be within d of those rows are, per
+// column length k' = k + delta and per column f' bucket, one contiguous range of the sorted order (the g
+// band): the wave walks the (delta, f') candidates, turns each into a column range with two start3
+// look-ups, and compares its rows with the range in sub-batches of 16 signature dwords:
+//   columns: coalesced 256-byte chunk loads, parked in the wave's LDS slice, re-read as wave-uniform
+//            ds_read_b128 broadcasts (v_xor with VGPR operands runs at full rate; an SGPR operand halves it);
+//   per pair slot: W x (v_xor + v_bcnt) and half a v_min3, minima kept per group of 4 columns;
+//   one v_cmp + ballot per sub-batch; only hit groups are revisited; hits go to the wave's LDS queue (slots
+//   from a ballot prefix, fill level in a wave-uniform register), filtered and flushed by flush_hits.
+// Waves are independent (no block barrier); the hardware's block scheduler balances the tiles.
+// ------------------------------------------------------------------------------------------------
 template <int W, int R>
-__global__ __launch_bounds__(256, 5) void k_prefilter(const uint32_t *__restrict__ sig1, const int4 *__restrict__ items,
-                                                    const int *__restrict__ blk_item, int n, int vb0, int nvb,
-                                                    int u_begin, int u_end, PairArgs pa) {
-    constexpr int CC = 64 / W;          // columns per unit: one 256-byte chunk of signatures (64 dwords)
+__global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
+                                                              int shard0, int nshards, int t_begin, int t_end,
+                                                              PairArgs pa) {
+    constexpr int CC = 64 / W;          // columns per 256-byte chunk of signatures (64 dwords)
     constexpr int SB = 16 / W;          // columns per sub-batch (16 dwords): the hit-detection granularity
     constexpr int NG = 4, GC = SB / NG; // minima per group of GC columns
-    __shared__ int2 sbuf[4][PF_LDS_QUEUE];
-    __shared__ __attribute__((aligned(16))) uint32_t scol[4][64];
+    constexpr int QCAP = PF_LDS_QUEUE * R;  // per-wave hit queue entries (room for one group's worst case)
+    __shared__ int2 sbuf[PF_WAVES][QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t scol[PF_WAVES][64];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave index is wave-uniform, so that everything derived from it
-    // (unit slice, item descriptors) stays in SGPRs / scalar loads
+    // (tile descriptor, candidate ranges) stays in SGPRs / scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t d = (uint32_t)pa.d;
-    const int qshard = (blockIdx.x * 4 + wave) & (CAND_SHARDS - 1);
-    // Every WAVE is its own worker: a wave-tile is 64*R consecutive (k,f)-sorted rows (R per lane), a unit
-    // is one chunk of CC columns against a wave-tile, and each wave takes an equal slice of the unit space.
-    unsigned u0, u1;
-    int w;
-    const unsigned long long t_start = pa.dbg_t ? wall_clock64() : 0ull;
-    if (blk_item) {  // normal run: slices of the whole unit space, first item precomputed by k_tiles
-        const unsigned U = pa.ctr->n_units;
-        const unsigned vb = (unsigned)(vb0 + blockIdx.x) * 4u + (unsigned)wave;
-        u0 = unit_cut(U, vb, (unsigned)nvb);
-        u1 = unit_cut(U, vb + 1u, (unsigned)nvb);
-        if (u0 >= u1) return;
-        w = blk_item[vb];
-    } else {  // recovery run over [u_begin, u_end): locate the item by binary search
-        const unsigned len = (unsigned)(u_end - u_begin);
-        const unsigned vb = blockIdx.x * 4u + (unsigned)wave;
-        u0 = (unsigned)u_begin + unit_cut(len, vb, gridDim.x * 4u);
-        u1 = (unsigned)u_begin + unit_cut(len, vb + 1u, gridDim.x * 4u);
-        if (u0 >= u1) return;
-        int lo = 0, hi = (int)pa.ctr->n_work - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((unsigned)items[mid].w <= u0) lo = mid;
-            else hi = mid - 1;
-        }
-        w = lo;
-    }
+    const int n_tiles = min((int)pa.ctr->n_work, t_end);
+    // one BLOCK per tile; its waves take the chunks of the tile's column ranges round-robin (a hub row — a
+    // profile with thousands of neighbours — would otherwise serialise on one wave)
+    const int t = t_begin + (int)blockIdx.x * nshards + shard0;
+    if (t >= n_tiles) return;
+    const unsigned long long t_start = ba.dbg_t ? wall_clock64() : 0ull;
+    unsigned long long t_rng = 0, t_main = 0;
+    int dbg_hits = 0, dbg_chunks = 0;
+    const int qshard = (blockIdx.x * PF_WAVES + wave) & (CAND_SHARDS - 1);
     int2 *myq = sbuf[wave];
     uint32_t *mycol = scol[wave];
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
-    unsigned long long evaluated = 0;
+    const int4 tile = ba.tiles[t];
+    const int row0 = tile.x, nrows = tile.y;
+    const int fb = ba.key.fb, gb = ba.key.gb;
+    const int k0 = tile.z / (fb * gb), f0 = (tile.z / gb) % fb, g0 = tile.z % gb;
     uint32_t rs[R][W];
-    int cur_row0 = -1;
-    const int n_items = (int)pa.ctr->n_work;
-    int4 it = items[w];
-    const unsigned long long t_loop = pa.dbg_t ? wall_clock64() : 0ull;
-    int dbg_items = 0;
-    while (true) {
-        dbg_items++;
-        const int4 nxt_it = items[min(w + 1, n_items - 1)];  // prefetch the next descriptor
-        const int row0 = it.x, ctrue = it.y, cend = it.z;
-        const int cal = ctrue & ~(CC - 1);
-        const int nb = (cend - cal + CC - 1) / CC;
-        // an item spans ITEM_OVH_UNITS + nb units: the fixed part prices the item switch for load balance
-        const unsigned ub = (unsigned)it.w + ITEM_OVH_UNITS;
-        const int first = u0 > ub ? (int)(u0 - ub) : 0;
-        const int last = u1 > ub ? (int)min((unsigned)nb, u1 - ub) : 0;
-        if (row0 != cur_row0) {
-            cur_row0 = row0;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int p = row0 + r * 64 + lane;
-                const int pc = p < n ? p : n - 1;
+    for (int r = 0; r < R; r++) {
+        const int p = min(row0 + r * 64 + lane, n - 1);
 #pragma unroll
-                for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)pc * W + x];
+        for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)p * W + x];
+    }
+    // Candidate column ranges, one per lane (all look-ups in flight together): candidate c = (delta, f' slot);
+    // with (d+1)^2 > 64 candidates the f' split is dropped (one range per column length, all g).
+    const int D = (int)d, D1 = D + 1;
+    const bool split_f = D1 * D1 <= 64;
+    const int ncand = split_f ? D1 * D1 : D1;
+    int my_cb = 0, my_ce = 0;
+    for (int cbase = 0; cbase < ncand; cbase += 64) {  // more than 64 candidates only when d >= 64
+        const int c = cbase + lane;
+        int cb = 0, ce = 0;
+        if (c < ncand) {
+            const int delta = split_f ? c / D1 : c;
+            const int kp = k0 + delta;
+            if (kp <= ba.kcap) {
+                const int amax = (D - delta) >> 1, bmax = amax + delta;
+                int fa, fz, ga, gz;
+                key_band(f0, f0, k0, kp, amax, bmax, fb, &fa, &fz);
+                key_band(g0, g0, k0, kp, amax, bmax, gb, &ga, &gz);
+                if (split_f) {
+                    const int fp = fa + c % D1;
+                    if (fp <= fz) {
+                        cb = ba.start3[(kp * fb + fp) * gb + ga];
+                        ce = ba.start3[(kp * fb + fp) * gb + gz + 1];
+                    }
+                } else {
+                    cb = ba.start3[(kp * fb + fa) * gb];
+                    ce = ba.start3[(kp * fb + fz + 1) * gb];
+                }
+                cb = max(cb, row0);  // q > p >= row0
             }
         }
-        const int qbeg = cal + first * CC, qend = cal + max(last, first) * CC;
-        // Column signatures: one coalesced 256-byte load per chunk (the next chunk is in flight while this
-        // one is compared), parked in the wave's LDS slice and re-read as wave-uniform ds_read_b128
-        // broadcasts, so the v_xor operands are VGPRs (full rate; an SGPR operand halves it on gfx950).
-        uint32_t v = sig1[(size_t)qbeg * W + lane];
-        for (int q0 = qbeg; q0 < qend; q0 += CC) {
-            const uint32_t vn = sig1[(size_t)(q0 + CC) * W + lane];  // array is padded past n
-            mycol[lane] = v;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int sb = 0; sb < CC / SB; sb++) {
-                uint32_t cs[16];
-#pragma unroll
-                for (int x4 = 0; x4 < 4; x4++) {
-                    const uint4 t = *reinterpret_cast<const uint4 *>(&mycol[sb * 16 + x4 * 4]);
-                    cs[x4 * 4 + 0] = t.x;
-                    cs[x4 * 4 + 1] = t.y;
-                    cs[x4 * 4 + 2] = t.z;
-                    cs[x4 * 4 + 3] = t.w;
+        if (cbase == 0) {
+            my_cb = cb;
+            my_ce = ce;
+        } else {  // d >= 64: process this round immediately (ranges of later rounds overwrite)
+            my_cb = cb;
+            my_ce = ce;
+        }
+        if (ba.dbg_t) t_rng = wall_clock64() + (unsigned long long)(my_cb & 0);  // after the range look-ups landed
+        long long slots = 0;
+        const int nc = min(64, ncand - cbase);
+        // Chunk iterator over all ranges of this round: this wave takes the chunks whose running number is
+        // == wave (mod PF_WAVES).  Everything here is wave-uniform (SGPRs).
+        int it_ci = -1, it_q0 = 0, it_ctrue = 0, it_cend = 0, chunk_no = 0;
+        auto advance = [&]() {
+            it_q0 += PF_WAVES * CC;
+            while (it_ci < nc && it_q0 >= it_cend) {
+                it_ci++;
+                if (it_ci >= nc) break;
+                it_ctrue = __builtin_amdgcn_readlane(my_cb, it_ci);
+                it_cend = __builtin_amdgcn_readlane(my_ce, it_ci);
+                if (it_cend <= it_ctrue) {
+                    it_cend = it_q0 = 0;  // empty range: keep looking
+                    continue;
                 }
-                uint32_t mg[NG];
-#pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    mg[g] = 0xFFFFu;
-#pragma unroll
-                    for (int j = g * GC; j < (g + 1) * GC; j++) {
-#pragma unroll
-                        for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
-                    }
-                }
-                const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
-                if (!(pa.dbg & 2) && __builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
-                    // revisit only the column groups that hit; build a per-lane bit mask of the (column,row)
-                    // hits (bit = j*R + r inside the sub-batch), then drain it in ONE place (small code).
-                    // (Doing this on the scalar unit via v_readlane was tried: one SALU per CU makes it 5x slower.)
-                    unsigned long long hm = 0ull;
-#pragma unroll
-                    for (int g = 0; g < NG; g++) {
-                        if (__builtin_amdgcn_ballot_w64(mg[g] <= d) != 0ull) {
-                            uint32_t bits = 0;
-#pragma unroll
-                            for (int j = (g + 1) * GC - 1; j >= g * GC; j--) {
-#pragma unroll
-                                for (int r = R - 1; r >= 0; r--)
-                                    bits = (bits << 1) | (sigdist<W>(rs[r], &cs[j * W]) <= d ? 1u : 0u);
-                            }
-                            hm |= (unsigned long long)bits << (g * GC * R);
-                        }
-                    }
-                    // the queue is private to the wave: slots come from a ballot prefix, the fill level is a
-                    // wave-uniform register (no LDS atomic)
-                    while (true) {
-                        int b = -1;
-                        if (hm) {
-                            b = __ffsll((long long)hm) - 1;
-                            hm &= hm - 1;
-                            const int q = q0 + sb * SB + b / R;
-                            if (q < ctrue || q >= cend) b = -1;  // alignment padding belongs to another item
-                        }
-                        const unsigned long long act = __builtin_amdgcn_ballot_w64(b >= 0);
-                        if (act == 0ull && __builtin_amdgcn_ballot_w64(hm != 0ull) == 0ull) break;
-                        const int na = __popcll(act);
-                        if (qn + na > PF_LDS_QUEUE) {  // would overflow inside one chunk (very dense input): drain now
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            flush_hits(pa, myq, qn, qshard);
-                            __builtin_amdgcn_wave_barrier();
-                            qn = 0;
-                        }
-                        if (b >= 0)
-                            myq[qn + __popcll(act & ((1ull << lane) - 1ull))] =
-                                make_int2(row0 + (b % R) * 64 + lane, q0 + sb * SB + b / R);
-                        qn += na;
-                    }
-                }
+                const int cal = it_ctrue & ~(CC - 1);
+                const int nch = (it_cend - cal + CC - 1) / CC;
+                it_q0 = cal + ((wave - chunk_no) & (PF_WAVES - 1)) * CC;
+                chunk_no += nch;
             }
-            v = vn;
-            // the hit queue is per wave, so it can be drained without a block barrier: keep it below half
-            if (qn > PF_LDS_QUEUE / 2) {
+        };
+        advance();
+        // Column signatures: one coalesced 256-byte load per chunk, FOUR chunks in flight (a chunk's compare is
+        // ~0.5 us, a load from L2 1-2 us: with one chunk in flight the wave is latency-bound).
+        int q0a = 0, cta = 0, cea = 0, q0b = 0, ctb = 0, ceb = 0, q0c = 0, ctc = 0, cec = 0, q0d = 0, ctd = 0, ced = 0;
+        bool va = false, vb = false, vc = false, vd = false;
+        uint32_t xa = 0, xb = 0, xc = 0, xd = 0;
+#define PF_FETCH(q0x, ctx, cex, valid, xx)                         \
+    valid = it_ci < nc;                                            \
+    if (valid) {                                                   \
+        q0x = it_q0;                                               \
+        ctx = it_ctrue;                                            \
+        cex = it_cend;                                             \
+        xx = sig1[(size_t)min(it_q0, n) * W + lane];               \
+        advance();                                                 \
+    }
+        PF_FETCH(q0a, cta, cea, va, xa)
+        PF_FETCH(q0b, ctb, ceb, vb, xb)
+        PF_FETCH(q0c, ctc, cec, vc, xc)
+        PF_FETCH(q0d, ctd, ced, vd, xd)
+        while (va) {
+            const int q0 = q0a, ctrue = cta, cend = cea;
+            {
+                mycol[lane] = xa;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                flush_hits(pa, myq, qn, qshard);
-                __builtin_amdgcn_wave_barrier();
-                qn = 0;
+                dbg_chunks++;
+                const int sb_lo = max(0, (ctrue - q0) / SB), sb_hi = min(CC / SB, (cend - q0 + SB - 1) / SB);
+                slots += (long long)(sb_hi - sb_lo) * SB * nrows;
+#pragma unroll 1
+                for (int sb = sb_lo; sb < sb_hi; sb++) {
+                    uint32_t cs[16];
+#pragma unroll
+                    for (int x4 = 0; x4 < 4; x4++) {
+                        const uint4 tt = *reinterpret_cast<const uint4 *>(&mycol[sb * 16 + x4 * 4]);
+                        cs[x4 * 4 + 0] = tt.x;
+                        cs[x4 * 4 + 1] = tt.y;
+                        cs[x4 * 4 + 2] = tt.z;
+                        cs[x4 * 4 + 3] = tt.w;
+                    }
+                    uint32_t mg[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        mg[g] = 0xFFFFu;
+#pragma unroll
+                        for (int j = g * GC; j < (g + 1) * GC; j++) {
+#pragma unroll
+                            for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
+                        }
+                    }
+                    const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
+                    if (!(pa.dbg & 2) && __builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
+                        // Hit path: only the column groups that hit are revisited, one compare per (column,row)
+                        // and a wave-level branch around the push.  The queue is private to the wave: slots come
+                        // from the ballot (v_mbcnt), the fill level is a wave-uniform register — no LDS atomic,
+                        // no per-lane bit masks, no drain loop.
+#pragma unroll
+                        for (int g = 0; g < NG; g++) {
+                            if (__builtin_amdgcn_ballot_w64(mg[g] <= d) == 0ull) continue;
+                            if (qn > QCAP - 64 * GC * R) {  // make room for the worst case of one group
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                flush_hits(pa, myq, qn, qshard);
+                                __builtin_amdgcn_wave_barrier();
+                                qn = 0;
+                            }
+#pragma unroll
+                            for (int j = g * GC; j < (g + 1) * GC; j++) {
+                                const int q = q0 + sb * SB + j;
+                                if (q < ctrue || q >= cend) continue;  // alignment padding (wave-uniform test)
+#pragma unroll
+                                for (int r = 0; r < R; r++) {
+                                    const bool h = sigdist<W>(rs[r], &cs[j * W]) <= d && r * 64 + lane < nrows;
+                                    const unsigned long long act = __builtin_amdgcn_ballot_w64(h);
+                                    if (act == 0ull) continue;
+                                    if (h) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = make_int2(row0 + r * 64 + lane, q);
+                                    qn += __popcll(act);
+                                    dbg_hits += __popcll(act);
+                                }
+                            }
+                        }
+                    }
+                }
             }
+            // rotate the pipeline and fetch one more chunk
+            q0a = q0b; cta = ctb; cea = ceb; va = vb; xa = xb;
+            q0b = q0c; ctb = ctc; ceb = cec; vb = vc; xb = xc;
+            q0c = q0d; ctc = ctd; cec = ced; vc = vd; xc = xd;
+            PF_FETCH(q0d, ctd, ced, vd, xd)
         }
-        evaluated += (unsigned long long)max(last - first, 0);
-        u0 = ub + (unsigned)nb;  // end of this item in unit space
-        if (u0 >= u1 || w + 1 >= n_items) break;
-        w++;
-        it = nxt_it;
+#undef PF_FETCH
+        if (lane == 0) {  // plain store (no statistics atomics); later rounds (d >= 64) accumulate
+            int *ts = &ba.tile_slots[t * PF_WAVES + wave];
+            *ts = (int)min((long long)(cbase ? *ts : 0) + slots, (long long)0x7fffffff);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned long long t_main = pa.dbg_t ? wall_clock64() : 0ull;
-    const int cnt = qn;
-    if (cnt > 0 && !(pa.dbg & 1)) flush_hits(pa, myq, cnt, qshard);  // one flush per wave
-    if (pa.dbg_t && lane == 0) {
-        unsigned long long *o = pa.dbg_t + (size_t)(blockIdx.x * 4 + wave) * 8;
+    if (ba.dbg_t) t_main = wall_clock64();
+    if (qn > 0 && !(pa.dbg & 1)) flush_hits(pa, myq, qn, qshard);  // one flush per wave
+    if (ba.dbg_t && lane == 0) {
+        unsigned long long *o = ba.dbg_t + (size_t)(t * PF_WAVES + wave) * 8;
         o[0] = t_start;
-        o[1] = t_loop;
+        o[1] = t_rng;
         o[2] = t_main;
         o[3] = wall_clock64();
-        o[4] = (unsigned long long)dbg_items;
-        o[5] = (unsigned long long)cnt;
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        o[6] = xcc;
-        o[7] = evaluated;
+        o[4] = (unsigned long long)dbg_chunks;
+        o[5] = (unsigned long long)dbg_hits;
+        o[6] = (unsigned long long)nrows;
+        o[7] = (unsigned long long)tile.z;
     }
-    // (no per-wave statistics atomics here: 5120 adds to one word serialise to ~50 us; k_tiles counts the units)
-    (void)evaluated;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1239,7 +1158,6 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.sig2 = pl.sig2;
     pa.n = pl.n;
     pa.dbg = pl.dbg;
-    pa.dbg_t = pl.dbg_t;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
     pa.candk = pl.candk;
@@ -1249,27 +1167,38 @@ static PairArgs make_pair_args(const Plan &pl) {
     return pa;
 }
 
-// prefilter + verify + union.  Normal run (u_end < 0): every (virtual) block takes its precomputed slice of
-// the unit space.  Recovery run: the unit range [u_begin, u_end) only.
-int launch_pairs(const Plan &pl, int u_begin, int u_end, hipStream_t st, hipEvent_t *ev) {
+// prefilter + verify + union over tiles [t_begin, t_end) (whole list for a normal run; slices in recovery)
+int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev) {
     const int n = pl.n;
     PairArgs pa = make_pair_args(pl);
-    const int *blk = u_end < 0 ? pl.blk_item : nullptr;
-    const int vb0 = pl.shard * pl.pf_grid, nvb = pl.n_shards * pl.pf_grid * 4;  // workers are waves
-    switch (pl.w1) {
-        case 1:
-            hipLaunchKernelGGL((k_prefilter<1, PF_ROWS_W1>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
-                               vb0, nvb, u_begin, u_end, pa);
-            break;
-        case 2:
-            hipLaunchKernelGGL((k_prefilter<2, PF_ROWS_W2>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
-                               vb0, nvb, u_begin, u_end, pa);
-            break;
-        default:
-            hipLaunchKernelGGL((k_prefilter<4, PF_ROWS_W4>), dim3(pl.pf_grid), dim3(256), 0, st, pl.sig1, pl.items, blk, n,
-                               vb0, nvb, u_begin, u_end, pa);
-            break;
+    BandArgs ba;
+    ba.start3 = pl.start3;
+    ba.tiles = pl.tiles;
+    ba.tile_slots = pl.tile_slots;
+    ba.dbg_t = pl.dbg_t;
+    ba.key.fb = pl.fb;
+    ba.key.gb = pl.gb;
+    ba.kcap = pl.kcap;
+    ba.d = pl.d;
+    // one wave per tile of this shard; the tile count lives on the device, so the grid covers the host-side
+    // bound and surplus waves exit at once
+    const long long span = (long long)std::min(t_end, pl.tile_cap) - t_begin;
+    const int grid = std::max(1, (int)((span + pl.n_shards - 1) / pl.n_shards));  // one block per tile
+#define PF_CASE(W, R)                                                                                              \
+    hipLaunchKernelGGL((k_prefilter<W, R>), dim3(grid), dim3(PF_WAVES * 64), 0, st, pl.sig1, ba, n, pl.shard, pl.n_shards, \
+                       t_begin, t_end, pa)
+    switch (pl.w1 * 10 + pl.rows_per_lane) {
+        case 11: PF_CASE(1, 1); break;
+        case 12: PF_CASE(1, 2); break;
+        case 14: PF_CASE(1, 4); break;
+        case 21: PF_CASE(2, 1); break;
+        case 22: PF_CASE(2, 2); break;
+        case 24: PF_CASE(2, 4); break;
+        case 41: PF_CASE(4, 1); break;
+        case 42: PF_CASE(4, 2); break;
+        default: PF_CASE(4, 4); break;
     }
+#undef PF_CASE
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa);
@@ -1296,22 +1225,16 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     rk.key.gb = pl.gb;
     const int canon_blocks = min((n + 3) / 4, 256 * 16);
     const int lds_cap = pl.long_lds_cap;
-    PlanArgs pa;
-    pa.hist3 = pl.hist3;
-    pa.sub3 = pl.sub3;
-    pa.start = pl.start;
-    pa.keysorted = pl.keysorted;
-    pa.items = pl.items;
-    pa.blk_item = pl.blk_item;
-    pa.ctr = pl.ctr;
-    pa.key = rk.key;
-    pa.n = n;
-    pa.kcap = pl.kcap;
-    pa.d = pl.d;
-    pa.tr = pl.tr;
-    pa.cb = pl.cb;
-    pa.nvblocks = pl.n_shards * pl.pf_grid * 4;
-    pa.item_cap = pl.item_cap;
+    CellArgs ca;
+    ca.hist3 = pl.hist3;
+    ca.start3 = pl.start3;
+    ca.tiles = pl.tiles;
+    ca.chain = pl.chain;
+    ca.ctr = pl.ctr;
+    ca.n = n;
+    ca.cells = (pl.kcap + 1) * pl.fb * pl.gb;
+    ca.tr = 64 * pl.rows_per_lane;
+    ca.tile_cap = pl.tile_cap;
     switch (pl.w1) {
 #define PREP_CASE(W)                                                                                                      \
     case W:                                                                                                               \
@@ -1320,12 +1243,10 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         if (pl.kcap > 256)                                                                                                \
             hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,         \
                                pl.indices, pl.kcap, rk, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr, lds_cap);        \
-        hipLaunchKernelGGL(k_rowrank, dim3((n + 255) / 256), dim3(256), 0, st, pl.rowkey, n, pl.hist3, pl.rowrank);        \
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, pa);                                                       \
-        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.gb, pl.start,    \
-                           pl.sub3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.keysorted, pl.sig1, \
-                           pl.sig2);                                                                                      \
-        hipLaunchKernelGGL(k_tiles, dim3(1), dim3(1024), 0, st, pa);                                                      \
+        hipLaunchKernelGGL(k_rowrank, dim3((n + 1023) / 1024), dim3(1024), 0, st, pl.rowkey, n, pl.hist3, pl.rowrank);     \
+        hipLaunchKernelGGL(k_cells, dim3((ca.cells + 8191) / 8192), dim3(1024), 0, st, ca);                               \
+        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.start3,          \
+                           pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2);              \
         break;
         PREP_CASE(1)
         PREP_CASE(2)
@@ -1336,7 +1257,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     }
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    if (int e = launch_pairs(pl, 0, -1, st, ev)) return e;
+    if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
     return launch_flatten(pl, st, ev);
 }
 
