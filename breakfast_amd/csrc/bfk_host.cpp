@@ -576,6 +576,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         int64_t retry_slices = 0;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
+            // the queue was too small for this input: double it so that the next run fits in one pass
+            if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
         }
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;

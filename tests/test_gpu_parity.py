@@ -140,7 +140,8 @@ def _random_multisets(n, seed, alphabet, kmax, p_empty=0.05):
 @pytest.mark.parametrize("n,alphabet,kmax,d,seed", [
     (1, 5, 3, 1, 0), (2, 5, 3, 1, 1), (7, 4, 3, 2, 2), (500, 40, 10, 1, 3), (500, 40, 10, 3, 4),
     (1500, 200, 40, 2, 5), (1500, 30, 6, 1, 6), (800, 1000, 300, 5, 7), (600, 3000, 700, 7, 8),
-    (400, 8, 90, 4, 9), (1200, 100, 70, 12, 10),
+    (400, 8, 90, 4, 9), (1200, 100, 70, 12, 10), (300, 60, 90, 70, 11), (900, 12, 5, 2, 12),
+    (2000, 4000, 30, 1, 13),
 ])
 def test_random_multisets_vs_oracle(n, alphabet, kmax, d, seed):
     indptr, indices = _random_multisets(n, seed, alphabet, kmax)
@@ -150,6 +151,30 @@ def test_random_multisets_vs_oracle(n, alphabet, kmax, d, seed):
     got, st = _lib.cluster_csr(indptr, indices, d)
     assert np.array_equal(got, want)
     assert st["sig_words"] == (1 if d <= 2 else 2 if d <= 5 else 4)
+
+
+def test_hub_and_spokes_dense_cells():
+    """a root profile with thousands of direct children (all in four (k,f,g) cells) plus grandchildren: the hub
+    row has thousands of neighbours, the children's cells are dense — exercises the hit queue drain and the
+    tile splitting across waves"""
+    rng = np.random.default_rng(3)
+    root = rng.choice(50000, size=30, replace=False)
+    rows = [root]
+    for _ in range(6000):
+        rows.append(np.append(root, rng.integers(50000, 90000)))
+    for i in range(1, 1500):
+        rows.append(np.append(rows[i], rng.integers(90000, 120000)))
+    order = rng.permutation(len(rows))
+    rows = [rng.permutation(rows[i]).astype(np.int32) for i in order]
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows)
+    for d in (1, 2):
+        want = orc.cluster_csr(indptr, indices, d, n_threads=16)["labels"]
+        got, st = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want)
+    ptr, idx = _lib.neighbours_csr(indptr, indices, 1, np.array([int(np.flatnonzero(order == 0)[0])], np.int64))
+    assert ptr[1] - ptr[0] == 6001  # the root sees itself and its 6000 children
 
 
 def test_all_identical_rows_clique():
