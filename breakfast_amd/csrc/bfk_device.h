@@ -8,9 +8,10 @@ namespace bfk {
 constexpr int KEY_BUCKETS = 16;        // f / g buckets per row length in the (k,f,g) sort key (window around k/2)
 constexpr int KEY_MAX_BINS3 = 1 << 24; // cap on (kmax+1)*fb*gb counters (64 MiB); buckets are halved beyond it
 constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
-constexpr int CAND_SHARDS = 64;        // candidate queue shards: returning atomics on one word serialise (~90/us)
+constexpr int CAND_SHARDS = 512;       // candidate queue shards: returning atomics on one word serialise (~90/us)
 constexpr int PF_WAVES = 2;            // waves per prefilter block = waves sharing one tile
-constexpr int PF_LDS_QUEUE = 512;      // per-wave LDS hit queue entries (4 KiB per wave), drained at half full
+constexpr int PF_LDS_QUEUE = 256;      // per-wave LDS coarse hit queue entries (2 KiB per wave)
+constexpr int PF_PAIR_LIST = 256;      // per-wave LDS list of exact pairs inside flush_hits (2 KiB per wave)
 constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane group in k_verify (512 B/group)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
 constexpr int LONG_LDS_CAP = 15360;    // tokens of a long row staged in LDS by k_canon_long (60 KiB)

@@ -342,9 +342,9 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         if (int rc = dev_realloc(&c->d_tile_slots, &c->tile_slots_cap, c->tile_cap * PF_WAVES, 1.0)) return rc;
     }
     {
-        // per shard: 4N pairs (8 shards -> 32N), and never less than one unit's pair slots
-        // total 32N pairs; every shard holds at least one unit's pair slots (64 lanes x R rows x 64 columns)
-        int64_t want = std::max<int64_t>((int64_t)64 * 4 * 64, (32 * n) / CAND_SHARDS + 1024);
+        // 16N candidate slots in all (d=1 needs ~0.7N, a dense d=5 graph ~15N); an overflow is repaired by
+        // bfk_ctx_sync (sliced re-run) and doubles the queue for the following runs
+        int64_t want = std::max<int64_t>(1024, (16 * n) / CAND_SHARDS + 256);
         if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;

@@ -648,7 +648,7 @@ __device__ __forceinline__ void push_cand(const PairArgs &a, int shard, int idx,
 // flush `cnt` queued (p,q) hits: filter, translate to row ids, append to the shard's global queue with
 // one global atomic per wave; a full global queue raises the overflow flag (host re-runs in slices).
 // Every load that depends only on (p,q) is issued up front, so a flush costs ~3 dependent round trips.
-__device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, int cnt, int shard) {
+__device__ __forceinline__ void flush_pairs(const PairArgs &a, const int2 *sbuf, int cnt, int shard) {
     const int lane = threadIdx.x & 63;
     for (int i0 = 0; i0 < cnt; i0 += 64) {  // called by ONE wave on its own queue
         const int i = i0 + lane;
@@ -670,6 +670,7 @@ __device__ __forceinline__ void flush_hits(const PairArgs &a, const int2 *sbuf, 
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask == 0ull) continue;
+        shard = (shard + 1) & (CAND_SHARDS - 1);  // a hub row's thousands of candidates spread over the shards
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(&a.ctr->ncand[shard], (unsigned)__popcll(mask));
         int ba = 0, ea = 0, bb = 0, eb = 0;
@@ -701,6 +702,68 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
     return c;
 }
 
+// inclusive prefix sum over the 64 lanes (DPP row prefix, then row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);  // row_bcast15 into rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);  // row_bcast31 into rows 2,3
+    return x;
+}
+
+// Flush of the prefilter's COARSE hit queue.  An entry says "column q is within d (first-level signature) of
+// at least one of the SB rows starting at sorted row pb".  Finding which rows is done here, one entry per
+// lane (64 entries per instruction), instead of in the scan loop where a hit costs the whole wave a serial
+// rescan: the 16 row dwords and the column signature are re-read from L2, the exact (row, column) pairs are
+// compacted into `pairs` (LDS, PF_PAIR_LIST entries per round) with a wave prefix sum, and flush_pairs does the rest.
+template <int W>
+__device__ __forceinline__ void flush_hits(const PairArgs &a, const uint32_t *__restrict__ sig1, const int2 *coarse, int cnt,
+                                           int row_end, int2 *pairs, int shard) {
+    constexpr int SB = 16 / W;
+    const int lane = threadIdx.x & 63;
+    const uint32_t d = (uint32_t)a.d;
+    for (int i0 = 0; i0 < cnt; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t mask = 0;
+        int pb = 0, q = 0;
+        if (i < cnt) {
+            const int2 e = coarse[i];
+            pb = e.x;
+            q = e.y;
+            uint32_t cq[W];
+#pragma unroll
+            for (int x = 0; x < W; x++) cq[x] = sig1[(size_t)q * W + x];
+            uint32_t rw[16];
+#pragma unroll
+            for (int x = 0; x < 16; x++) rw[x] = sig1[(size_t)pb * W + x];  // padded array: in bounds past n
+#pragma unroll
+            for (int j = 0; j < SB; j++)
+                if (pb + j < row_end && sigdist<W>(cq, &rw[j * W]) <= d) mask |= 1u << j;
+        }
+        const int mine = __popc(mask);
+        const int incl = wave_incl_scan_add(mine);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int first = incl - mine;
+        for (int base = 0; base < total; base += PF_PAIR_LIST) {  // usually one round: ~1 pair per entry
+            int o = first;
+            uint32_t mm = mask;
+            while (mm) {
+                const int j = __ffs((int)mm) - 1;
+                mm &= mm - 1;
+                if (o >= base && o < base + PF_PAIR_LIST) pairs[o - base] = make_int2(pb + j, q);
+                o++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            flush_pairs(a, pairs, min(PF_PAIR_LIST, total - base), shard);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 struct BandArgs {
     unsigned long long *dbg_t;  // BFK_PF_DEBUG & 4: per-wave stamps
     const int *start3;
@@ -711,36 +774,39 @@ struct BandArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_prefilter<W, R>: the all-pairs kernel.  One WAVE per tile.  A tile is up to 64*R sorted rows of ONE
-// (k,f,g) cell, R per lane, signatures in VGPRs.  The columns that can be within d of those rows are, per
-// column length k' = k + delta and per column f' bucket, one contiguous range of the sorted order (the g
-// band): the wave walks the (delta, f') candidates, turns each into a column range with two start3
-// look-ups, and compares its rows with the range in sub-batches of 16 signature dwords:
-//   columns: coalesced 256-byte chunk loads, parked in the wave's LDS slice, re-read as wave-uniform
-//            ds_read_b128 broadcasts (v_xor with VGPR operands runs at full rate; an SGPR operand halves it);
-//   per pair slot: W x (v_xor + v_bcnt) and half a v_min3, minima kept per group of 4 columns;
-//   one v_cmp + ballot per sub-batch; only hit groups are revisited; hits go to the wave's LDS queue (slots
-//   from a ballot prefix, fill level in a wave-uniform register), filtered and flushed by flush_hits.
-// Waves are independent (no block barrier); the hardware's block scheduler balances the tiles.
+// k_prefilter<W, R>: the all-pairs kernel.  One BLOCK (PF_WAVES waves) per tile.  A tile is up to 64*R sorted
+// rows of ONE (k,f,g) cell.  The columns that can be within d of those rows are, per column length
+// k' = k + delta and per column f' bucket, one contiguous range of the sorted order (the g band): every
+// lane turns one (delta, f') candidate into a column range with two start3 look-ups (all in flight at once).
+// Orientation: the COLUMNS sit in the lanes (one signature per lane, 64 consecutive columns per chunk, four
+// chunks in flight per wave) and the tile's ROWS are broadcast — cells are small (~25 rows at 100k rows), a
+// column range is several cells wide, so this keeps the lanes full where rows-in-lanes would leave 60% idle.
+// The tile's row signatures are parked once in the wave's LDS slice and re-read as wave-uniform
+// ds_read_b128 broadcasts (v_xor with VGPR operands runs at full rate; an SGPR operand halves it on gfx950).
+//   per pair slot: W x (v_xor + v_bcnt) and half a v_min3, minima kept per group of 4 rows;
+//   one v_cmp + ballot per sub-batch of 16 row-dwords; only hit groups are revisited, one compare per
+//   (row, column) with a wave-level branch around the push; hits go to the wave's LDS queue (slot from the
+//   ballot prefix, fill level in a wave-uniform register), filtered and flushed by flush_hits.
+// The waves of a block take the tile's chunks round-robin (a hub row with thousands of neighbours would
+// otherwise serialise on one wave); waves never synchronise; the hardware block scheduler balances tiles.
 // ------------------------------------------------------------------------------------------------
 template <int W, int R>
 __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
                                                               int shard0, int nshards, int t_begin, int t_end,
                                                               PairArgs pa) {
-    constexpr int CC = 64 / W;          // columns per 256-byte chunk of signatures (64 dwords)
-    constexpr int SB = 16 / W;          // columns per sub-batch (16 dwords): the hit-detection granularity
-    constexpr int NG = 4, GC = SB / NG; // minima per group of GC columns
-    constexpr int QCAP = PF_LDS_QUEUE * R;  // per-wave hit queue entries (room for one group's worst case)
+    constexpr int CC = 64;              // columns per chunk: one per lane
+    constexpr int SB = 16 / W;          // rows per sub-batch (16 dwords): the hit-detection granularity
+    constexpr int QCAP = PF_LDS_QUEUE;  // per-wave coarse hit queue entries
+    constexpr int TROWS = 64 * R;       // most rows a tile can have
     __shared__ int2 sbuf[PF_WAVES][QCAP];
-    __shared__ __attribute__((aligned(16))) uint32_t scol[PF_WAVES][64];
+    __shared__ int2 spairs[PF_WAVES][PF_PAIR_LIST];  // flush_hits: exact pairs of a batch of 64 coarse entries
+    __shared__ __attribute__((aligned(16))) uint32_t srow[PF_WAVES][TROWS * W];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave index is wave-uniform, so that everything derived from it
     // (tile descriptor, candidate ranges) stays in SGPRs / scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t d = (uint32_t)pa.d;
     const int n_tiles = min((int)pa.ctr->n_work, t_end);
-    // one BLOCK per tile; its waves take the chunks of the tile's column ranges round-robin (a hub row — a
-    // profile with thousands of neighbours — would otherwise serialise on one wave)
     const int t = t_begin + (int)blockIdx.x * nshards + shard0;
     if (t >= n_tiles) return;
     const unsigned long long t_start = ba.dbg_t ? wall_clock64() : 0ull;
@@ -748,28 +814,28 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
     int dbg_hits = 0, dbg_chunks = 0;
     const int qshard = (blockIdx.x * PF_WAVES + wave) & (CAND_SHARDS - 1);
     int2 *myq = sbuf[wave];
-    uint32_t *mycol = scol[wave];
+    uint32_t *myrow = srow[wave];
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
     const int4 tile = ba.tiles[t];
     const int row0 = tile.x, nrows = tile.y;
     const int fb = ba.key.fb, gb = ba.key.gb;
     const int k0 = tile.z / (fb * gb), f0 = (tile.z / gb) % fb, g0 = tile.z % gb;
-    uint32_t rs[R][W];
+    // the tile's row signatures -> LDS (rows past the tile are padding: they are compared but never pushed)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int p = min(row0 + r * 64 + lane, n - 1);
 #pragma unroll
-        for (int x = 0; x < W; x++) rs[r][x] = sig1[(size_t)p * W + x];
+        for (int x = 0; x < W; x++) myrow[(r * 64 + lane) * W + x] = sig1[(size_t)p * W + x];
     }
+    const int nsb = (nrows + SB - 1) / SB;
     // Candidate column ranges, one per lane (all look-ups in flight together): candidate c = (delta, f' slot);
     // with (d+1)^2 > 64 candidates the f' split is dropped (one range per column length, all g).
     const int D = (int)d, D1 = D + 1;
     const bool split_f = D1 * D1 <= 64;
     const int ncand = split_f ? D1 * D1 : D1;
-    int my_cb = 0, my_ce = 0;
     for (int cbase = 0; cbase < ncand; cbase += 64) {  // more than 64 candidates only when d >= 64
         const int c = cbase + lane;
-        int cb = 0, ce = 0;
+        int my_cb = 0, my_ce = 0;
         if (c < ncand) {
             const int delta = split_f ? c / D1 : c;
             const int kp = k0 + delta;
@@ -781,23 +847,19 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
                 if (split_f) {
                     const int fp = fa + c % D1;
                     if (fp <= fz) {
-                        cb = ba.start3[(kp * fb + fp) * gb + ga];
-                        ce = ba.start3[(kp * fb + fp) * gb + gz + 1];
+                        my_cb = ba.start3[(kp * fb + fp) * gb + ga];
+                        my_ce = ba.start3[(kp * fb + fp) * gb + gz + 1];
                     }
                 } else {
-                    cb = ba.start3[(kp * fb + fa) * gb];
-                    ce = ba.start3[(kp * fb + fz + 1) * gb];
+                    my_cb = ba.start3[(kp * fb + fa) * gb];
+                    my_ce = ba.start3[(kp * fb + fz + 1) * gb];
                 }
-                cb = max(cb, row0);  // q > p >= row0
+                my_cb = max(my_cb, row0);  // q > p >= row0
             }
         }
-        if (cbase == 0) {
-            my_cb = cb;
-            my_ce = ce;
-        } else {  // d >= 64: process this round immediately (ranges of later rounds overwrite)
-            my_cb = cb;
-            my_ce = ce;
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (ba.dbg_t) t_rng = wall_clock64() + (unsigned long long)(my_cb & 0);  // after the range look-ups landed
         long long slots = 0;
         const int nc = min(64, ncand - cbase);
@@ -822,94 +884,71 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
             }
         };
         advance();
-        // Column signatures: one coalesced 256-byte load per chunk, FOUR chunks in flight (a chunk's compare is
-        // ~0.5 us, a load from L2 1-2 us: with one chunk in flight the wave is latency-bound).
+        // Column signatures: one coalesced load per chunk (64 columns, one per lane), FOUR chunks in flight
+        // (a chunk's compare is ~0.3 us, a load from L2 1-2 us).
         int q0a = 0, cta = 0, cea = 0, q0b = 0, ctb = 0, ceb = 0, q0c = 0, ctc = 0, cec = 0, q0d = 0, ctd = 0, ced = 0;
         bool va = false, vb = false, vc = false, vd = false;
-        uint32_t xa = 0, xb = 0, xc = 0, xd = 0;
-#define PF_FETCH(q0x, ctx, cex, valid, xx)                         \
-    valid = it_ci < nc;                                            \
-    if (valid) {                                                   \
-        q0x = it_q0;                                               \
-        ctx = it_ctrue;                                            \
-        cex = it_cend;                                             \
-        xx = sig1[(size_t)min(it_q0, n) * W + lane];               \
-        advance();                                                 \
+        uint32_t xa[W], xb[W], xc[W], xd[W];
+#define PF_FETCH(q0x, ctx, cex, valid, xx)                                                \
+    valid = it_ci < nc;                                                                   \
+    if (valid) {                                                                          \
+        q0x = it_q0;                                                                      \
+        ctx = it_ctrue;                                                                   \
+        cex = it_cend;                                                                    \
+        _Pragma("unroll") for (int x = 0; x < W; x++) xx[x] = sig1[(size_t)min(it_q0 + lane, n) * W + x]; \
+        advance();                                                                        \
     }
         PF_FETCH(q0a, cta, cea, va, xa)
         PF_FETCH(q0b, ctb, ceb, vb, xb)
         PF_FETCH(q0c, ctc, cec, vc, xc)
         PF_FETCH(q0d, ctd, ced, vd, xd)
         while (va) {
-            const int q0 = q0a, ctrue = cta, cend = cea;
-            {
-                mycol[lane] = xa;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                dbg_chunks++;
-                const int sb_lo = max(0, (ctrue - q0) / SB), sb_hi = min(CC / SB, (cend - q0 + SB - 1) / SB);
-                slots += (long long)(sb_hi - sb_lo) * SB * nrows;
+            const int q = q0a + lane;                      // this lane's column
+            const bool colok = q >= cta && q < cea;         // inside the range (chunks are aligned down/up)
+            dbg_chunks++;
+            slots += (long long)nsb * SB * (min(cea, q0a + CC) - max(cta, q0a));
 #pragma unroll 1
-                for (int sb = sb_lo; sb < sb_hi; sb++) {
-                    uint32_t cs[16];
+            for (int sb = 0; sb < nsb; sb++) {
+                uint32_t rsig[16];
 #pragma unroll
-                    for (int x4 = 0; x4 < 4; x4++) {
-                        const uint4 tt = *reinterpret_cast<const uint4 *>(&mycol[sb * 16 + x4 * 4]);
-                        cs[x4 * 4 + 0] = tt.x;
-                        cs[x4 * 4 + 1] = tt.y;
-                        cs[x4 * 4 + 2] = tt.z;
-                        cs[x4 * 4 + 3] = tt.w;
+                for (int x4 = 0; x4 < 4; x4++) {
+                    const uint4 tt = *reinterpret_cast<const uint4 *>(&myrow[sb * 16 + x4 * 4]);
+                    rsig[x4 * 4 + 0] = tt.x;
+                    rsig[x4 * 4 + 1] = tt.y;
+                    rsig[x4 * 4 + 2] = tt.z;
+                    rsig[x4 * 4 + 3] = tt.w;
+                }
+                uint32_t m = 0xFFFFu;
+#pragma unroll
+                for (int j = 0; j < SB; j++) m = min(m, sigdist<W>(xa, &rsig[j * W]));
+                // Hit: queue the COARSE fact (sub-batch, column); which of the SB rows it was is worked out in
+                // flush_hits, lane-parallel.  The queue is private to the wave: the slot comes from the ballot
+                // (v_mbcnt), the fill level is a wave-uniform register — no LDS atomic, no rescan.
+                const bool h = m <= d && colok;
+                const unsigned long long act = (pa.dbg & 2) ? 0ull : __builtin_amdgcn_ballot_w64(h);
+                if (act != 0ull) {
+                    if (qn > QCAP - 64) {  // make room
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);
+                        qn = 0;
                     }
-                    uint32_t mg[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; g++) {
-                        mg[g] = 0xFFFFu;
-#pragma unroll
-                        for (int j = g * GC; j < (g + 1) * GC; j++) {
-#pragma unroll
-                            for (int r = 0; r < R; r++) mg[g] = min(mg[g], sigdist<W>(rs[r], &cs[j * W]));
-                        }
-                    }
-                    const uint32_t m = min(min(mg[0], mg[1]), min(mg[2], mg[3]));
-                    if (!(pa.dbg & 2) && __builtin_amdgcn_ballot_w64(m <= d) != 0ull) {
-                        // Hit path: only the column groups that hit are revisited, one compare per (column,row)
-                        // and a wave-level branch around the push.  The queue is private to the wave: slots come
-                        // from the ballot (v_mbcnt), the fill level is a wave-uniform register — no LDS atomic,
-                        // no per-lane bit masks, no drain loop.
-#pragma unroll
-                        for (int g = 0; g < NG; g++) {
-                            if (__builtin_amdgcn_ballot_w64(mg[g] <= d) == 0ull) continue;
-                            if (qn > QCAP - 64 * GC * R) {  // make room for the worst case of one group
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                flush_hits(pa, myq, qn, qshard);
-                                __builtin_amdgcn_wave_barrier();
-                                qn = 0;
-                            }
-#pragma unroll
-                            for (int j = g * GC; j < (g + 1) * GC; j++) {
-                                const int q = q0 + sb * SB + j;
-                                if (q < ctrue || q >= cend) continue;  // alignment padding (wave-uniform test)
-#pragma unroll
-                                for (int r = 0; r < R; r++) {
-                                    const bool h = sigdist<W>(rs[r], &cs[j * W]) <= d && r * 64 + lane < nrows;
-                                    const unsigned long long act = __builtin_amdgcn_ballot_w64(h);
-                                    if (act == 0ull) continue;
-                                    if (h) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = make_int2(row0 + r * 64 + lane, q);
-                                    qn += __popcll(act);
-                                    dbg_hits += __popcll(act);
-                                }
-                            }
-                        }
-                    }
+                    if (h) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = make_int2(row0 + sb * SB, q);
+                    qn += __popcll(act);
+                    dbg_hits += __popcll(act);
                 }
             }
             // rotate the pipeline and fetch one more chunk
-            q0a = q0b; cta = ctb; cea = ceb; va = vb; xa = xb;
-            q0b = q0c; ctb = ctc; ceb = cec; vb = vc; xb = xc;
-            q0c = q0d; ctc = ctd; cec = ced; vc = vd; xc = xd;
+            q0a = q0b; cta = ctb; cea = ceb; va = vb;
+            q0b = q0c; ctb = ctc; ceb = cec; vb = vc;
+            q0c = q0d; ctc = ctd; cec = ced; vc = vd;
+#pragma unroll
+            for (int x = 0; x < W; x++) {
+                xa[x] = xb[x];
+                xb[x] = xc[x];
+                xc[x] = xd[x];
+            }
             PF_FETCH(q0d, ctd, ced, vd, xd)
         }
 #undef PF_FETCH
@@ -922,7 +961,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (ba.dbg_t) t_main = wall_clock64();
-    if (qn > 0 && !(pa.dbg & 1)) flush_hits(pa, myq, qn, qshard);  // one flush per wave
+    if (qn > 0 && !(pa.dbg & 1)) flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
     if (ba.dbg_t && lane == 0) {
         unsigned long long *o = ba.dbg_t + (size_t)(t * PF_WAVES + wave) * 8;
         o[0] = t_start;
@@ -946,17 +985,23 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
 // A pair farther apart than d is marked (row a = -1); k_union then hooks the surviving edges, one per lane.
 // ------------------------------------------------------------------------------------------------
 // the shard queues seen as one index space: prefix of min(ncand[s], cap), built once per block in LDS
+// (first wave: 8 consecutive shards per lane, then a wave scan)
 __device__ __forceinline__ void shard_prefix(const PairArgs &pa, int *pre /*CAND_SHARDS+1, LDS*/) {
+    static_assert(CAND_SHARDS == 512, "8 shard counters per lane of the first wave");
     if (threadIdx.x < 64) {
-        static_assert(CAND_SHARDS == 64, "one shard counter per lane of the first wave");
-        const int c = (int)min(pa.ctr->ncand[threadIdx.x], (unsigned)pa.cand_cap_shard);
-        int inc = c;
-        for (int s = 1; s < 64; s <<= 1) {
-            const int y = __shfl_up(inc, s);
-            if ((int)threadIdx.x >= s) inc += y;
+        int c[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c[j] = (int)min(pa.ctr->ncand[threadIdx.x * 8 + j], (unsigned)pa.cand_cap_shard);
+            sum += c[j];
         }
-        pre[threadIdx.x + 1] = inc;
+        int run = wave_incl_scan_add(sum) - sum;
         if (threadIdx.x == 0) pre[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            run += c[j];
+            pre[threadIdx.x * 8 + j + 1] = run;
+        }
     }
     __syncthreads();
 }
