@@ -181,11 +181,11 @@ def main():
         # this rank's share of the pair tiles (work items are dealt round-robin)
         achieved = b_alg / world / t_pf / 1e9 if t_pf > 0 else None
         w = st["sig_words"]
-        ops_per_pair = 2 * w + 0.5
+        ops_per_pair = 2 * w + 1
         valu = st["pairs_filtered"] * ops_per_pair / t_pf if t_pf > 0 else None
         # measured issue cost on gfx950 (tools/ubench/valu_rate.hip, cycles per wave-instruction per SIMD @2.4 GHz):
-        # v_xor (VGPR operands) 2.6, v_bcnt 4.3, v_min3 4.4 per two slots
-        cyc_per_slot = w * (2.6 + 4.3) + 2.2
+        # v_xor (VGPR operands) 2.6, v_bcnt 4.3, v_min 4.3 per slot
+        cyc_per_slot = w * (2.6 + 4.3) + 4.3
         slots_ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
         slots_rate = st["pairs_filtered"] / t_pf if t_pf > 0 else None
         out = {
@@ -220,9 +220,12 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_launch": b_alg / world,
                 "kernel_ms": st["ms_prefilter"],
-                "note": "SURVEY 8(d) untiled operand-stream bytes (4(k_i+k_j) per in-band pair); the kernel "
-                        "keeps row signatures in VGPRs and streams column signatures through SGPRs, so it is "
-                        "VALU-issue bound and frac > 1 means operand reuse, not HBM over-subscription",
+                "note": "SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
+                        "band + 8 B per pruned pair.  The kernel never streams those operands: the (k,f,g) sort key "
+                        "prunes ~92% of the band before any comparison and the rest is a 4-byte signature compare "
+                        "out of registers/LDS, so frac >> 1 measures algorithmic reuse, not HBM over-subscription; "
+                        "measured HBM bytes per launch are in profiles/ (FETCH_SIZE/WRITE_SIZE passes)",
+                "pairs_in_reference_band": merged_pairs,
                 "valu": {"lane_ops_per_s": valu, "peak": VALU_PEAK_LANEOPS,
                          "frac": valu / VALU_PEAK_LANEOPS if valu else None,
                          "ops_per_pair": ops_per_pair, "pair_slots": st["pairs_filtered"],

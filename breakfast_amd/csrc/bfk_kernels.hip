@@ -1,18 +1,21 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
-// Pipeline (one stream, no host round trip between kernels):
-//   k_canon     one wave per row: sort key bin (k, f), bitonic sort of the token ids in registers, duplicate
-//               ranks, two XOR-parity signatures; parent[i] = i
-//   k_rowrank   (k,f,g) histogram + rank of every row inside its key
-//   k_cells     scan of the (k,f,g) cell counters -> start3, tile list (tiles never cross cells); re-zeroes state
-//   k_place     counting-sort scatter of row ids / lengths / signatures into (k,f) order
+// Pipeline (one stream, no host round trip and no memset between kernels):
+//   k_canon      one wave per row: sort key (k, f, g), bitonic sort of the token ids in registers (DPP /
+//                permlane exchanges), repeat ranks, two XOR-parity signatures; parent[i] = i
 //   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
-//   k_prefilter THE dominant kernel: all in-band pairs, popcount(sig_p ^ sig_q) <= d  (necessary
-//               condition for |A delta B| <= d); survivors pass a 128-bit second level and are queued
-//   k_verify    one wave per candidate: row B staged in LDS, lanes binary-search A's elements,
-//               ballot/popcount -> exact multiset distance; <= d -> lock-free union-find hook
-//   k_flatten   labels[i] = root(i) = smallest row index of the component
-//   k_merge     multi-GPU: unite (i, gathered[g][i]) pseudo-edges
+//   k_rowrank    (k,f,g) cell histogram + rank of every row inside its cell (LDS hash aggregation)
+//   k_cells      chained multi-block scan of the cell counters -> start3, tile list (tiles never cross cells);
+//                re-zeroes histogram and counters for the next step
+//   k_place      counting-sort scatter of row ids / lengths / signatures into (k,f,g) order
+//   k_prefilter  the pair kernel: one block per tile; the columns that can be within d of the tile's rows are
+//                a few contiguous ranges (the (k,f,g) band); popcount(sig_row ^ sig_col) <= d is a necessary
+//                condition for |A delta B| <= d; survivors pass a 64-bit second level and are queued
+//   k_verify     one 16-lane group per candidate: longer row staged in LDS, lanes binary-search the shorter
+//                row's elements, ballot/popcount -> exact multiset distance
+//   k_union      one verified edge per lane: lock-free union-find hook
+//   k_flatten    labels[i] = root(i) = smallest row index of the component
+//   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
 //
 // What it replaces in the reference: the band loop + get_neighbours_batch + sklearn _sparse_manhattan +
 // _reduce_func + networkx components (src/breakfast/breakfast.py:223-276, 287-326).
@@ -338,37 +341,6 @@ __device__ __forceinline__ void wave_bitonic(uint32_t (&x)[E], int lane) {
     bitonic_all<E, 64 * E>(x, lane);
 }
 
-template <int E>
-__device__ __forceinline__ void wave_bitonic_bpermute(uint32_t (&x)[E], int lane) {
-#pragma unroll
-    for (int size = 2; size <= 64 * E; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 64) {
-                const int es = stride >> 6;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if ((e & es) == 0) {
-                        const int e2 = e | es;
-                        const bool asc = (((e * 64) & size) == 0);
-                        uint32_t lo = min(x[e], x[e2]), hi = max(x[e], x[e2]);
-                        x[e] = asc ? lo : hi;
-                        x[e2] = asc ? hi : lo;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    uint32_t y = __shfl_xor(x[e], stride);
-                    const bool asc = ((((e * 64) + lane) & size) == 0);
-                    const bool lower = ((lane & stride) == 0);
-                    x[e] = (lower == asc) ? min(x[e], y) : max(x[e], y);
-                }
-            }
-        }
-    }
-}
-
 // the row's sort key (k, f, g) -> key3
 struct RowKeyArgs {
     int *rowkey;
@@ -631,19 +603,6 @@ struct PairArgs {
     int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
     Counters *ctr;
 };
-
-// queue record: everything k_verify needs in ONE round trip (row ids, row offsets, row lengths)
-__device__ __forceinline__ void push_cand(const PairArgs &a, int shard, int idx, int ra, int rb) {
-    if (idx >= a.cand_cap_shard) {
-        a.ctr->overflow = 1;  // dropped: the host re-runs the item range in smaller slices
-        return;
-    }
-    const int ba = a.indptr[ra], ea = a.indptr[ra + 1];
-    const int bb = a.indptr[rb], eb = a.indptr[rb + 1];
-    const size_t o = (size_t)shard * a.cand_cap_shard + idx;
-    a.cand[o] = make_int4(ra, rb, ba, bb);
-    a.candk[o] = make_int2(ea - ba, eb - bb);
-}
 
 // flush `cnt` queued (p,q) hits: filter, translate to row ids, append to the shard's global queue with
 // one global atomic per wave; a full global queue raises the overflow flag (host re-runs in slices).
