@@ -12,19 +12,21 @@ constexpr int CAND_SHARDS = 512;       // candidate queue shards: returning atom
 constexpr int PF_WAVES = 2;            // waves per prefilter block = waves sharing one tile
 constexpr int PF_LDS_QUEUE = 256;      // per-wave LDS coarse hit queue entries (2 KiB per wave)
 constexpr int PF_PAIR_LIST = 256;      // per-wave LDS list of exact pairs inside flush_hits (2 KiB per wave)
-constexpr int VERIFY_LDS_ROW = 128;    // tokens of row B staged per 16-lane group in k_verify (512 B/group)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
-constexpr int LONG_LDS_CAP = 15360;    // tokens of a long row staged in LDS by k_canon_long (60 KiB)
+constexpr int VERIFY_TABLE = 256;       // hash-table slots per 16-lane group in k_verify (2 KiB of LDS)
+constexpr int VERIFY_MAX_TOKENS = 192;  // pairs with more tokens (both rows) go to k_verify_long
+constexpr int LONG_TABLE = 4096;        // hash-table slots in LDS per block of k_verify_long (32 KiB)
+constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long (each owns a slice of the global scratch table)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 
 struct Counters {
     unsigned int ncand[CAND_SHARDS];
     int err;
-    int err_rows;  // set by k_canon (row longer than at bind time); cleared by the host only
+    int err_rows;  // set by k_sig (row longer than at bind time); cleared by the host only
     unsigned int n_work;   // tiles
     unsigned int ticket;   // arrival order of the k_cells blocks
-    unsigned int n_long;
+    unsigned int pad_long;
     int overflow;
     unsigned long long pairs_in_band;
     unsigned long long pairs_filtered;
@@ -40,13 +42,15 @@ struct Plan {
     int rows_per_lane, fb, gb;
     int shard, n_shards;
     int verify_grid, union_grid;
-    int tile_cap, cand_cap_shard, edge_cap, long_lds_cap, dbg;
+    int tile_cap, cand_cap_shard, edge_cap, dbg;
+    unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;
     const uint32_t *indices;
-    uint32_t *cols;
     int *hist3, *start3, *rowkey, *rowrank, *tile_slots;
     unsigned long long *chain;
-    int *perm, *ksorted, *parent, *longrows;
+    int *perm, *ksorted, *parent;
+    uint32_t *gkey;
+    int *gcnt;
     uint32_t *sig1, *sig2, *sigu1, *sigu2;
     int4 *tiles;
     int4 *cand;

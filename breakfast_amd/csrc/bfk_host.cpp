@@ -165,9 +165,10 @@ struct bfk_ctx {
     unsigned long long *d_chain = nullptr;
     int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
     int64_t bins3 = 0;
-    uint32_t *d_cols = nullptr;
-    int64_t cols_cap = 0;
-    int *d_perm = nullptr, *d_ksorted = nullptr, *d_parent = nullptr, *d_longrows = nullptr;
+    uint32_t *d_gkey = nullptr;
+    int *d_gcnt = nullptr;
+    int64_t gslots = 0, gkey_cap = 0, gcnt_cap = 0;
+    int *d_perm = nullptr, *d_ksorted = nullptr, *d_parent = nullptr;
     uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
     bool need_zero = true;  // head (counters + histogram) must be memset before the next run
     int64_t rows_cap = 0;
@@ -240,8 +241,8 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_cols,   c->d_perm,   c->d_sigu1,
-                    c->d_ksorted,  c->d_parent,    c->d_longrows, c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_gkey,   c->d_perm,   c->d_sigu1,
+                    c->d_ksorted,  c->d_parent,    c->d_gcnt,   c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
                     c->d_rowrank,  c->d_tile_slots, c->d_cand,  c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
                     c->d_chain};
     for (void *p : ptrs)
@@ -312,14 +313,23 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         c->bins_cap = bins3;
         c->need_zero = true;
     }
-    if (int rc = dev_realloc(&c->d_cols, &c->cols_cap, nnz + 1, 1.0)) return rc;
+    (void)nnz;
+    {   // k_verify_long: pairs of very long rows that do not fit the 64 KiB LDS table use a global scratch table
+        c->gslots = 0;
+        if (2 * (int64_t)c->kcap * 4 > (int64_t)LONG_TABLE * 3) {
+            int64_t tsz = 1024;
+            while (tsz * 3 < 2 * (int64_t)c->kcap * 4) tsz <<= 1;
+            c->gslots = tsz;
+            if (int rc = dev_realloc(&c->d_gkey, &c->gkey_cap, tsz * LONG_BLOCKS, 1.0)) return rc;
+            if (int rc = dev_realloc(&c->d_gcnt, &c->gcnt_cap, tsz * LONG_BLOCKS, 1.0)) return rc;
+        }
+    }
     if (n + SIG_PAD_ROWS > c->rows_cap) {
         int64_t cap = 0, want = n + SIG_PAD_ROWS;
         int rc = 0;
         cap = 0; rc |= dev_realloc(&c->d_perm, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
-        cap = 0; rc |= dev_realloc(&c->d_longrows, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowkey, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
@@ -432,7 +442,9 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
-    pl.long_lds_cap = LONG_LDS_CAP;
+    pl.gkey = c->d_gkey;
+    pl.gcnt = c->d_gcnt;
+    pl.gslots = (unsigned)c->gslots;
     pl.dbg = getenv("BFK_PF_DEBUG") ? atoi(getenv("BFK_PF_DEBUG")) : 0;
     pl.dbg_t = nullptr;
     if (pl.dbg & 4) {
@@ -448,7 +460,6 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     }
     pl.indptr = c->d_indptr;
     pl.indices = c->d_indices;
-    pl.cols = c->d_cols;
     pl.ctr = (Counters *)c->d_head;
     pl.hist3 = (int *)(c->d_head + sizeof(Counters));
     pl.start3 = c->d_start3;
@@ -459,7 +470,6 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.perm = c->d_perm;
     pl.ksorted = c->d_ksorted;
     pl.parent = c->d_parent;
-    pl.longrows = c->d_longrows;
     pl.sig1 = c->d_sig1;
     pl.sig2 = c->d_sig2;
     pl.sigu1 = c->d_sigu1;

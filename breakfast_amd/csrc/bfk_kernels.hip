@@ -74,11 +74,15 @@ __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
     return false;
 }
 
-// signature hashes of the composite key (token id x, repeat rank r)
-__device__ __forceinline__ uint32_t hash1(uint32_t x, uint32_t r) { return x * 0x9E3779B1u + r * 0x7FEB352Du; }
-__device__ __forceinline__ uint32_t hash2(uint32_t x, uint32_t r) {
-    uint32_t h = (x ^ (x >> 15)) * 0x85EBCA6Bu + r * 0xC2B2AE35u;
+// signature hashes of a token id (two independent multiplicative hashes) and the verify table's slot hash
+__device__ __forceinline__ uint32_t hash1(uint32_t x) { return x * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t hash2(uint32_t x) {
+    uint32_t h = (x ^ (x >> 15)) * 0x85EBCA6Bu;
     return h ^ (h >> 13);
+}
+__device__ __forceinline__ uint32_t hash3(uint32_t x) {
+    uint32_t h = x * 0xC2B2AE35u;
+    return h ^ (h >> 15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,7 +196,6 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         if (threadIdx.x == 64) {
             a.ctr->err = 0;
             a.ctr->overflow = 0;
-            a.ctr->n_long = 0;  // consumed by k_canon_long, which ran before this kernel
             a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
         }
     }
@@ -260,35 +263,14 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_canon: one wave per row.  Bitonic sort of 64*E token ids held E per lane (index j = e*64 + lane:
-// partners at distance < 64 are a cross-lane exchange, >= 64 an in-register one), duplicate ranks,
-// signatures.  Writes the canonical row (sorted, repeats kept) to cols and the signatures at the row's
-// length-sorted position.
+// k_sig: one wave per row, 64 tokens per step: the row's sort key (k, f, g) and its two XOR-parity
+// signatures.  Nothing here needs the row sorted: a token that occurs an even number of times cancels itself
+// in the signature, which keeps popcount(sig(A) ^ sig(B)) <= #{t : a_t + b_t odd} <= sum_t |a_t - b_t| = L1
+// valid for multiset rows (the reference's count matrix) — so the rows are never sorted at all; the exact
+// check (k_verify) works on the unsorted rows through a hash table.  parent[i] = i.
 // ------------------------------------------------------------------------------------------------
-// cross-lane exchange x[lane ^ STRIDE] without the LDS crossbar: ds_bpermute costs ~26 cycles per
-// wave-instruction per SIMD on gfx950 (tools/ubench/valu_rate.hip), a DPP move ~4, v_permlane*_swap ~8.
-template <int STRIDE>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
-    if constexpr (STRIDE == 1) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-    } else if constexpr (STRIDE == 2) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-    } else if constexpr (STRIDE == 4) {
-        // banks 0,2 of each 16-lane row read lane+4 (row_shl:4), banks 1,3 read lane-4 (row_shr:4)
-        int y = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);
-        return (uint32_t)__builtin_amdgcn_update_dpp(y, (int)x, 0x114, 0xF, 0xA, false);
-    } else if constexpr (STRIDE == 8) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
-    } else if constexpr (STRIDE == 16) {
-        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // {x0,x0,x2,x2}, {x1,x1,x3,x3}
-        return (lane & 16) ? r[0] : r[1];
-    } else {
-        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // {lo,lo}, {hi,hi}
-        return (lane & 32) ? r[0] : r[1];
-    }
-}
-
-// XOR of x over the 64 lanes, valid in lane 63 (DPP prefix within rows, then row broadcasts)
+// XOR of x over the 64 lanes, valid in lane 63 (DPP prefix within rows, then row broadcasts; a DPP op costs
+// ~4 cycles per wave-instruction on gfx950, ds_bpermute ~26: tools/ubench/valu_rate.hip)
 __device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t x) {
     x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
     x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
@@ -299,234 +281,81 @@ __device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t x) {
     return x;
 }
 
-template <int E, int SIZE, int STRIDE>
-__device__ __forceinline__ void bitonic_step(uint32_t (&x)[E], int lane) {
-    if constexpr (STRIDE >= 64) {
-        constexpr int es = STRIDE >> 6;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            if ((e & es) == 0) {
-                const int e2 = e | es;
-                const bool asc = (((e * 64) & SIZE) == 0);
-                uint32_t lo = min(x[e], x[e2]), hi = max(x[e], x[e2]);
-                x[e] = asc ? lo : hi;
-                x[e2] = asc ? hi : lo;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t y = lane_xor<STRIDE>(x[e], lane);
-            const bool asc = ((((e * 64) + lane) & SIZE) == 0);
-            const bool lower = ((lane & STRIDE) == 0);
-            x[e] = (lower == asc) ? min(x[e], y) : max(x[e], y);
-        }
-    }
-}
-
-template <int E, int SIZE, int STRIDE>
-__device__ __forceinline__ void bitonic_merge(uint32_t (&x)[E], int lane) {
-    bitonic_step<E, SIZE, STRIDE>(x, lane);
-    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, (STRIDE >> 1)>(x, lane);
-}
-
-template <int E, int SIZE>
-__device__ __forceinline__ void bitonic_all(uint32_t (&x)[E], int lane) {
-    if constexpr (SIZE > 2) bitonic_all<E, (SIZE >> 1)>(x, lane);
-    bitonic_merge<E, SIZE, (SIZE >> 1)>(x, lane);
-}
-
-template <int E>
-__device__ __forceinline__ void wave_bitonic(uint32_t (&x)[E], int lane) {
-    bitonic_all<E, 64 * E>(x, lane);
-}
-
-// the row's sort key (k, f, g) -> key3
-struct RowKeyArgs {
-    int *rowkey;
-    KeyCfg key;
-};
-
-template <int E, int W1>
-__device__ __forceinline__ void canon_row(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int k,
-                                          int lane, uint32_t *lds_row, uint32_t *sig1_out, uint32_t *sig2_out,
-                                          const RowKeyArgs &rk, int row) {
-    uint32_t x[E];
-    int f = 0, g = 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        int j = e * 64 + lane;
-        x[e] = j < k ? src[j] : 0xFFFFFFFFu;
-        f += __popcll(__builtin_amdgcn_ballot_w64(j < k && fbit(x[e]) != 0u));
-        g += __popcll(__builtin_amdgcn_ballot_w64(j < k && gbit(x[e]) != 0u));
-    }
-    const int key3 = key3_of(rk.key, k, f, g);
-    wave_bitonic<E>(x, lane);
-    // repeat rank r_j = number of equal predecessors (0 unless the multiset row repeats a token)
-    uint32_t r[E];
-    bool anydup = false;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        int j = e * 64 + lane;
-        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[e], 0x138, 0xF, 0xF, false);  // wave_shr:1
-        if (e > 0) {
-            uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)x[e - 1], 63);
-            if (lane == 0) prev = tail;
-        }
-        bool eq = (j > 0) && (j < k) && (prev == x[e]);
-        r[e] = eq ? 1u : 0u;
-        anydup |= eq;
-        if (j < k) dst[j] = x[e];
-    }
-    if (__any(anydup)) {  // rare: stage the sorted row in the wave's LDS slice and count runs
-#pragma unroll
-        for (int e = 0; e < E; e++) lds_row[e * 64 + lane] = x[e];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            int j = e * 64 + lane;
-            uint32_t c = 0;
-            if (j < k)
-                while ((int)c < j && lds_row[j - 1 - (int)c] == x[e]) c++;
-            r[e] = c;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    uint32_t s1[W1], s2[SIG2_WORDS];
-#pragma unroll
-    for (int w = 0; w < W1; w++) s1[w] = 0;
-#pragma unroll
-    for (int w = 0; w < SIG2_WORDS; w++) s2[w] = 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        int j = e * 64 + lane;
-        if (j < k) {
-            uint32_t b1 = hash1(x[e], r[e]) >> (32 - (5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2))));
-            uint32_t b2 = hash2(x[e], r[e]) >> (32 - 6);
-#pragma unroll
-            for (int w = 0; w < W1; w++)
-                if ((int)(b1 >> 5) == w) s1[w] ^= 1u << (b1 & 31);
-#pragma unroll
-            for (int w = 0; w < SIG2_WORDS; w++)
-                if ((int)(b2 >> 5) == w) s2[w] ^= 1u << (b2 & 31);
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < W1; w++) s1[w] = wave_xor_to_lane63(s1[w]);
-#pragma unroll
-    for (int w = 0; w < SIG2_WORDS; w++) s2[w] = wave_xor_to_lane63(s2[w]);
-    if (lane == 63) {
-#pragma unroll
-        for (int w = 0; w < W1; w++) sig1_out[w] = s1[w];
-#pragma unroll
-        for (int w = 0; w < SIG2_WORDS; w++) sig2_out[w] = s2[w];
-    }
-    if (lane == 0) rk.rowkey[row] = key3;  // ranked by k_rowrank (a returning atomic here would stall the wave)
-}
-
 template <int W1>
-__global__ __launch_bounds__(256) void k_canon(const int *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                int n, int kcap, RowKeyArgs rk, int *__restrict__ parent,
-                                                uint32_t *__restrict__ cols, uint32_t *__restrict__ sigu1,
-                                                uint32_t *__restrict__ sigu2, int *longrows, Counters *ctr) {
-    __shared__ uint32_t lds_rows[4][256];
+__global__ __launch_bounds__(256) void k_sig(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
+                                              int kcap, KeyCfg key, int *__restrict__ rowkey, int *__restrict__ parent,
+                                              uint32_t *__restrict__ sigu1, uint32_t *__restrict__ sigu2, Counters *ctr) {
+    constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
     int i = blockIdx.x * 4 + wave;
     if (i >= n) return;
+    // software pipeline over this wave's rows: extents are fetched two rows ahead, the first 64 tokens one
+    // row ahead, so a row costs no exposed round trip
     int b = indptr[i], e = indptr[i + 1];
+    int nb = 0, ne = 0;
+    if (i + nwaves < n) {
+        nb = indptr[i + nwaves];
+        ne = indptr[i + nwaves + 1];
+    }
+    uint32_t xfirst = (lane < e - b) ? indices[b + lane] : 0u;
     while (true) {
-        // the next row's extent is fetched while this row is sorted (one dependent round trip fewer per row)
-        const int inext = i + nwaves;
-        int nb = 0, ne = 0;
-        if (inext < n) {
-            nb = indptr[inext];
-            ne = indptr[inext + 1];
+        const int inext = i + nwaves, inext2 = i + 2 * nwaves;
+        int nb2 = 0, ne2 = 0;
+        if (inext2 < n) {
+            nb2 = indptr[inext2];
+            ne2 = indptr[inext2 + 1];
         }
+        const uint32_t xnext = (inext < n && lane < ne - nb) ? indices[nb + lane] : 0u;
         int k = e - b;
         if (k < 0 || k > kcap) {
             if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
             k = k < 0 ? 0 : kcap;
         }
-        if (lane == 0) parent[i] = i;
-        const uint32_t *src = indices + b;
-        uint32_t *dst = cols + b;
-        uint32_t *o1 = sigu1 + (size_t)i * W1, *o2 = sigu2 + (size_t)i * SIG2_WORDS;  // row order; k_place sorts
-        if (k <= 64) canon_row<1, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
-        else if (k <= 128) canon_row<2, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
-        else if (k <= 256) canon_row<4, W1>(src, dst, k, lane, lds_rows[wave], o1, o2, rk, i);
-        else if (lane == 0) longrows[atomicAdd(&ctr->n_long, 1u)] = i;
+        uint32_t s1[W1], s2[SIG2_WORDS];
+#pragma unroll
+        for (int w = 0; w < W1; w++) s1[w] = 0;
+#pragma unroll
+        for (int w = 0; w < SIG2_WORDS; w++) s2[w] = 0;
+        int f = 0, g = 0;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < k;
+            const uint32_t x = j0 == 0 ? xfirst : (valid ? indices[b + j] : 0u);
+            f += __popcll(__builtin_amdgcn_ballot_w64(valid && fbit(x) != 0u));
+            g += __popcll(__builtin_amdgcn_ballot_w64(valid && gbit(x) != 0u));
+            if (valid) {
+                const uint32_t b1 = hash1(x) >> (32 - LOG1);
+                const uint32_t b2 = hash2(x) >> (32 - 6);
+#pragma unroll
+                for (int w = 0; w < W1; w++)
+                    if ((int)(b1 >> 5) == w) s1[w] ^= 1u << (b1 & 31);
+#pragma unroll
+                for (int w = 0; w < SIG2_WORDS; w++)
+                    if ((int)(b2 >> 5) == w) s2[w] ^= 1u << (b2 & 31);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W1; w++) s1[w] = wave_xor_to_lane63(s1[w]);
+#pragma unroll
+        for (int w = 0; w < SIG2_WORDS; w++) s2[w] = wave_xor_to_lane63(s2[w]);
+        if (lane == 63) {  // row order; k_place moves them to the sorted position
+#pragma unroll
+            for (int w = 0; w < W1; w++) sigu1[(size_t)i * W1 + w] = s1[w];
+#pragma unroll
+            for (int w = 0; w < SIG2_WORDS; w++) sigu2[(size_t)i * SIG2_WORDS + w] = s2[w];
+        }
+        if (lane == 0) {
+            rowkey[i] = key3_of(key, k, f, g);
+            parent[i] = i;
+        }
         if (inext >= n) break;
         i = inext;
         b = nb;
         e = ne;
-    }
-}
-
-// rows longer than 256 tokens: one block per row, rank sort (each element counts its predecessors);
-// the row is staged in dynamic LDS when it fits (up to 32768 tokens = 128 KiB of the CU's 160 KiB).
-template <int W1>
-__global__ __launch_bounds__(256) void k_canon_long(const int *__restrict__ indptr,
-                                                     const uint32_t *__restrict__ indices, int kcap, RowKeyArgs rk,
-                                                     uint32_t *cols, uint32_t *sigu1, uint32_t *sigu2,
-                                                     const int *__restrict__ longrows, const Counters *ctr,
-                                                     int lds_cap) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t row_lds[];
-    __shared__ uint32_t s1[4], s2[SIG2_WORDS];
-    __shared__ int sf, sg;
-    const int nlong = (int)ctr->n_long;
-    for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
-        int i = longrows[li];
-        int b = indptr[i];
-        int k = min(indptr[i + 1] - b, kcap);
-        const uint32_t *src = indices + b;
-        uint32_t *dst = cols + b;
-        const bool staged = k <= lds_cap;
-        if (threadIdx.x < 4) s1[threadIdx.x] = 0;
-        if (threadIdx.x < SIG2_WORDS) s2[threadIdx.x] = 0;
-        if (threadIdx.x == 0) sf = sg = 0;
-        if (staged)
-            for (int j = threadIdx.x; j < k; j += 256) row_lds[j] = src[j];
-        __syncthreads();
-        int fl = 0, gl = 0;
-        for (int j = threadIdx.x; j < k; j += 256) {
-            uint32_t x = staged ? row_lds[j] : src[j];
-            fl += (int)fbit(x);
-            gl += (int)gbit(x);
-            int rank = 0;
-            if (staged) {
-                for (int m = 0; m < k; m++) {
-                    uint32_t y = row_lds[m];
-                    rank += (y < x) || (y == x && m < j);
-                }
-            } else {
-                for (int m = 0; m < k; m++) {
-                    uint32_t y = src[m];
-                    rank += (y < x) || (y == x && m < j);
-                }
-            }
-            __hip_atomic_store(dst + rank, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (fl) atomicAdd(&sf, fl);
-        if (gl) atomicAdd(&sg, gl);
-        __threadfence_block();
-        __syncthreads();
-        for (int j = threadIdx.x; j < k; j += 256) {
-            uint32_t x = ld_agent_u(dst + j);
-            uint32_t r = 0;
-            while ((int)r < j && ld_agent_u(dst + j - 1 - (int)r) == x) r++;
-            uint32_t b1 = hash1(x, r) >> (32 - (5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2))));
-            uint32_t b2 = hash2(x, r) >> (32 - 6);
-            atomicXor(&s1[b1 >> 5], 1u << (b1 & 31));
-            atomicXor(&s2[b2 >> 5], 1u << (b2 & 31));
-        }
-        __syncthreads();
-        if (threadIdx.x < W1) sigu1[(size_t)i * W1 + threadIdx.x] = s1[threadIdx.x];
-        if (threadIdx.x < SIG2_WORDS) sigu2[(size_t)i * SIG2_WORDS + threadIdx.x] = s2[threadIdx.x];
-        if (threadIdx.x == 0) rk.rowkey[i] = key3_of(rk.key, k, sf, sg);
-        __syncthreads();
+        nb = nb2;
+        ne = ne2;
+        xfirst = xnext;
     }
 }
 
@@ -590,7 +419,7 @@ __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, i
 // ------------------------------------------------------------------------------------------------
 struct PairArgs {
     const int *indptr;
-    const uint32_t *cols;
+    const uint32_t *rows;  // the raw CSR indices (unsorted rows, repeats kept)
     const int *perm;
     const int *ksorted;
     const uint32_t *sig2;
@@ -935,13 +764,13 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_verify: exact multiset distance of every queued candidate, one 16-lane group per candidate (four
-// per wave: the work is latency-bound — dependent memory round trips per pair — so the kernel is
-// organised for pairs in flight, not lanes per pair).  The longer row (B) is staged in the group's LDS
-// slice by a coalesced load; each lane takes elements of the shorter row (A, 16 per step), finds the
-// lower bound in B by binary search and checks the (token, repeat-rank) match; the ballot's popcount
-// over the group's 16 bits counts A elements without a partner.  |A delta B| = kA + kB - 2*matches.
-// A pair farther apart than d is marked (row a = -1); k_union then hooks the surviving edges, one per lane.
+// k_verify: exact multiset distance of every queued candidate, one 16-lane group per pair (four per wave:
+// the work is latency-bound, so the kernel is organised for pairs in flight, not lanes per pair).
+// The rows are NOT sorted.  The group owns a 256-slot hash table in LDS ({token, signed count}); the tokens of
+// row A are inserted with +1 and those of row B with -1, 16 at a time (CAS on the key claims a slot, equal
+// tokens meet in the same slot, ds_add adds the sign); the distance is sum |count| over the table
+// (= sum_t |a_t - b_t|, exact for multisets).  Pairs with more than VERIFY_MAX_TOKENS tokens are left to
+// k_verify_long.  A pair farther apart than d is marked (row a = -1); k_union hooks the rest.
 // ------------------------------------------------------------------------------------------------
 // the shard queues seen as one index space: prefix of min(ncand[s], cap), built once per block in LDS
 // (first wave: 8 consecutive shards per lane, then a wave scan)
@@ -974,80 +803,138 @@ __device__ __forceinline__ size_t shard_slot(const int *pre, const PairArgs &pa,
     return (size_t)lo * pa.cand_cap_shard + (size_t)(c - pre[lo]);
 }
 
+// sum of x over the 16 lanes of a DPP row, valid in the row's lane 15
+__device__ __forceinline__ int row16_sum_to_lane15(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    return x;
+}
+
+// insert token x with sign sgn into an open-addressing table of `mask`+1 slots (LDS or global)
+__device__ __forceinline__ void table_add(uint32_t *tkey, int *tcnt, uint32_t mask, uint32_t x, int sgn) {
+    uint32_t s = hash3(x) & mask;
+    while (true) {
+        const uint32_t old = atomicCAS(&tkey[s], 0xFFFFFFFFu, x);
+        if (old == 0xFFFFFFFFu || old == x) break;
+        s = (s + 1) & mask;
+    }
+    atomicAdd(&tcnt[s], sgn);
+}
+
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
-    __shared__ uint32_t sB[16][VERIFY_LDS_ROW];
-    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;           // 0..15 in the block
-    const int gsh = (lane >> 4) * 16;           // bit offset of this group inside the wave ballot
-    const int gg = blockIdx.x * 16 + grp, ng = gridDim.x * 16;
-    uint32_t *myB = sB[grp];
+    __shared__ uint2 tab[16][VERIFY_TABLE];  // {token, signed count}
     __shared__ int spre[CAND_SHARDS + 1];
+    const int l16 = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;           // 0..15 in the block
+    const int gg = blockIdx.x * 16 + grp, ng = gridDim.x * 16;
+    uint2 *mt = tab[grp];
     shard_prefix(pa, spre);
     const int total = spre[CAND_SHARDS];
     for (int c = gg; c < total; c += ng) {
         const size_t slot = shard_slot(spre, pa, c);
         const int4 rec = pa.cand[slot];
         const int2 kk = pa.candk[slot];
-        int ba = rec.z, ka = kk.x, bb = rec.w, kb = kk.y;
-        if (ka > kb) {  // A = shorter row
-            int t = ba; ba = bb; bb = t;
-            t = ka; ka = kb; kb = t;
-        }
-        const uint32_t *A = pa.cols + ba, *B = pa.cols + bb;
-        const int allowed = (pa.d - (kb - ka)) >> 1;  // A elements allowed to stay unmatched
-        bool ok = (kb - ka) <= pa.d;
-        const bool staged = kb <= VERIFY_LDS_ROW;
-        int miss = 0;
-        for (int i0 = 0; i0 < ka; i0 += 64) {  // 64 A elements per step: 4 per lane, all loads in flight at once
-            uint32_t x[4], xp[4];
+        const int ka = kk.x, kb = kk.y, kt = ka + kb;
+        if (kt > VERIFY_MAX_TOKENS) continue;  // k_verify_long
+        const uint32_t *A = pa.rows + rec.z, *B = pa.rows + rec.w;
+        // all token loads of the pair are issued first (one round trip, not one per step)
+        constexpr int STEPS = VERIFY_MAX_TOKENS / 16;
+        uint32_t x[STEPS];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = i0 + e * 16 + l16;
-                x[e] = (ok && i < ka) ? A[i] : 0u;
-                xp[e] = (ok && i < ka && i > 0) ? A[i - 1] : 0xFFFFFFFFu;
-            }
-            if (i0 == 0) {
-                if (ok && staged)
-                    for (int j = l16; j < kb; j += 16) myB[j] = B[j];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = i0 + e * 16 + l16;
-                const bool valid = ok && i < ka;
-                bool found = false;
-                if (valid) {
-                    int r = 0;
-                    if (xp[e] == x[e]) {  // repeated token: rank inside its run
-                        r = 1;
-                        while (r < i && A[i - 1 - r] == x[e]) r++;
-                    }
-                    int lo = 0, hi = kb;  // lower bound of x in B
-                    if (staged) {
-                        while (lo < hi) {
-                            int mid = (lo + hi) >> 1;
-                            if (myB[mid] < x[e]) lo = mid + 1;
-                            else hi = mid;
-                        }
-                        found = (lo + r < kb) && (myB[lo + r] == x[e]);
-                    } else {
-                        while (lo < hi) {
-                            int mid = (lo + hi) >> 1;
-                            if (B[mid] < x[e]) lo = mid + 1;
-                            else hi = mid;
-                        }
-                        found = (lo + r < kb) && (B[lo + r] == x[e]);
-                    }
-                }
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && !found);
-                miss += __popc((unsigned)((bal >> gsh) & 0xFFFFull));
-            }
-            if (miss > allowed) ok = false;
+        for (int s = 0; s < STEPS; s++) {
+            const int j = s * 16 + l16;
+            x[s] = j < ka ? A[j] : (j < kt ? B[j - ka] : 0u);
         }
+        // table size: power of two >= 2 * tokens (load <= 1/2), capped at VERIFY_TABLE (load <= 3/4)
+        uint32_t tsz = 16;
+        while ((int)tsz < 2 * kt && tsz < VERIFY_TABLE) tsz <<= 1;
+        const uint32_t mask = tsz - 1;
+        for (uint32_t t = l16; t < tsz; t += 16) mt[t] = make_uint2(0xFFFFFFFFu, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (!ok && l16 == 0) pa.cand[slot].x = -1;
+        // first probe of every token: the CASes are independent, so they are all in flight together
+        uint32_t sl[STEPS], old[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            sl[s] = hash3(x[s]) & mask;
+            old[s] = 0xFFFFFFFFu;
+            if (s * 16 + l16 < kt) old[s] = atomicCAS(&mt[sl[s]].x, 0xFFFFFFFFu, x[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int j = s * 16 + l16;
+            if (j < kt) {
+                uint32_t p = sl[s], o = old[s];
+                while (o != 0xFFFFFFFFu && o != x[s]) {  // occupied by another token: linear probing
+                    p = (p + 1) & mask;
+                    o = atomicCAS(&mt[p].x, 0xFFFFFFFFu, x[s]);
+                }
+                atomicAdd(reinterpret_cast<int *>(&mt[p].y), j < ka ? 1 : -1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int dist = 0;
+        for (uint32_t t = l16; t < tsz; t += 16) dist += abs((int)mt[t].y);
+        dist = row16_sum_to_lane15(dist);
+        __builtin_amdgcn_wave_barrier();
+        if (l16 == 15 && dist > pa.d) pa.cand[slot].x = -1;
+    }
+}
+
+// k_verify_long: pairs with more tokens than a group table holds: one block per pair, table in dynamic LDS
+// (up to LONG_TABLE slots) or, beyond that, in the block's slice of a global scratch table.
+__global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey, int *gcnt, unsigned gslots) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldyn[];
+    __shared__ int spre[CAND_SHARDS + 1];
+    __shared__ int sdist;
+    shard_prefix(pa, spre);
+    const int total = spre[CAND_SHARDS];
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {
+        const size_t slot = shard_slot(spre, pa, c);
+        const int2 kk = pa.candk[slot];
+        const int ka = kk.x, kb = kk.y, kt = ka + kb;
+        if (kt <= VERIFY_MAX_TOKENS) continue;  // done by k_verify
+        const int4 rec = pa.cand[slot];
+        uint32_t tsz = 1024;
+        while ((unsigned long long)tsz * 3ull < (unsigned long long)kt * 4ull) tsz <<= 1;
+        uint32_t *mk;
+        int *mc;
+        if (tsz <= LONG_TABLE) {
+            mk = ldyn;
+            mc = reinterpret_cast<int *>(ldyn + tsz);
+        } else {
+            if (tsz > gslots || !gkey) {  // cannot happen: the scratch table is sized from the longest row at bind time
+                if (threadIdx.x == 0) atomicOr(&pa.ctr->err, ERR_WORKCAP);
+                continue;
+            }
+            mk = gkey + (size_t)blockIdx.x * gslots;
+            mc = gcnt + (size_t)blockIdx.x * gslots;
+        }
+        const uint32_t mask = tsz - 1;
+        for (uint32_t t = threadIdx.x; t < tsz; t += 256) {
+            mk[t] = 0xFFFFFFFFu;
+            mc[t] = 0;
+        }
+        if (threadIdx.x == 0) sdist = 0;
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t *A = pa.rows + rec.z, *B = pa.rows + rec.w;
+        for (int j = threadIdx.x; j < kt; j += 256) {
+            const bool fromA = j < ka;
+            table_add(mk, mc, mask, fromA ? A[j] : B[j - ka], fromA ? 1 : -1);
+        }
+        __threadfence_block();
+        __syncthreads();
+        int dist = 0;
+        for (uint32_t t = threadIdx.x; t < tsz; t += 256) dist += abs(__hip_atomic_load(&mc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (dist) atomicAdd(&sdist, dist);
+        __syncthreads();
+        if (threadIdx.x == 0 && sdist > pa.d) pa.cand[slot].x = -1;
+        __syncthreads();
     }
 }
 
@@ -1156,7 +1043,7 @@ int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st) {
 static PairArgs make_pair_args(const Plan &pl) {
     PairArgs pa;
     pa.indptr = pl.indptr;
-    pa.cols = pl.cols;
+    pa.rows = pl.indices;
     pa.perm = pl.perm;
     pa.ksorted = pl.ksorted;
     pa.sig2 = pl.sig2;
@@ -1207,6 +1094,11 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa);
     LAUNCH_CHECK();
+    if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table
+        hipLaunchKernelGGL(k_verify_long, dim3(LONG_BLOCKS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey, pl.gcnt,
+                           pl.gslots);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_union, dim3(pl.union_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
@@ -1223,12 +1115,10 @@ int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/) {
     const int n = pl.n;
     if (ev) (void)hipEventRecord(ev[0], st);
-    RowKeyArgs rk;
-    rk.rowkey = pl.rowkey;
-    rk.key.fb = pl.fb;
-    rk.key.gb = pl.gb;
-    const int canon_blocks = min((n + 3) / 4, 256 * 16);
-    const int lds_cap = pl.long_lds_cap;
+    KeyCfg key;
+    key.fb = pl.fb;
+    key.gb = pl.gb;
+    const int sig_blocks = min((n + 3) / 4, 256 * 16);
     CellArgs ca;
     ca.hist3 = pl.hist3;
     ca.start3 = pl.start3;
@@ -1242,11 +1132,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     switch (pl.w1) {
 #define PREP_CASE(W)                                                                                                      \
     case W:                                                                                                               \
-        hipLaunchKernelGGL(k_canon<W>, dim3(canon_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.kcap, rk,        \
-                           pl.parent, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr);                                   \
-        if (pl.kcap > 256)                                                                                                \
-            hipLaunchKernelGGL(k_canon_long<W>, dim3(min(n, 1024)), dim3(256), (size_t)lds_cap * 4, st, pl.indptr,         \
-                               pl.indices, pl.kcap, rk, pl.cols, pl.sigu1, pl.sigu2, pl.longrows, pl.ctr, lds_cap);        \
+        hipLaunchKernelGGL(k_sig<W>, dim3(sig_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.kcap, key,           \
+                           pl.rowkey, pl.parent, pl.sigu1, pl.sigu2, pl.ctr);                                              \
         hipLaunchKernelGGL(k_rowrank, dim3((n + 1023) / 1024), dim3(1024), 0, st, pl.rowkey, n, pl.hist3, pl.rowrank);     \
         hipLaunchKernelGGL(k_cells, dim3((ca.cells + 8191) / 8192), dim3(1024), 0, st, ca);                               \
         hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.start3,          \

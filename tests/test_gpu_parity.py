@@ -177,6 +177,22 @@ def test_hub_and_spokes_dense_cells():
     assert ptr[1] - ptr[0] == 6001  # the root sees itself and its 6000 children
 
 
+def test_very_long_rows_use_the_global_table():
+    """rows of ~5000 tokens: pairs exceed the LDS table of k_verify_long and use the global scratch table"""
+    rng = np.random.default_rng(21)
+    base = rng.choice(200000, size=5000, replace=False).astype(np.int32)
+    rows = [base, np.append(base, 777777).astype(np.int32), np.delete(base, 10), rng.permutation(base),
+            np.append(np.delete(base, [1, 2, 3]), [888888, 888889]).astype(np.int32),
+            rng.choice(200000, size=4000, replace=False).astype(np.int32), np.array([5, 6, 7], np.int32)]
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows)
+    for d in (1, 2, 5):
+        want = orc.cluster_csr(indptr, indices, d, n_threads=4)["labels"]
+        got, _ = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want), d
+
+
 def test_all_identical_rows_clique():
     """every pair is within distance 0: a dense candidate set (queue pressure) must still be exact"""
     n = 3000
