@@ -36,6 +36,19 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FilterOpts(C.Structure):
+    _fields_ = [("var_type", C.c_int32), ("skip_ins", C.c_int32), ("skip_del", C.c_int32),
+                ("trim_start", C.c_int64), ("trim_end", C.c_int64), ("reference_length", C.c_int64)]
+
+
+class PrepInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_unique", C.c_int64), ("nnz", C.c_int64), ("n_invalid", C.c_int64),
+                ("n_vocab", C.c_int32), ("filtered", C.c_int32)]
+
+
+VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
+EUNSUPPORTED = -7
+
 EXPORTS = {
     "bfk_abi_version": (C.c_int, []),
     "bfk_device_count": (C.c_int, []),
@@ -61,6 +74,19 @@ EXPORTS = {
     "bfk_ctx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bfk_ctx_set_edge_capture": (C.c_int, [C.c_void_p, C.c_int32]),
     "bfk_ctx_edges": (C.c_int, [C.c_void_p, C.POINTER(c_i32p), c_i64p]),
+    "bfk_table_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bfk_table_from_buffers": (C.c_int, [C.c_char_p, c_i64p, C.c_char_p, c_i64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "bfk_table_rows": (C.c_int64, [C.c_void_p]),
+    "bfk_table_close": (None, [C.c_void_p]),
+    "bfk_table_prepare": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.POINTER(PrepInfo)]),
+    "bfk_table_group": (c_i32p, [C.c_void_p]),
+    "bfk_table_weight": (c_i32p, [C.c_void_p]),
+    "bfk_table_indptr": (c_i32p, [C.c_void_p]),
+    "bfk_table_indices": (c_i32p, [C.c_void_p]),
+    "bfk_table_invalid": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
+    "bfk_table_feature": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
+    "bfk_table_id": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
+    "bfk_table_write": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i64p]),
 }
 
 
@@ -162,6 +188,129 @@ def labels_from_lists(n_rows: int, lists):
     labels = np.empty(max(n_rows, 1), dtype=np.int32)
     _check(lib.bfk_labels_from_lists(int(n_rows), _p64(off), _p32(flat), len(lists), _p32(labels)))
     return labels[:n_rows]
+
+
+class Unsupported(Exception):
+    """the native reader declined the input (BFK_EUNSUPPORTED): use the pandas path"""
+
+
+class Table:
+    """bfk_table_*: native reader / filter + collapse + CSR / writer around the GPU path (include/bfk.h)."""
+
+    def __init__(self, handle):
+        self.lib = load()
+        self.h = handle
+        self.info = None
+
+    @classmethod
+    def open(cls, path, sep: str, id_col: str, feature_col: str):
+        lib = load()
+        h = C.c_void_p()
+        sepb = sep.encode()
+        rc = lib.bfk_table_open(str(path).encode(), sepb, len(sepb), id_col.encode(), feature_col.encode(), C.byref(h))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        return cls(h)
+
+    @classmethod
+    def from_lists(cls, ids, features):
+        """table from Python strings (tests, API callers); non-ASCII content raises Unsupported"""
+        lib = load()
+
+        def pack(strs):
+            try:
+                rows = [s.encode("ascii") for s in strs]
+            except UnicodeEncodeError as e:
+                raise Unsupported(str(e))
+            off = np.zeros(len(rows) + 1, dtype=np.int64)
+            if rows:
+                np.cumsum(np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows)), out=off[1:])
+            return b"".join(rows), off
+
+        ib, io = pack(ids)
+        fb, fo = pack(features)
+        h = C.c_void_p()
+        rc = lib.bfk_table_from_buffers(ib, _p64(io), fb, _p64(fo), len(io) - 1, C.byref(h))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            self.lib.bfk_table_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.lib.bfk_table_rows(self.h))
+
+    def prepare(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length):
+        opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
+                          int(reference_length))
+        info = PrepInfo()
+        sepb = sep2.encode()
+        rc = self.lib.bfk_table_prepare(self.h, sepb, len(sepb), C.byref(opts), C.byref(info))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        if rc == -1 and len(sepb) == 0:
+            raise ValueError("empty separator")
+        _check(rc)
+        self.info = info
+        return info
+
+    def _view(self, fn, n):
+        p = fn(self.h)
+        return np.ctypeslib.as_array(p, shape=(max(int(n), 1),))[: int(n)]
+
+    @property
+    def group(self):
+        return self._view(self.lib.bfk_table_group, self.info.n_rows)
+
+    @property
+    def weight(self):
+        return self._view(self.lib.bfk_table_weight, self.info.n_unique)
+
+    @property
+    def indptr(self):
+        return self._view(self.lib.bfk_table_indptr, self.info.n_unique + 1)
+
+    @property
+    def indices(self):
+        return self._view(self.lib.bfk_table_indices, self.info.nnz)
+
+    def _str(self, fn, i, owned):
+        p, n = C.c_void_p(), C.c_int64()
+        _check(fn(self.h, int(i), C.byref(p), C.byref(n)))
+        s = C.string_at(p, n.value).decode("ascii")
+        if owned:
+            self.lib.bfk_free(p)
+        return s
+
+    def invalid(self, i):
+        return self._str(self.lib.bfk_table_invalid, i, False)
+
+    def feature(self, u):
+        return self._str(self.lib.bfk_table_feature, u, True)
+
+    def id(self, r):
+        return self._str(self.lib.bfk_table_id, r, False)
+
+    def write(self, path, cluster_of_unique) -> int:
+        c = np.ascontiguousarray(cluster_of_unique, dtype=np.int32)
+        if len(c) != self.info.n_unique:
+            raise ValueError("one cluster number per unique row expected")
+        if len(c) == 0:
+            c = np.zeros(1, np.int32)
+        n = C.c_int64()
+        _check(self.lib.bfk_table_write(self.h, str(path).encode(), _p32(c), C.byref(n)))
+        return int(n.value)
 
 
 class Context:

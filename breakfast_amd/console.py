@@ -7,7 +7,7 @@ import pathlib
 import click
 from click.core import ParameterSource
 
-from . import __version__, breakfast
+from . import __version__
 
 _DNA = ("covsonar_dna", "nextclade_dna")
 
@@ -67,6 +67,16 @@ def main(input_file, outdir, input_cache, output_cache, id_col, clust_col, var_t
     ):
         print(f"  {label} = {value}")
     os.environ["OMP_NUM_THREADS"] = str(jobs)
+
+    # native end-to-end path (reader, filter + collapse + CSR, GPU clustering, writer: fastpath.py); it declines
+    # inputs that need pandas' CSV dialect handling, the reference's exceptions, or the cache
+    if os.environ.get("BFK_NO_FASTPATH") != "1":
+        from . import fastpath
+
+        if fastpath.run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+                        reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache):
+            return
+    from . import breakfast  # pandas-based mirror of the reference's functions
 
     meta = breakfast.read_input(input_file, sep, id_col, clust_col)
     meta["feature"] = breakfast.filter_features(meta["feature"], sep2, var_type, skip_ins, skip_del, trim_start,

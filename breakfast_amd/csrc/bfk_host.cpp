@@ -21,6 +21,7 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+int bfk_fail(int code, const std::string &msg) { return fail(code, msg); }  // for bfk_frontend.cpp
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \

@@ -1,0 +1,65 @@
+"""Native end-to-end path of the CLI (SURVEY.md 8 f1 + f3): reader, filter + collapse + CSR and the
+clusters.tsv writer run in libbfk (bfk_table_*), the clustering on the GPU; pandas is not imported.
+
+Equivalent, byte for byte and print for print, to
+
+    meta = read_input(...); meta["feature"] = filter_features(...); nodups = collapse_duplicates(meta)
+    clustered = cluster(nodups, ...); write_output(clustered, meta, outdir)           (console.py:153-170)
+
+for every input the native reader accepts; it declines (returns False, nothing printed or written) whenever
+the result could depend on pandas' CSV dialect handling or a reference exception is due (duplicate ids,
+missing columns ...), and when a cache is involved (the cache file stores pandas objects).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def cluster_ids(labels, weight, min_cluster_size):
+    """breakfast.py:329-339 on canonical labels: a component counts the ORIGINAL sequences of its rows;
+    -> (cluster number per unique row, 0 = none; number of clusters)"""
+    uniq, inv = np.unique(labels, return_inverse=True)
+    size = np.bincount(inv, weights=weight, minlength=len(uniq))
+    keep = size >= min_cluster_size
+    new_id = np.cumsum(keep) * keep
+    return new_id[inv].astype(np.int32), int(keep.sum())
+
+
+def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+        reference_length, max_dist, min_cluster_size, outdir, input_cache=None, output_cache=None) -> bool:
+    if input_cache is not None or output_cache:
+        return False
+    if var_type not in _lib.VAR_TYPES or len(sep2) == 0:
+        return False
+    try:
+        table = _lib.Table.open(input_file, sep, id_col, clust_col)
+        info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
+    except _lib.Unsupported:
+        return False
+    n, nu = int(info.n_rows), int(info.n_unique)
+    print(f"Number of sequences: {n}")
+    for i in range(int(info.n_invalid)):
+        print(f"Skipping invalid feature: '{table.invalid(i)}'")
+    print(f"Number of duplicates: {n - nu}")
+    print(f"Number of unique sequences: {nu}")
+    if max_dist == 0:
+        print("Skip sparse matrix calculation since max-dist = 0")
+        labels = np.arange(nu, dtype=np.int32)
+    else:
+        if info.nnz == 0:
+            # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
+            raise ValueError("unable to infer matrix dimensions")
+        print("Imported cached results are not available. "
+              "Distance matrix of complete dataset will be calculated.")
+        labels, _ = _lib.cluster_csr(table.indptr, table.indices, max_dist)
+        print("Create graph and recover connected components")
+        print("Save clusters")
+    cid, n_clusters = cluster_ids(labels, table.weight, min_cluster_size)
+    print(f"Number of clusters found: {n_clusters}")
+    outdir.mkdir(parents=True, exist_ok=True)
+    table.write(outdir / "clusters.tsv", cid)
+    table.close()
+    return True

@@ -36,6 +36,8 @@ extern "C" {
 #define BFK_EHIP -4      /* HIP runtime error during the call (message has the hipError string) */
 #define BFK_EOVERFLOW -5 /* an internal device buffer overflowed and could not be recovered */
 #define BFK_ESTATE -6    /* call order violated (e.g. cluster before a CSR was bound) */
+#define BFK_EUNSUPPORTED -7 /* bfk_table_*: the input needs the general (pandas) reader; nothing was done */
+#define BFK_EIO -8       /* file could not be read / written */
 
 typedef struct bfk_ctx bfk_ctx;
 
@@ -139,6 +141,72 @@ int bfk_ctx_device_free(bfk_ctx *ctx, void *d_ptr);
 /* edges of the last bfk_ctx_cluster run with edge capture enabled: (i<j) int32 pairs, library-allocated */
 int bfk_ctx_set_edge_capture(bfk_ctx *ctx, int32_t enable);
 int bfk_ctx_edges(bfk_ctx *ctx, int32_t **edges_out, int64_t *n_edges_out);
+
+
+/* ---------------------------------------------------------------------------------------------------
+ * Text front end and writer: the host stages either side of the GPU path, native.
+ * A bfk_table holds the id and feature column of an input file (or of caller buffers) as byte ranges.
+ *   bfk_table_open        replaces read_input            src/breakfast/breakfast.py:16-29
+ *   bfk_table_prepare     replaces filter_features       :116-190
+ *                                + collapse_duplicates   :72-79
+ *                                + sparse_feature_matrix :193-215  (same CSR as bfk_build_csr on the unique rows)
+ *   bfk_table_write       replaces write_output          :32-69
+ * The reader is deliberately strict: anything whose meaning depends on pandas' CSV dialect handling
+ * (quotes, CR, NUL or non-ASCII bytes, ragged rows, NA-valued or duplicate ids, duplicate / missing
+ * column names, multi-byte separators, no data rows) returns BFK_EUNSUPPORTED and the caller uses the
+ * reference's own pandas reader, which also raises the reference's exceptions.  For every input it accepts,
+ * the result is byte-identical to that path (tests/test_frontend.py).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct bfk_table bfk_table;
+
+#define BFK_VAR_COVSONAR_DNA 0
+#define BFK_VAR_COVSONAR_AA 1
+#define BFK_VAR_NEXTCLADE_DNA 2
+#define BFK_VAR_NEXTCLADE_AA 3
+#define BFK_VAR_RAW 4
+
+typedef struct bfk_filter_opts {
+    int32_t var_type;                                /* BFK_VAR_* (--var-type, breakfast.py:131-160) */
+    int32_t skip_ins, skip_del;                      /* --skip-ins / --skip-del */
+    int64_t trim_start, trim_end, reference_length;  /* --trim-start / --trim-end / --reference-length */
+} bfk_filter_opts;
+
+typedef struct bfk_prep_info {
+    int64_t n_rows;     /* input sequences */
+    int64_t n_unique;   /* distinct filtered feature strings (rows of the CSR), first-appearance order */
+    int64_t nnz;        /* CSR entries */
+    int64_t n_invalid;  /* token occurrences that matched no pattern ("Skipping invalid feature") */
+    int32_t n_vocab;    /* distinct kept tokens */
+    int32_t filtered;   /* 0: nothing to filter, features were taken verbatim (breakfast.py:128-129) */
+} bfk_prep_info;
+
+/* read `path`, locate the two columns by header name (read_input's usecols) */
+int bfk_table_open(const char *path, const char *sep, int64_t sep_len, const char *id_col, const char *feature_col,
+                   bfk_table **out);
+/* same table from caller memory: ids / features are concatenated byte strings with N+1 offsets each
+ * (copied).  No dialect checks apply except: no NUL, CR, LF or non-ASCII bytes.                       */
+int bfk_table_from_buffers(const char *id_buf, const int64_t *id_off, const char *feat_buf, const int64_t *feat_off,
+                           int64_t n_rows, bfk_table **out);
+int64_t bfk_table_rows(const bfk_table *t);
+void bfk_table_close(bfk_table *t);
+
+/* filter + collapse + vocabulary/CSR in one pass over the feature bytes */
+int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, bfk_prep_info *info_out);
+/* views into the table, valid until the next prepare / close */
+const int32_t *bfk_table_group(const bfk_table *t);    /* [n_rows]  unique-row index of every input row */
+const int32_t *bfk_table_weight(const bfk_table *t);   /* [n_unique] input rows per unique row (len of the id tuple) */
+const int32_t *bfk_table_indptr(const bfk_table *t);   /* [n_unique + 1] */
+const int32_t *bfk_table_indices(const bfk_table *t);  /* [nnz] */
+/* i-th invalid token occurrence, in the order the reference prints them */
+int bfk_table_invalid(const bfk_table *t, int64_t i, const char **tok_out, int64_t *len_out);
+/* filtered feature string of unique row u (sep2-joined kept tokens): library-allocated, bfk_free */
+int bfk_table_feature(const bfk_table *t, int64_t u, char **str_out, int64_t *len_out);
+/* id of input row r (view) */
+int bfk_table_id(const bfk_table *t, int64_t r, const char **id_out, int64_t *len_out);
+
+/* write `path` = "id\tcluster_id" per input row in input order; cluster_of_unique[u] = any positive cluster
+ * number or 0 for none; numbers are re-assigned 1.. by first appearance in input order (:51-60).       */
+int bfk_table_write(const bfk_table *t, const char *path, const int32_t *cluster_of_unique, int64_t *n_clusters_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,244 @@
+"""CPU: the native front end / writer (bfk_table_*, SURVEY.md 8 f1 + f3) against the pandas-based mirror of the
+reference's functions (breakfast_amd.breakfast, itself pinned to the reference by tests/test_shell.py and the
+golden vectors).  No GPU: only --max-dist 0 reaches the clustering step here."""
+
+import io
+import re
+from contextlib import redirect_stdout
+
+import click.testing
+import numpy as np
+import pandas as pd
+import pytest
+from conftest import GOLD, load_stage, stage_names
+
+from breakfast_amd import _lib, breakfast, console, fastpath, synth
+
+FIX = GOLD / "ref_fixtures"
+OPTS = [  # (skip_ins, skip_del, trim_start, trim_end, reference_length)
+    (True, True, 264, 228, 29903), (False, False, 0, 0, 29903), (True, False, 0, 0, 1000), (False, True, 100, 0, 1000),
+    (False, False, 0, 100, 1000), (True, True, 0, 0, 0),
+]
+
+
+def mirror(ids, features, sep2, var_type, opts):
+    """the pandas path: filter -> collapse -> CSR; -> (group, weight, indptr, indices, ufeatures, stdout)"""
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        meta = pd.DataFrame({"id": ids, "feature": features})
+        meta["feature"] = breakfast.filter_features(meta["feature"], sep2, var_type, *opts)
+        nod = breakfast.collapse_duplicates(meta)
+    ufeat = nod["feature"].tolist()
+    where = {f: i for i, f in enumerate(ufeat)}
+    group = np.array([where[f] for f in meta["feature"]], dtype=np.int32)
+    weight = np.array([len(t) for t in nod["id"]], dtype=np.int32)
+    indptr, indices, nv = _lib.build_csr(ufeat, sep2)
+    return group, weight, indptr, indices, ufeat, buf.getvalue(), meta, nod
+
+
+def check_against_mirror(ids, features, sep2, var_type, opts):
+    t = _lib.Table.from_lists(ids, features)
+    info = t.prepare(sep2, var_type, *opts)
+    group, weight, indptr, indices, ufeat, out, meta, nod = mirror(ids, features, sep2, var_type, opts)
+    assert info.n_rows == len(ids) and info.n_unique == len(ufeat)
+    np.testing.assert_array_equal(t.group, group)
+    np.testing.assert_array_equal(t.weight, weight)
+    np.testing.assert_array_equal(t.indptr, indptr)
+    np.testing.assert_array_equal(t.indices, indices)
+    assert [t.feature(u) for u in range(info.n_unique)] == ufeat
+    printed = [m for m in re.findall(r"Skipping invalid feature: '(.*)'", out)]
+    assert [t.invalid(i) for i in range(info.n_invalid)] == printed
+    return t, meta, nod
+
+
+# ---- token grammar fuzz: the hand-written matchers vs the reference's regular expressions ----------------
+def _fuzz_tokens(rng, n):
+    pieces = ["A", "C", "T", "Z", "a", "z", "0", "1", "9", "27", "00300", "123456789012345678901", ":", "-", "*", "del",
+              "del:", "ORF1a", "S", "N", "AB", ".", "_", "x:"]
+    toks = []
+    for _ in range(n):
+        k = int(rng.integers(0, 6))
+        toks.append("".join(pieces[int(rng.integers(0, len(pieces)))] for _ in range(k)))
+    # well-formed examples of every class
+    toks += ["C241T", "A23403G", "G5343TT", "del:11288:9", "del:1:", "del::1", "S:N501Y", "ORF1a:del:12:7", "N:A34AK",
+             "S:V70-", "S:Q493*", "22204:GAGCCAGAA", "21765-21770", "28271", "1-", "-1", "S:", ":N501Y", "C0T", "C264T",
+             "C265T", "C29674T", "C29675T", "C772T", "C771T", "A1000000000000000000000T", "A0000000000000000000300T"]
+    return toks
+
+
+@pytest.mark.parametrize("var_type", ["covsonar_dna", "covsonar_aa", "nextclade_dna", "nextclade_aa", "raw"])
+@pytest.mark.parametrize("opts", OPTS)
+def test_classifier_fuzz_vs_regex_mirror(var_type, opts):
+    rng = np.random.default_rng(hash((var_type, opts)) % (2**32))
+    toks = _fuzz_tokens(rng, 1500)
+    feats = []
+    for _ in range(300):
+        k = int(rng.integers(0, 8))
+        feats.append(" ".join(toks[int(rng.integers(0, len(toks)))] for _ in range(k)))
+    feats += ["", " ", "  ", "C241T  A23403G", " C241T", "C241T "]
+    ids = [f"s{i}" for i in range(len(feats))]
+    check_against_mirror(ids, feats, " ", var_type, opts)
+
+
+@pytest.mark.parametrize("sep2", [" ", ",", "::", "ab"])
+def test_token_separators(sep2):
+    rng = np.random.default_rng(7)
+    toks = ["C241T", "A23403G", "G5343TT", "del:11288:9", "x", ""]
+    feats = [sep2.join(toks[int(rng.integers(0, len(toks)))] for _ in range(int(rng.integers(0, 6)))) for _ in range(200)]
+    ids = [f"s{i}" for i in range(len(feats))]
+    check_against_mirror(ids, feats, sep2, "covsonar_dna", (True, False, 0, 0, 29903))
+    check_against_mirror(ids, feats, sep2, "raw", (False, False, 0, 0, 29903))
+
+
+@pytest.mark.parametrize("name", stage_names())
+def test_stage_vectors(name):
+    """golden stage vectors made by the reference: filtered unique features and their CSR"""
+    g = load_stage(name)
+    ids = [f"s{i}" for i in range(len(g["ufeatures"]))]
+    t = _lib.Table.from_lists(ids, g["ufeatures"])
+    info = t.prepare(g["sep"], "raw", False, False, 0, 0, 0)
+    assert info.n_unique == len(ids)
+    np.testing.assert_array_equal(t.indptr, g["indptr"])
+    np.testing.assert_array_equal(t.indices, g["indices"])
+
+
+def test_synthetic_with_indels_and_duplicates():
+    feats = synth.generate_profiles(3000, seed=11, p_del=0.05, p_ins=0.02)
+    feats += feats[:50]  # exact duplicates
+    ids = [f"q{i}" for i in range(len(feats))]
+    for opts in OPTS[:3]:
+        check_against_mirror(ids, feats, " ", "covsonar_dna", opts)
+
+
+# ---- reader ---------------------------------------------------------------------------------------------
+def _both_readers(path, sep="\t", id_col="id", feat="f"):
+    with redirect_stdout(io.StringIO()):
+        meta = breakfast.read_input(path, sep, id_col, feat)
+    t = _lib.Table.open(path, sep, id_col, feat)
+    info = t.prepare(" ", "raw", False, False, 0, 0, 0)
+    assert [t.id(r) for r in range(len(t))] == meta["id"].tolist()
+    got = [t.feature(int(u)) for u in t.group]
+    assert got == meta["feature"].tolist()
+    return t, meta, info
+
+
+@pytest.mark.parametrize("text,sep", [
+    ("id\tf\na\tX Y\nb\tX\n", "\t"),
+    ("id\tf\na\tX Y\n\nb\t\n", "\t"),           # blank line, empty feature
+    ("\n\nid\tf\na\tb\n", "\t"),                # leading blank lines
+    ("id\tf\na\tb", "\t"),                      # no trailing newline
+    ("x\tf\ty\tid\n1\tNA\t2\ta\n1\tnull\t2\tb\n3\tN/A\t4\tc\n5\tq\t6\td\n", "\t"),  # NA features, other columns
+    ("f,id\nX Y,a\nX,b b\n", ","),              # other separator, swapped columns
+    ("id\tf\n a \t X \n", "\t"),                # spaces are data
+    ("id\tf\r\na\tX\r\n\r\nb\tY Z\r\n", "\t"),   # CRLF file (the reference's fixtures are)
+    ("id\tf\r\na\tX\r", "\t"),                 # CR at end of file
+])
+def test_reader_accepts_and_matches_pandas(text, sep, tmp_path):
+    p = tmp_path / "in.tsv"
+    p.write_text(text)
+    _both_readers(p, sep)
+
+
+@pytest.mark.parametrize("text", [
+    'id\tf\n"a"\tX\n',                # quotes
+    "id\tf\na\rb\tX\n",               # lone CR
+    "id\tf\na\tX\tz\nb\tq\n",         # long row
+    "id\tf\na\tX\nb\n",               # short row
+    "id\tf\nNA\tX\n",                 # NA id
+    "id\tf\na\tX\na\tY\n",            # duplicate ids
+    "id\tg\na\tX\n",                  # missing column
+    "id\tf\tf\na\tX\tY\n",            # duplicate column names
+    "id\tf\n",                        # no rows
+    "",                               # empty
+    "id\tf\na\tXé\n",            # non-ASCII
+    "id\tf\n   \nc\td\n",             # whitespace-only line
+])
+def test_reader_declines(text, tmp_path):
+    p = tmp_path / "in.tsv"
+    p.write_text(text)
+    with pytest.raises(_lib.Unsupported):
+        _lib.Table.open(p, "\t", "id", "f")
+
+
+@pytest.mark.parametrize("fixture,idc,fc", [("testfile.tsv", "accession", "dna_profile"),
+                                            ("testfile_nextclade.tsv", "seqName", "substitutions")])
+def test_reader_on_reference_fixtures(fixture, idc, fc):
+    path = FIX / fixture
+    if not path.exists():
+        pytest.skip("fixture not captured")
+    hdr = path.read_text().split("\n")[0].split("\t")
+    if idc not in hdr or fc not in hdr:
+        pytest.skip("columns differ")
+    _both_readers(path, "\t", idc, fc)
+
+
+# ---- writer ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sep", ["\t", ","])
+def test_writer_matches_pandas_writer(sep, tmp_path):
+    rng = np.random.default_rng(3)
+    n = 500
+    feats = [" ".join(f"T{int(x)}" for x in rng.integers(0, 30, size=int(rng.integers(0, 4)))) for _ in range(n)]
+    ids = [f"id {i}" if i % 7 else f"i\td{i}" for i in range(n)] if sep == "," else [f"id {i}" for i in range(n)]
+    p = tmp_path / "in.txt"
+    p.write_text(f"id{sep}f\n" + "".join(f"{i}{sep}{f}\n" for i, f in zip(ids, feats)))
+    t, meta, info = _both_readers(p, sep)
+    with redirect_stdout(io.StringIO()):
+        nod = breakfast.collapse_duplicates(meta)
+    assert len(nod) == info.n_unique
+    cid = rng.integers(0, 40, size=info.n_unique).astype(np.int32)  # 0 = none, arbitrary numbering otherwise
+    col = pd.array(cid, dtype="Int64")
+    col[cid == 0] = pd.NA
+    nod["cluster_id"] = col.astype(object)
+    breakfast.write_output(nod, meta, tmp_path / "a")
+    k = t.write(tmp_path / "b.tsv", cid)
+    assert (tmp_path / "b.tsv").read_bytes() == (tmp_path / "a" / "clusters.tsv").read_bytes()
+    assert k == len(set(cid[cid != 0].tolist()))
+
+
+# ---- the whole CLI at --max-dist 0 (no GPU involved): fast path == pandas path == reference ----------------
+@pytest.mark.parametrize("scenario", ["dist0", "nextclade_dist0"])
+def test_cli_fastpath_dist0(scenario, cli_runs, tmp_path, monkeypatch):
+    monkeypatch.chdir(FIX)
+    run = cli_runs[scenario]
+    taken = []
+    real = fastpath.run
+    monkeypatch.setattr(fastpath, "run", lambda *a, **k: taken.append(real(*a, **k)) or taken[-1])
+    res_fast = click.testing.CliRunner().invoke(console.main, run["args"] + ["--outdir", str(tmp_path / "f")])
+    assert res_fast.exit_code == 0, res_fast.output
+    assert taken == [True]
+    monkeypatch.setenv("BFK_NO_FASTPATH", "1")
+    res_slow = click.testing.CliRunner().invoke(console.main, run["args"] + ["--outdir", str(tmp_path / "s")])
+    assert res_slow.exit_code == 0
+    assert (tmp_path / "f" / "clusters.tsv").read_text() == run["clusters_tsv"]
+    assert (tmp_path / "s" / "clusters.tsv").read_text() == run["clusters_tsv"]
+    strip = lambda s: s.replace(str(tmp_path / "f"), "").replace(str(tmp_path / "s"), "")
+    assert strip(res_fast.output) == strip(res_slow.output)  # same prints, same order
+
+
+def test_cli_fastpath_synthetic_dist0_with_invalid_tokens(tmp_path, monkeypatch):
+    rows = synth.generate_profiles(2000, seed=5, p_del=0.05, p_ins=0.02)
+    rows[10] += " bogus!"
+    rows[11] = ""
+    rows += rows[:20]
+    p = tmp_path / "in.tsv"
+    p.write_text("accession\tdna_profile\tx\n" + "".join(f"s{i}\t{r}\t1\n" for i, r in enumerate(rows)))
+    args = ["--input-file", str(p), "--max-dist", "0"]
+    r1 = click.testing.CliRunner().invoke(console.main, args + ["--outdir", str(tmp_path / "f")])
+    monkeypatch.setenv("BFK_NO_FASTPATH", "1")
+    r2 = click.testing.CliRunner().invoke(console.main, args + ["--outdir", str(tmp_path / "s")])
+    assert r1.exit_code == 0 and r2.exit_code == 0, (r1.output, r2.output)
+    assert (tmp_path / "f" / "clusters.tsv").read_bytes() == (tmp_path / "s" / "clusters.tsv").read_bytes()
+    strip = lambda s: s.replace(str(tmp_path / "f"), "").replace(str(tmp_path / "s"), "")
+    assert strip(r1.output) == strip(r2.output)
+    assert "Skipping invalid feature: 'bogus!'" in r1.output
+
+
+def test_cli_fastpath_declines_cache_and_dialects(tmp_path):
+    p = tmp_path / "in.tsv"
+    p.write_text('accession\tdna_profile\n"a"\tC300T\n')
+    ok = fastpath.run(p, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 0, 2,
+                      tmp_path / "o")
+    assert ok is False and not (tmp_path / "o").exists()
+    p.write_text("accession\tdna_profile\na\tC300T\n")
+    assert fastpath.run(p, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 0, 2,
+                        tmp_path / "o", None, tmp_path / "cache.pkl") is False

@@ -13,7 +13,7 @@ import pandas as pd
 import pytest
 from conftest import GOLD, load_stage, stage_names
 
-from breakfast_amd import _lib, breakfast, console
+from breakfast_amd import fastpath, _lib, breakfast, console
 from breakfast_amd.synth import generate_profiles
 from oracle import ref_port as orc
 
@@ -89,12 +89,20 @@ def test_cluster_kats(kats, tmp_path):
 
 @pytest.mark.parametrize("scenario", ["dist0", "dist1", "dist1_noskipdel", "raw_defaults", "raw_explicit",
                                       "nextclade_dist0", "nextclade_dist1", "dist2_mcs3", "dist1_mcs3_noskip"])
-def test_cli_matches_reference_bytes(scenario, cli_runs, tmp_path, monkeypatch):
-    """the reference's own CLI scenarios (tests/test_breakfast.py) — byte-identical clusters.tsv"""
+@pytest.mark.parametrize("path", ["native", "pandas"])
+def test_cli_matches_reference_bytes(scenario, path, cli_runs, tmp_path, monkeypatch):
+    """the reference's own CLI scenarios (tests/test_breakfast.py) — byte-identical clusters.tsv, through the
+    native front end / writer (fastpath.py) and through the pandas mirror of the reference's functions"""
     monkeypatch.chdir(FIX)
     run = cli_runs[scenario]
+    taken = []
+    real = fastpath.run
+    monkeypatch.setattr(fastpath, "run", lambda *a, **k: taken.append(real(*a, **k)) or taken[-1])
+    if path == "pandas":
+        monkeypatch.setenv("BFK_NO_FASTPATH", "1")
     res = click.testing.CliRunner().invoke(console.main, run["args"] + ["--outdir", str(tmp_path)])
     assert res.exit_code == 0, res.output
+    assert taken == ([True] if path == "native" else [])
     data = (tmp_path / "clusters.tsv").read_bytes()
     assert data.decode() == run["clusters_tsv"]
     assert hashlib.sha256(data).hexdigest() == run["sha256"]
@@ -240,9 +248,12 @@ def _cli_sha(n, tmp_path, extra=()):
     return hashlib.sha256(inp.read_bytes()).hexdigest(), hashlib.sha256((tmp_path / "clusters.tsv").read_bytes()).hexdigest()
 
 
+@pytest.mark.parametrize("path", ["native", "pandas"])
 @pytest.mark.parametrize("key", ["syn2000_d1", "syn10000_d1", "syn100000_d1"])
-def test_clusters_tsv_sha256_at_baseline_sizes(key, tmp_path):
+def test_clusters_tsv_sha256_at_baseline_sizes(key, path, tmp_path, monkeypatch):
     """configs[1] (10k) and configs[2] (100k): the whole CLI, digest recorded from the reference"""
+    if path == "pandas":
+        monkeypatch.setenv("BFK_NO_FASTPATH", "1")
     want = json.loads((GOLD / "sha256.json").read_text())[key]
     h_in, h_out = _cli_sha(want["n"], tmp_path)
     assert h_in == want["input_sha256"]

@@ -18,15 +18,15 @@ export TMPDIR=/tmp
 python3 "$root/bench.py" "$@" > "$root/profiles/${tag}_bench.json"
 echo "[profile] bench line written"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- \
     python3 "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline "$@" > "$root/profiles/${tag}_bench_under_rocprof.json"
 echo "[profile] kernel trace done"
 
 i=0
-for pmc in "FETCH_SIZE WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
-           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_INSTS_VALU" \
+           "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
     i=$((i + 1))
-    rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -o p -- \
+    timeout -k 10 180 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -o p -- \
         python3 "$root/bench.py" --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null
     echo "[profile] pmc pass $i done"
 done
