@@ -71,3 +71,11 @@ def test_build_csr_edge_cases():
     big = " ".join(f"T{i}" for i in range(200000))  # forces hash-table growth
     indptr, indices, nv = _lib.build_csr([big, big], " ")
     assert nv == 200000 and np.array_equal(indices[:200000], np.arange(200000)) and indptr[-1] == 400000
+
+
+def test_library_embeds_a_gfx950_code_object():
+    """the build must carry device code for MI355X (a host-only link would load fine and fail at first launch)"""
+    data = _lib.LIB_PATH.read_bytes()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data  # the offload bundle entry of the embedded code object
+    assert b"amdgcn-amd-amdhsa--gfx906" not in data  # hipcc's default when --offload-arch got lost
+    assert b"k_prefilter" in data
