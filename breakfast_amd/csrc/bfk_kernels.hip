@@ -1,9 +1,9 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
 // Pipeline (one stream, no host round trip and no memset between kernels):
-//   k_canon      one wave per row: sort key (k, f, g), bitonic sort of the token ids in registers (DPP /
-//                permlane exchanges), repeat ranks, two XOR-parity signatures; parent[i] = i
-//   k_canon_long block per row for k > 256 (rank sort, row staged in LDS)
+//   k_sig        one wave per row: sort key (k, f, g) and two XOR-parity signatures of the UNSORTED row
+//                (a token repeated an even number of times cancels itself, so the bound holds for multisets
+//                without sorting or ranking repeats); parent[i] = i
 //   k_rowrank    (k,f,g) cell histogram + rank of every row inside its cell (LDS hash aggregation)
 //   k_cells      chained multi-block scan of the cell counters -> start3, tile list (tiles never cross cells);
 //                re-zeroes histogram and counters for the next step
@@ -11,8 +11,8 @@
 //   k_prefilter  the pair kernel: one block per tile; the columns that can be within d of the tile's rows are
 //                a few contiguous ranges (the (k,f,g) band); popcount(sig_row ^ sig_col) <= d is a necessary
 //                condition for |A delta B| <= d; survivors pass a 64-bit second level and are queued
-//   k_verify     one 16-lane group per candidate: longer row staged in LDS, lanes binary-search the shorter
-//                row's elements, ballot/popcount -> exact multiset distance
+//   k_verify     one 16-lane group per candidate: signed counting of both rows' tokens in a hash table in
+//                the group's LDS slice -> exact multiset distance; k_verify_long for pairs > 192 tokens
 //   k_union      one verified edge per lane: lock-free union-find hook
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
 //   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
