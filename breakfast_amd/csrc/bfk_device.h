@@ -9,7 +9,7 @@ constexpr int KEY_BUCKETS = 16;        // f / g buckets per row length in the (k
 constexpr int KEY_MAX_BINS3 = 1 << 24; // cap on (kmax+1)*fb*gb counters (64 MiB); buckets are halved beyond it
 constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
 constexpr int CAND_SHARDS = 512;       // candidate queue shards: returning atomics on one word serialise (~90/us)
-constexpr int PF_WAVES = 2;            // waves per prefilter block = waves sharing one tile
+constexpr int PF_WAVES_MAX = 4;         // most waves per prefilter block (= waves sharing one tile: 2 or 4, Plan::pf_waves)
 constexpr int PF_LDS_QUEUE = 256;      // per-wave LDS coarse hit queue entries (2 KiB per wave)
 constexpr int PF_PAIR_LIST = 256;      // per-wave LDS list of exact pairs inside flush_hits (2 KiB per wave)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
@@ -26,7 +26,7 @@ struct Counters {
     int err_rows;  // set by k_sig (row longer than at bind time); cleared by the host only
     unsigned int n_work;   // tiles
     unsigned int ticket;   // arrival order of the k_cells blocks
-    unsigned int pad_long;
+    unsigned int pad0;
     int overflow;
     unsigned long long pairs_in_band;
     unsigned long long pairs_filtered;
@@ -38,11 +38,11 @@ struct Counters {
 
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
 struct Plan {
-    int n, kcap, d, w1;
+    int n, nnz, kcap, d, w1;
     int rows_per_lane, fb, gb;
     int shard, n_shards;
     int verify_grid, union_grid;
-    int tile_cap, cand_cap_shard, edge_cap, dbg;
+    int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;
     const uint32_t *indices;

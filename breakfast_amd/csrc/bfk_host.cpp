@@ -145,6 +145,7 @@ extern "C" int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_
 // ================================================================================================
 struct bfk_ctx {
     int device = 0;
+    int n_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool profiling = false, edge_capture = false;
     static constexpr int EV_SLOTS = 64;  // ring of per-step event sets: up to 64 steps are averaged per sync
@@ -175,6 +176,7 @@ struct bfk_ctx {
     int64_t rows_cap = 0;
     int4 *d_tiles = nullptr;
     int64_t tile_cap = 0, tile_slots_cap = 0;
+    int64_t last_tiles = 0;  // tile count seen by the last sync on this CSR (sizes the pair kernel's grid)
     int rows_per_lane = 1;
     int *d_rowkey = nullptr, *d_rowrank = nullptr;
     int4 *d_cand = nullptr;
@@ -225,6 +227,7 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
     HIP_TRY(hipSetDevice(device));
     bfk_ctx *c = new bfk_ctx();
     c->device = device;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(BFK_EHIP, "hipStreamCreate failed");
@@ -350,7 +353,7 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         // tiles: one per non-empty cell plus one per full tile of rows
         const int64_t want = std::min<int64_t>(bins3, n) + n / (64 * c->rows_per_lane) + 16;
         if (int rc = dev_realloc(&c->d_tiles, &c->tile_cap, want, 1.0)) return rc;
-        if (int rc = dev_realloc(&c->d_tile_slots, &c->tile_slots_cap, c->tile_cap * PF_WAVES, 1.0)) return rc;
+        if (int rc = dev_realloc(&c->d_tile_slots, &c->tile_slots_cap, c->tile_cap * PF_WAVES_MAX, 1.0)) return rc;
     }
     {
         // 16N candidate slots in all (d=1 needs ~0.7N, a dense d=5 graph ~15N); an overflow is repaired by
@@ -362,6 +365,7 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
 }
 
 static int ctx_after_bind(bfk_ctx *c) {
+    c->last_tiles = 0;  // another CSR: no tile count known yet
     // nnz and the longest row come back once per bind (set-up, not part of a timed step)
     int h[2] = {0, 0};
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16, c->stream));
@@ -431,6 +435,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     Plan pl{};
     pl.n = (int)c->n;
     pl.kcap = c->kcap;
+    pl.nnz = (int)c->nnz;
     pl.d = std::min<int>(max_dist, 1 << 20);
     pl.w1 = c->last_w1;
     pl.rows_per_lane = c->rows_per_lane;
@@ -441,6 +446,13 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.verify_grid = 2048;
     pl.union_grid = 512;
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
+    pl.pf_blocks = c->n_cus * 256;  // upper bound of the pair kernel's grid (it strides over the tile entries)
+    pl.pf_waves = (c->rows_per_lane == 1 && c->n < 400000) ? 4 : 2;
+    if (const char *e = getenv("BFK_PF_WAVES")) pl.pf_waves = atoi(e) == 4 && c->rows_per_lane == 1 ? 4 : 2;
+    // grid of the pair kernel: the tile count of the previous step on this CSR (+12%), or a guess before the
+    // first sync; the kernel strides, so a wrong hint costs balance, never results
+    pl.tile_hint = (int)std::min<int64_t>(pl.tile_cap, c->last_tiles > 0 ? c->last_tiles + c->last_tiles / 8 + 64
+                                                                          : std::max<int64_t>(4096, c->n / 8));
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
     pl.gkey = c->d_gkey;
@@ -453,10 +465,10 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
         static int64_t dbg_cap = 0;
         if (dbg_cap < c->tile_cap) {
             if (dbg_buf) (void)hipFree(dbg_buf);
-            (void)hipMalloc((void **)&dbg_buf, (size_t)c->tile_cap * PF_WAVES * 8 * 8);
+            (void)hipMalloc((void **)&dbg_buf, (size_t)c->tile_cap * PF_WAVES_MAX * 8 * 8);
             dbg_cap = c->tile_cap;
         }
-        (void)hipMemsetAsync(dbg_buf, 0, (size_t)c->tile_cap * PF_WAVES * 8 * 8, c->stream);
+        (void)hipMemsetAsync(dbg_buf, 0, (size_t)c->tile_cap * PF_WAVES_MAX * 8 * 8, c->stream);
         pl.dbg_t = dbg_buf;
     }
     pl.indptr = c->d_indptr;
@@ -569,13 +581,14 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
         if (h.err || h.err_rows) c->need_zero = true;
+        c->last_tiles = (int64_t)h.n_work;
         if (h.err_rows) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
         if (getenv("BFK_DEBUG"))
             fprintf(stderr, "[bfk] k_cells %.1f us, %u tiles\n", (h.dbg[1] - h.dbg[0]) / 100.0, h.n_work);
         if (c->plan.dbg_t) {
-            std::vector<unsigned long long> t((size_t)h.n_work * PF_WAVES * 8);
+            std::vector<unsigned long long> t((size_t)h.n_work * c->plan.pf_waves * 8);
             (void)hipMemcpy(t.data(), c->plan.dbg_t, t.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = fopen("gpurun_out/pf_waves.txt", "w")) {
                 for (size_t i = 0; i < t.size(); i += 8)
@@ -594,11 +607,11 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
         s.pairs_in_band = (int64_t)h.pairs_in_band;
         {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
-            std::vector<int> ts((size_t)h.n_work * PF_WAVES);
+            std::vector<int> ts((size_t)h.n_work * c->plan.pf_waves);
             if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
             int64_t acc = 0;
             for (size_t t = (size_t)c->plan.shard; t < (size_t)h.n_work; t += (size_t)c->plan.n_shards)
-                for (int w = 0; w < PF_WAVES; w++) acc += ts[t * PF_WAVES + w];
+                for (int w = 0; w < c->plan.pf_waves; w++) acc += ts[t * (size_t)c->plan.pf_waves + w];
             s.pairs_filtered = acc;
         }
         s.n_candidates = (int64_t)h.n_cand_total;
@@ -606,6 +619,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.n_retry_slices = retry_slices;
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;
+        c->last_tiles = (int64_t)h.n_work;
         if (c->profiling && c->n_prof_calls > 0) {
             const int used = std::min(c->n_prof_calls, (int)bfk_ctx::EV_SLOTS);
             double acc[5] = {0, 0, 0, 0, 0};

@@ -4,7 +4,7 @@
 //   k_sig        one wave per row: sort key (k, f, g) and two XOR-parity signatures of the UNSORTED row
 //                (a token repeated an even number of times cancels itself, so the bound holds for multisets
 //                without sorting or ranking repeats); parent[i] = i
-//   k_rowrank    (k,f,g) cell histogram + rank of every row inside its cell (LDS hash aggregation)
+//                + (k,f,g) cell histogram and rank of every row inside its cell (LDS hash aggregation per block)
 //   k_cells      chained multi-block scan of the cell counters -> start3, tile list (tiles never cross cells);
 //                re-zeroes histogram and counters for the next step
 //   k_place      counting-sort scatter of row ids / lengths / signatures into (k,f,g) order
@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace bfk {
 
@@ -74,12 +75,7 @@ __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
     return false;
 }
 
-// signature hashes of a token id (two independent multiplicative hashes) and the verify table's slot hash
-__device__ __forceinline__ uint32_t hash1(uint32_t x) { return x * 0x9E3779B1u; }
-__device__ __forceinline__ uint32_t hash2(uint32_t x) {
-    uint32_t h = (x ^ (x >> 15)) * 0x85EBCA6Bu;
-    return h ^ (h >> 13);
-}
+// slot hash of the verify tables
 __device__ __forceinline__ uint32_t hash3(uint32_t x) {
     uint32_t h = x * 0xC2B2AE35u;
     return h ^ (h >> 15);
@@ -112,8 +108,6 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 // (sigma ~ 3 at k = 40), so each of the two keys cuts the pair slots by ~2.5x at d = 1.
 // f and g are stored as buckets: v - (k/2 - nb/2) clamped to [0, nb) (a window centred on the mean).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fbit(uint32_t x) { return (x * 0xB5297A4Du) >> 31; }
-__device__ __forceinline__ uint32_t gbit(uint32_t x) { return ((x ^ (x >> 11)) * 0x2C1B3C6Du) >> 31; }
 
 struct KeyCfg {
     int fb, gb;  // buckets per row length for f and g (powers of two; 1 = key unused)
@@ -133,62 +127,47 @@ __device__ __forceinline__ void key_band(int rlo, int rhi, int k, int kp, int am
     *hi = (rhi >= nb - 1) ? nb - 1 : min(rhi + bmax - s, nb - 1);
 }
 
-// block-wide exclusive scan (1024 threads, one 64-bit value each); tmp: 40 x u64 of LDS
-__device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long *tmp,
-                                                                   unsigned long long *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long inc = v;
-    for (int s = 1; s < 64; s <<= 1) {
-        unsigned long long y = __shfl_up(inc, s);
-        if (lane >= s) inc += y;
-    }
-    if (lane == 63) tmp[wave] = inc;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long w = lane < 16 ? tmp[lane] : 0ull;
-        unsigned long long winc = w;
-        for (int s = 1; s < 16; s <<= 1) {
-            unsigned long long y = __shfl_up(winc, s);
-            if (lane >= s) winc += y;
-        }
-        if (lane < 16) tmp[16 + lane] = winc - w;
-        if (lane == 15) tmp[32] = winc;
-    }
-    __syncthreads();
-    unsigned long long res = inc - v + tmp[16 + wave];
-    *total = tmp[32];
-    __syncthreads();
-    return res;
-}
-
 struct CellArgs {
     int *hist3;     // (kcap+1)*fb*gb cell counters, re-zeroed here
     int *start3;    // cells + 1: first sorted position of every (k,f,g) cell
     int4 *tiles;    // {first sorted row, rows, cell key, 0}: tiles never cross a cell boundary
-    unsigned long long *chain;  // one hand-off word per block of k_cells (zero between steps)
+    unsigned long long *chain;  // one status word per block of k_cells (zeroed again by k_place)
     Counters *ctr;
-    int n, cells, tr, tile_cap;
+    int n, cells, tr_shift, tile_cap;
 };
+
+// inclusive prefix sum over the 64 lanes (DPP row prefix, then row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);  // row_bcast15 into rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);  // row_bcast31 into rows 2,3
+    return x;
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_cells: exclusive scan of the (k,f,g) cell counters -> start3, and the tile list: every non-empty cell is
-// cut into tiles of at most TR rows (a tile never crosses a cell boundary, so its band is as tight as the
-// sort key allows).  One block per 8192 cells; a block's base offset comes from its predecessor through a
-// chained hand-off (one 64-bit word per block: value + 1, published with an agent-scope release, polled with
-// relaxed loads then acquired — all blocks are co-resident: <= cells/8192 <= 2048).  The histogram and the
-// per-step counters are re-zeroed, so a step needs no memset; the hand-off words are re-zeroed by the last
-// block for the next step.
+// cut into tiles of at most TR = 2^tr_shift rows (a tile never crosses a cell boundary, so its band is as
+// tight as the sort key allows).  One block per 8192 cells.  Cross-block offsets by decoupled look-back on
+// aggregates: a block publishes (tiles, rows) of its own cells as soon as its local scan is done (one 64-bit
+// status word, value + 1, agent-scope release) and then sums the words of ALL its predecessors, 64 per wave
+// step, so the chain costs one round trip instead of one per block.  Grids larger than the guaranteed
+// co-residency take their logical index from an arrival ticket (a block then only ever waits for blocks that
+// have started).  The histogram and the per-step counters are re-zeroed here, the status words by k_place.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
-    __shared__ unsigned long long tmp[40];
     __shared__ int s_cnt[8192];
-    __shared__ unsigned long long s_base;
-    __shared__ int s_bid;
-    // logical block order = order of arrival (HIP promises nothing about dispatch order): a block only ever
-    // waits for a block that has already started
-    if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.ctr->ticket, 1u);
-    __syncthreads();
-    const int bid = s_bid;
+    __shared__ int s_wr[16], s_wt[16];  // per-wave totals: rows, tiles
+    __shared__ int s_base_r, s_base_t, s_bid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    if (gridDim.x > 256) {  // beyond 256 blocks co-residency is not certain: order by arrival
+        if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.ctr->ticket, 1u);
+        __syncthreads();
+        bid = s_bid;
+    }
 #define PLAN_STAMP(i) if (threadIdx.x == 0) a.ctr->dbg[i] = wall_clock64();
     if (bid == 0) PLAN_STAMP(0)
     if (bid == 0) {
@@ -196,6 +175,7 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         if (threadIdx.x == 64) {
             a.ctr->err = 0;
             a.ctr->overflow = 0;
+
             a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
         }
     }
@@ -211,53 +191,77 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         s_cnt[j * 1024 + threadIdx.x] = v;
     }
     __syncthreads();
+    const int trm = (1 << a.tr_shift) - 1;
     int cnt[8];
-    unsigned long long sum = 0;  // tiles in the high word, rows in the low word
+    int rows = 0, tl = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         cnt[j] = s_cnt[threadIdx.x * 8 + j];
-        sum += ((unsigned long long)((cnt[j] + a.tr - 1) / a.tr) << 32) | (unsigned)cnt[j];
+        rows += cnt[j];
+        tl += (cnt[j] + trm) >> a.tr_shift;
     }
-    unsigned long long tot;
-    const unsigned long long ex = block_excl_scan_1024(sum, tmp, &tot);
-    if (threadIdx.x == 0) {
-        unsigned long long before = 0;
-        if (bid > 0) {
-            unsigned long long v;
-            int spins = 0;
-            while ((v = __hip_atomic_load(&a.chain[bid - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) {  // never expected: bound the spin
-                    atomicOr(&a.ctr->err, ERR_WORKCAP);
-                    break;
+    const int inc_r = wave_incl_scan_add(rows), inc_t = wave_incl_scan_add(tl);
+    if (lane == 63) {
+        s_wr[wave] = inc_r;
+        s_wt[wave] = inc_t;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // totals of the 16 waves -> exclusive wave offsets; lane 15 holds the block totals
+        const int wr = lane < 16 ? s_wr[lane] : 0, wt = lane < 16 ? s_wt[lane] : 0;
+        const int ir = wave_incl_scan_add(wr), it = wave_incl_scan_add(wt);
+        if (lane < 16) {
+            s_wr[lane] = ir - wr;
+            s_wt[lane] = it - wt;
+        }
+        const int tot_r = __builtin_amdgcn_readlane(ir, 15), tot_t = __builtin_amdgcn_readlane(it, 15);
+        if (lane == 0)
+            __hip_atomic_store(&a.chain[bid], ((((unsigned long long)(unsigned)tot_t) << 32) | (unsigned)tot_r) + 1ull,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // look-back: sum the aggregates of all predecessors
+        int before_r = 0, before_t = 0;
+        for (int w0 = bid - 1; w0 >= 0; w0 -= 64) {
+            const int p = w0 - lane;
+            unsigned long long v = 1ull;
+            if (p >= 0) {
+                int spins = 0;
+                while ((v = __hip_atomic_load(&a.chain[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) {  // never expected: bound the spin
+                        atomicOr(&a.ctr->err, ERR_WORKCAP);
+                        v = 1ull;
+                        break;
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            before = v - 1ull;
-            a.chain[bid - 1] = 0ull;  // consumed: clean for the next step
+            v -= 1ull;
+            before_r += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(unsigned)(v & 0xffffffffull)), 63);
+            before_t += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(v >> 32)), 63);
         }
-        s_base = before;
-        if (bid + 1 < (int)gridDim.x) {
-            __hip_atomic_store(&a.chain[bid], before + tot + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            a.ctr->ticket = 0;  // every block has taken its ticket: clean for the next step
-            a.start3[a.cells] = a.n;
-            const unsigned nt = (unsigned)((before + tot) >> 32);
-            if (nt > (unsigned)a.tile_cap) atomicOr(&a.ctr->err, ERR_WORKCAP);
-            a.ctr->n_work = min(nt, (unsigned)a.tile_cap);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) {
+            s_base_r = before_r;
+            s_base_t = before_t;
+            if (bid + 1 == (int)gridDim.x) {
+                a.ctr->ticket = 0;  // every block has taken its ticket: clean for the next step
+                a.start3[a.cells] = a.n;
+                const unsigned nt = (unsigned)(before_t + tot_t);
+                if (nt > (unsigned)a.tile_cap) atomicOr(&a.ctr->err, ERR_WORKCAP);
+                a.ctr->n_work = min(nt, (unsigned)a.tile_cap);
+            }
         }
     }
     __syncthreads();
-    unsigned long long run = s_base + ex;
+    int pos = s_base_r + s_wr[wave] + inc_r - rows;
+    int t = s_base_t + s_wt[wave] + inc_t - tl;
+    const int tr = 1 << a.tr_shift;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int c = base + threadIdx.x * 8 + j;
-        const int pos = (int)(unsigned)(run & 0xffffffffull);
-        int t = (int)(run >> 32);
         if (c < a.cells) a.start3[c] = pos;
-        for (int r0 = 0; r0 < cnt[j]; r0 += a.tr, t++)
-            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(a.tr, cnt[j] - r0), c, 0);
-        run += ((unsigned long long)((cnt[j] + a.tr - 1) / a.tr) << 32) | (unsigned)cnt[j];
+        for (int r0 = 0; r0 < cnt[j]; r0 += tr, t++)
+            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, cnt[j] - r0), c, 0);
+        pos += cnt[j];
     }
     if (bid + 1 == (int)gridDim.x) PLAN_STAMP(1)
 }
@@ -281,116 +285,139 @@ __device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t x) {
     return x;
 }
 
-template <int W1>
-__global__ __launch_bounds__(256) void k_sig(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
-                                              int kcap, KeyCfg key, int *__restrict__ rowkey, int *__restrict__ parent,
-                                              uint32_t *__restrict__ sigu1, uint32_t *__restrict__ sigu2, Counters *ctr) {
-    constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * 4;
-    int i = blockIdx.x * 4 + wave;
-    if (i >= n) return;
-    // software pipeline over this wave's rows: extents are fetched two rows ahead, the first 64 tokens one
-    // row ahead, so a row costs no exposed round trip
-    int b = indptr[i], e = indptr[i + 1];
-    int nb = 0, ne = 0;
-    if (i + nwaves < n) {
-        nb = indptr[i + nwaves];
-        ne = indptr[i + nwaves + 1];
-    }
-    uint32_t xfirst = (lane < e - b) ? indices[b + lane] : 0u;
-    while (true) {
-        const int inext = i + nwaves, inext2 = i + 2 * nwaves;
-        int nb2 = 0, ne2 = 0;
-        if (inext2 < n) {
-            nb2 = indptr[inext2];
-            ne2 = indptr[inext2 + 1];
-        }
-        const uint32_t xnext = (inext < n && lane < ne - nb) ? indices[nb + lane] : 0u;
-        int k = e - b;
-        if (k < 0 || k > kcap) {
-            if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
-            k = k < 0 ? 0 : kcap;
-        }
-        uint32_t s1[W1], s2[SIG2_WORDS];
-#pragma unroll
-        for (int w = 0; w < W1; w++) s1[w] = 0;
-#pragma unroll
-        for (int w = 0; w < SIG2_WORDS; w++) s2[w] = 0;
-        int f = 0, g = 0;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int j = j0 + lane;
-            const bool valid = j < k;
-            const uint32_t x = j0 == 0 ? xfirst : (valid ? indices[b + j] : 0u);
-            f += __popcll(__builtin_amdgcn_ballot_w64(valid && fbit(x) != 0u));
-            g += __popcll(__builtin_amdgcn_ballot_w64(valid && gbit(x) != 0u));
-            if (valid) {
-                const uint32_t b1 = hash1(x) >> (32 - LOG1);
-                const uint32_t b2 = hash2(x) >> (32 - 6);
-#pragma unroll
-                for (int w = 0; w < W1; w++)
-                    if ((int)(b1 >> 5) == w) s1[w] ^= 1u << (b1 & 31);
-#pragma unroll
-                for (int w = 0; w < SIG2_WORDS; w++)
-                    if ((int)(b2 >> 5) == w) s2[w] ^= 1u << (b2 & 31);
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W1; w++) s1[w] = wave_xor_to_lane63(s1[w]);
-#pragma unroll
-        for (int w = 0; w < SIG2_WORDS; w++) s2[w] = wave_xor_to_lane63(s2[w]);
-        if (lane == 63) {  // row order; k_place moves them to the sorted position
-#pragma unroll
-            for (int w = 0; w < W1; w++) sigu1[(size_t)i * W1 + w] = s1[w];
-#pragma unroll
-            for (int w = 0; w < SIG2_WORDS; w++) sigu2[(size_t)i * SIG2_WORDS + w] = s2[w];
-        }
-        if (lane == 0) {
-            rowkey[i] = key3_of(key, k, f, g);
-            parent[i] = i;
-        }
-        if (inext >= n) break;
-        i = inext;
-        b = nb;
-        e = ne;
-        nb = nb2;
-        ne = ne2;
-        xfirst = xnext;
-    }
-}
+// token hashes of k_sig: two 24x24-bit multiplies (v_mul_u32_u24 issues at full rate; v_mul_lo_u32 is a
+// quarter-rate instruction).  Only the low 24 bits of a token id enter: ids that differ above bit 23 merely
+// share signature bits, which weakens the filter and never the result.
+__device__ __forceinline__ uint32_t sig_h1(uint32_t x) { return __umul24(x, 0x9E3779u); }
+__device__ __forceinline__ uint32_t sig_h2(uint32_t h1) { return __umul24(h1 >> 8, 0x85EBCBu); }
 
-// k_rowrank: histogram of the (k,f,g) cells and every row's rank inside its cell.  Hub cells (e.g. the
-// children of a common ancestor: thousands of rows in 4 cells) make per-row returning atomics serialise, so a
-// 1024-row block first aggregates its rows in an LDS hash table keyed by cell (open addressing, 2048 slots)
-// and then reserves one range per distinct cell with a single global atomic.
-__global__ __launch_bounds__(1024) void k_rowrank(const int *__restrict__ rowkey, int n, int *hist3,
-                                                   int *__restrict__ rowrank) {
-    constexpr int SLOTS = 2048;
-    __shared__ int s_key[SLOTS], s_cnt[SLOTS];
-    for (int t = threadIdx.x; t < SLOTS; t += 1024) {
-        s_key[t] = -1;
-        s_cnt[t] = 0;
+// One block = 16 waves = up to 256 consecutive rows (rpw rows per wave).  Phase 1: one wave per row, 64 tokens
+// per step, rows software-pipelined (all extents of the wave's rows in one load, the next row's first 64
+// tokens in flight while this row is reduced).  Phase 2 (one thread per row): key3, the coalesced row-order
+// stores, and the histogram of the (k,f,g) cells + every row's rank inside its cell.  Hub cells (the children
+// of a common ancestor: thousands of rows in 4 cells) make per-row returning atomics on one word serialise
+// (~90/us), so the block first aggregates its rows in an LDS hash table keyed by cell and reserves one range
+// per distinct cell with a single global atomic.
+template <int W1>
+__global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
+                                               int nnz, int kcap, int rpw, KeyCfg key, int *__restrict__ rowkey,
+                                               int *__restrict__ parent, uint32_t *__restrict__ sigu1,
+                                               uint32_t *__restrict__ sigu2, int *hist3, int *__restrict__ rowrank,
+                                               Counters *ctr) {
+    constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
+    constexpr int MAXR = 256, SLOTS = 512;
+    __shared__ int s_k[MAXR], s_f[MAXR], s_g[MAXR];
+    __shared__ uint32_t s_s1[MAXR * W1], s_s2[MAXR * SIG2_WORDS];
+    __shared__ int t_key[SLOTS], t_cnt[SLOTS];
+    static_assert(SIG2_WORDS == 2, "second-level signature = 64 bits");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < SLOTS) {
+        t_key[threadIdx.x] = -1;
+        t_cnt[threadIdx.x] = 0;
+    }
+    const int rows_per_block = rpw * 16;
+    const int base = blockIdx.x * rows_per_block;
+    const int r0 = base + wave * rpw;
+    const int nr = max(0, min(rpw, n - r0));
+    if (nr > 0 && nnz > 0) {
+        // extents of all rows of this wave: lane l holds indptr[r0 + l]
+        const int ext = indptr[min(r0 + min(lane, rpw), n)];
+        int b = __builtin_amdgcn_readlane(ext, 0), e = __builtin_amdgcn_readlane(ext, 1);
+        // token prefetches are unconditional loads from a clamped address (a lane past the row reads a
+        // neighbour's token and contributes nothing): a predicated load would sit in a branch and force a
+        // full vmcnt(0) wait in front of every row
+        uint32_t xfirst = indices[min(b + lane, nnz - 1)];
+        for (int t = 0; t < nr; t++) {
+            const int nb = e;
+            const int ne = (t + 1 < nr) ? __builtin_amdgcn_readlane(ext, t + 2) : e;
+            const uint32_t xnext = indices[min(nb + lane, nnz - 1)];
+            int k = e - b;
+            if (k < 0 || k > kcap) {
+                if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
+                k = k < 0 ? 0 : kcap;
+            }
+            uint32_t s1[W1], s2all = 0, s2hi = 0;
+#pragma unroll
+            for (int w = 0; w < W1; w++) s1[w] = 0;
+            int f = 0, g = 0;
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int rem = k - j0;  // wave-uniform
+                const uint32_t x = j0 == 0 ? xfirst : ((lane < rem) ? indices[b + j0 + lane] : 0u);
+                const unsigned long long vm = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                const uint32_t one = lane < rem ? 1u : 0u;  // lanes past the row contribute no bit
+                const uint32_t h1 = sig_h1(x), h2 = sig_h2(h1);
+                f += __popcll(__builtin_amdgcn_ballot_w64((int)h2 < 0) & vm);
+                g += __popcll(__builtin_amdgcn_ballot_w64((h2 & 0x40000000u) != 0u) & vm);
+                const uint32_t b1 = h1 >> (32 - LOG1);
+                const uint32_t bit1 = one << (b1 & 31);
+                if (W1 == 1) {
+                    s1[0] ^= bit1;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < W1; w++) s1[w] ^= ((int)(b1 >> 5) == w) ? bit1 : 0u;
+                }
+                const uint32_t bit2 = one << ((h2 >> 24) & 31);               // index bits 24..28
+                const uint32_t hi = (uint32_t)((int)(h2 << 2) >> 31) & bit2;  // bit 29 selects the word
+                s2all ^= bit2;
+                s2hi ^= hi;
+            }
+#pragma unroll
+            for (int w = 0; w < W1; w++) s1[w] = wave_xor_to_lane63(s1[w]);
+            s2all = wave_xor_to_lane63(s2all);
+            s2hi = wave_xor_to_lane63(s2hi);
+            const int lr = wave * rpw + t;
+            if (lane == 63) {
+#pragma unroll
+                for (int w = 0; w < W1; w++) s_s1[lr * W1 + w] = s1[w];
+                s_s2[lr * 2] = s2all ^ s2hi;
+                s_s2[lr * 2 + 1] = s2hi;
+            }
+            if (lane == 0) {
+                s_k[lr] = k;
+                s_f[lr] = f;
+                s_g[lr] = g;
+            }
+            b = nb;
+            e = ne;
+            xfirst = xnext;
+        }
+    } else if (nr > 0 && lane == 0) {  // no tokens at all: every row is empty
+        for (int t = 0; t < nr; t++) {
+            const int lr = wave * rpw + t;
+            s_k[lr] = s_f[lr] = s_g[lr] = 0;
+            for (int w = 0; w < W1; w++) s_s1[lr * W1 + w] = 0;
+            s_s2[lr * 2] = s_s2[lr * 2 + 1] = 0;
+        }
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int slot = 0, lr = 0;
-    if (i < n) {
-        const int key = rowkey[i];
-        slot = (int)(((uint32_t)key * 0x9E3779B1u) >> 21);  // 11 bits
+    // phase 2: one thread per row of the block
+    const int tr = threadIdx.x;
+    const int i = base + tr;  // row (wave, t) was parked at wave * rpw + t = its offset in the block
+    const bool live = tr < rows_per_block && i < n;
+    int slot = 0, lrk = 0;
+    if (live) {
+        const int key3 = key3_of(key, s_k[tr], s_f[tr], s_g[tr]);
+        rowkey[i] = key3;
+        parent[i] = i;
+#pragma unroll
+        for (int w = 0; w < W1; w++) sigu1[(size_t)i * W1 + w] = s_s1[tr * W1 + w];
+        *reinterpret_cast<uint2 *>(sigu2 + (size_t)i * 2) = make_uint2(s_s2[tr * 2], s_s2[tr * 2 + 1]);
+        slot = (int)(((uint32_t)key3 * 0x9E3779B1u) >> 23);  // 9 bits
         while (true) {
-            const int old = atomicCAS(&s_key[slot], -1, key);
-            if (old == -1 || old == key) break;
+            const int old = atomicCAS(&t_key[slot], -1, key3);
+            if (old == -1 || old == key3) break;
             slot = (slot + 1) & (SLOTS - 1);
         }
-        lr = atomicAdd(&s_cnt[slot], 1);
+        lrk = atomicAdd(&t_cnt[slot], 1);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < SLOTS; t += 1024) {
-        const int c = s_cnt[t];
-        if (c) s_cnt[t] = atomicAdd(&hist3[s_key[t]], c);  // base of this block's range in the cell
+    if (tr < SLOTS) {
+        const int c = t_cnt[tr];
+        if (c) t_cnt[tr] = atomicAdd(&hist3[t_key[tr]], c);  // base of this block's range in the cell
     }
     __syncthreads();
-    if (i < n) rowrank[i] = s_cnt[slot] + lr;
+    if (live) rowrank[i] = t_cnt[slot] + lrk;
 }
 
 // k_place: counting-sort scatter.  Row i goes to sorted position start3[key] + rank; its length and its two
@@ -401,8 +428,9 @@ __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, i
                                                 const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
                                                 const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
                                                 int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
-                                                uint32_t *__restrict__ sig2) {
+                                                uint32_t *__restrict__ sig2, unsigned long long *chain, int n_chain) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_chain) chain[i] = 0ull;  // k_cells' status words: clean for the next step
     if (i >= n) return;
     const int p = start3[rowkey[i]] + rowrank[i];
     const int k = indptr[i + 1] - indptr[i];
@@ -490,17 +518,6 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
     return c;
 }
 
-// inclusive prefix sum over the 64 lanes (DPP row prefix, then row broadcasts)
-__device__ __forceinline__ int wave_incl_scan_add(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true);  // row_bcast15 into rows 1,3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true);  // row_bcast31 into rows 2,3
-    return x;
-}
-
 // Flush of the prefilter's COARSE hit queue.  An entry says "column q is within d (first-level signature) of
 // at least one of the SB rows starting at sorted row pb".  Finding which rows is done here, one entry per
 // lane (64 entries per instruction), instead of in the scan loop where a hit costs the whole wave a serial
@@ -562,7 +579,7 @@ struct BandArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_prefilter<W, R>: the all-pairs kernel.  One BLOCK (PF_WAVES waves) per tile.  A tile is up to 64*R sorted
+// k_prefilter<W, R, PW>: the all-pairs kernel.  One BLOCK of PW waves per tile.  A tile is up to 64*R sorted
 // rows of ONE (k,f,g) cell.  The columns that can be within d of those rows are, per column length
 // k' = k + delta and per column f' bucket, one contiguous range of the sorted order (the g band): every
 // lane turns one (delta, f') candidate into a column range with two start3 look-ups (all in flight at once).
@@ -571,38 +588,51 @@ struct BandArgs {
 // column range is several cells wide, so this keeps the lanes full where rows-in-lanes would leave 60% idle.
 // The tile's row signatures are parked once in the wave's LDS slice and re-read as wave-uniform
 // ds_read_b128 broadcasts (v_xor with VGPR operands runs at full rate; an SGPR operand halves it on gfx950).
-//   per pair slot: W x (v_xor + v_bcnt) and half a v_min3, minima kept per group of 4 rows;
-//   one v_cmp + ballot per sub-batch of 16 row-dwords; only hit groups are revisited, one compare per
-//   (row, column) with a wave-level branch around the push; hits go to the wave's LDS queue (slot from the
-//   ballot prefix, fill level in a wave-uniform register), filtered and flushed by flush_hits.
-// The waves of a block take the tile's chunks round-robin (a hub row with thousands of neighbours would
-// otherwise serialise on one wave); waves never synchronise; the hardware block scheduler balances tiles.
+//   per pair slot: W x (v_xor + v_bcnt) + v_min; one v_cmp + ballot per sub-batch of 16 row-dwords;
+//   a hit queues the COARSE fact (sub-batch, column) in the wave's LDS queue (slot from the ballot prefix, fill
+//   level in a wave-uniform register); flush_hits works out the rows lane-parallel and applies the second level.
+// The PW waves of a block take the tile's chunks round-robin and never synchronise.  PW = 4 (one wave per SIMD
+// of the CU) for small inputs, where every block is resident at once and the kernel time is set by the SIMD
+// that happened to draw the heaviest waves (measured with BFK_PF_DEBUG=4 / tools/pf_timeline.py at 100k rows:
+// 54 chunks on the busiest SIMD against a mean of 30 with PW = 2); PW = 2 for large inputs, which are
+// throughput-bound and only pay for the extra per-wave set-up.  Tried and dropped for the same imbalance:
+// ticket counters for dynamic work distribution (returning atomics on one word serialise at ~90/us; spread
+// over 32 counters they still sit in the in-order vmcnt queue in front of the next item's loads), capping
+// residency so the hardware dispatcher balances (no gain: the heavy tiles are all dispatched in the first
+// round), s_setprio for waves with long scans (no effect), issuing the tiles of big cells several times with
+// the columns divided (helps at 100k, costs 40% at 1M rows).
 // ------------------------------------------------------------------------------------------------
-template <int W, int R>
-__global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
+template <int W, int R, int PW>
+__global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
                                                               int shard0, int nshards, int t_begin, int t_end,
                                                               PairArgs pa) {
     constexpr int CC = 64;              // columns per chunk: one per lane
     constexpr int SB = 16 / W;          // rows per sub-batch (16 dwords): the hit-detection granularity
     constexpr int QCAP = PF_LDS_QUEUE;  // per-wave coarse hit queue entries
     constexpr int TROWS = 64 * R;       // most rows a tile can have
-    __shared__ int2 sbuf[PF_WAVES][QCAP];
-    __shared__ int2 spairs[PF_WAVES][PF_PAIR_LIST];  // flush_hits: exact pairs of a batch of 64 coarse entries
-    __shared__ __attribute__((aligned(16))) uint32_t srow[PF_WAVES][TROWS * W];
+    __shared__ int2 sbuf[PW][QCAP];
+    __shared__ int2 spairs[PW][PF_PAIR_LIST];  // flush_hits: exact pairs of a batch of 64 coarse entries
+    __shared__ __attribute__((aligned(16))) uint32_t srow[PW][TROWS * W];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave index is wave-uniform, so that everything derived from it
     // (tile descriptor, candidate ranges) stays in SGPRs / scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t d = (uint32_t)pa.d;
     const int n_tiles = min((int)pa.ctr->n_work, t_end);
-    const int t = t_begin + (int)blockIdx.x * nshards + shard0;
-    if (t >= n_tiles) return;
+    const int qshard = (blockIdx.x * PW + wave) & (CAND_SHARDS - 1);
+    int2 *myq = sbuf[wave];
+    uint32_t *myrow = srow[wave];
+    // Work items = (tile, wave slot) pairs of this shard, taken by WAVES, grid-stride: the host launches one
+    // block per expected tile (the count lives on the device; any grid is correct).
+    const int n_entries = n_tiles > t_begin + shard0 ? (n_tiles - t_begin - shard0 + nshards - 1) / nshards : 0;
+    const int n_items = n_entries * PW;
+    int item = (int)blockIdx.x * PW + wave;
+    while (item < n_items) {
+    const int t = t_begin + (item / PW) * nshards + shard0;
+    const int wslot = item & (PW - 1);
     const unsigned long long t_start = ba.dbg_t ? wall_clock64() : 0ull;
     unsigned long long t_rng = 0, t_main = 0;
     int dbg_hits = 0, dbg_chunks = 0;
-    const int qshard = (blockIdx.x * PF_WAVES + wave) & (CAND_SHARDS - 1);
-    int2 *myq = sbuf[wave];
-    uint32_t *myrow = srow[wave];
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
     const int4 tile = ba.tiles[t];
     const int row0 = tile.x, nrows = tile.y;
@@ -652,10 +682,10 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
         long long slots = 0;
         const int nc = min(64, ncand - cbase);
         // Chunk iterator over all ranges of this round: this wave takes the chunks whose running number is
-        // == wave (mod PF_WAVES).  Everything here is wave-uniform (SGPRs).
+        // == wslot (mod PW).  Everything here is wave-uniform (SGPRs).
         int it_ci = -1, it_q0 = 0, it_ctrue = 0, it_cend = 0, chunk_no = 0;
         auto advance = [&]() {
-            it_q0 += PF_WAVES * CC;
+            it_q0 += PW * CC;
             while (it_ci < nc && it_q0 >= it_cend) {
                 it_ci++;
                 if (it_ci >= nc) break;
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
                 }
                 const int cal = it_ctrue & ~(CC - 1);
                 const int nch = (it_cend - cal + CC - 1) / CC;
-                it_q0 = cal + ((wave - chunk_no) & (PF_WAVES - 1)) * CC;
+                it_q0 = cal + ((wslot - chunk_no) & (PW - 1)) * CC;
                 chunk_no += nch;
             }
         };
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
         }
 #undef PF_FETCH
         if (lane == 0) {  // plain store (no statistics atomics); later rounds (d >= 64) accumulate
-            int *ts = &ba.tile_slots[t * PF_WAVES + wave];
+            int *ts = &ba.tile_slots[t * PW + wslot];
             *ts = (int)min((long long)(cbase ? *ts : 0) + slots, (long long)0x7fffffff);
         }
     }
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
     if (ba.dbg_t) t_main = wall_clock64();
     if (qn > 0 && !(pa.dbg & 1)) flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
     if (ba.dbg_t && lane == 0) {
-        unsigned long long *o = ba.dbg_t + (size_t)(t * PF_WAVES + wave) * 8;
+        unsigned long long *o = ba.dbg_t + (size_t)(t * PW + wslot) * 8;
         o[0] = t_start;
         o[1] = t_rng;
         o[2] = t_main;
@@ -759,8 +789,13 @@ __global__ __launch_bounds__(PF_WAVES * 64) void k_prefilter(const uint32_t *__r
         o[4] = (unsigned long long)dbg_chunks;
         o[5] = (unsigned long long)dbg_hits;
         o[6] = (unsigned long long)nrows;
-        o[7] = (unsigned long long)tile.z;
+        // where the wave ran: HW_ID (hwreg 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (hwreg 20)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        o[7] = (unsigned long long)(unsigned)tile.z | ((unsigned long long)(hw & 0xFFFFu) << 32) |
+               ((unsigned long long)(xcc & 0xFu) << 48);
     }
+    item += (int)gridDim.x * PW;
+    }  // items
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1071,25 +1106,32 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.key.gb = pl.gb;
     ba.kcap = pl.kcap;
     ba.d = pl.d;
-    // one wave per tile of this shard; the tile count lives on the device, so the grid covers the host-side
-    // bound and surplus waves exit at once
-    const long long span = (long long)std::min(t_end, pl.tile_cap) - t_begin;
-    const int grid = std::max(1, (int)((span + pl.n_shards - 1) / pl.n_shards));  // one block per tile
-#define PF_CASE(W, R)                                                                                              \
-    hipLaunchKernelGGL((k_prefilter<W, R>), dim3(grid), dim3(PF_WAVES * 64), 0, st, pl.sig1, ba, n, pl.shard, pl.n_shards, \
+    // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
+    // previous step's count (tile_hint) and the kernel strides over whatever the count turns out to be
+    const long long span = (long long)std::min(std::min(t_end, pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
+    const int grid = std::max(1, (int)std::min<long long>((span + pl.n_shards - 1) / pl.n_shards, pl.pf_blocks));
+
+#define PF_CASE_PW(W, R, PW)                                                                                       \
+    hipLaunchKernelGGL((k_prefilter<W, R, PW>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard, pl.n_shards,  \
                        t_begin, t_end, pa)
+#define PF_CASE(W, R) PF_CASE_PW(W, R, 2)
+    // waves per tile: 2, or 4 for 64-row tiles of small inputs (there a tile is ~8 chunks and the kernel time is
+    // set by the busiest SIMD: four waves on four SIMDs per tile even that out; large inputs are throughput-
+    // bound and the extra per-wave set-up only costs)
+    const bool pw4 = pl.pf_waves == 4;
     switch (pl.w1 * 10 + pl.rows_per_lane) {
-        case 11: PF_CASE(1, 1); break;
+        case 11: if (pw4) PF_CASE_PW(1, 1, 4); else PF_CASE(1, 1); break;
         case 12: PF_CASE(1, 2); break;
         case 14: PF_CASE(1, 4); break;
-        case 21: PF_CASE(2, 1); break;
+        case 21: if (pw4) PF_CASE_PW(2, 1, 4); else PF_CASE(2, 1); break;
         case 22: PF_CASE(2, 2); break;
         case 24: PF_CASE(2, 4); break;
-        case 41: PF_CASE(4, 1); break;
+        case 41: if (pw4) PF_CASE_PW(4, 1, 4); else PF_CASE(4, 1); break;
         case 42: PF_CASE(4, 2); break;
         default: PF_CASE(4, 4); break;
     }
 #undef PF_CASE
+#undef PF_CASE_PW
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa);
@@ -1118,7 +1160,10 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     KeyCfg key;
     key.fb = pl.fb;
     key.gb = pl.gb;
-    const int sig_blocks = min((n + 3) / 4, 256 * 16);
+    // rows per wave of k_sig: at most 16, and for small inputs few enough that every CU holds two blocks
+    // (512 blocks x 16 waves co-resident): block-granular imbalance would otherwise cost up to 30%
+    const int rpw = max(1, min(16, (n + 8191) / 8192));
+    const int sig_blocks = (n + rpw * 16 - 1) / (rpw * 16);
     CellArgs ca;
     ca.hist3 = pl.hist3;
     ca.start3 = pl.start3;
@@ -1127,17 +1172,19 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     ca.ctr = pl.ctr;
     ca.n = n;
     ca.cells = (pl.kcap + 1) * pl.fb * pl.gb;
-    ca.tr = 64 * pl.rows_per_lane;
+    ca.tr_shift = 6 + (pl.rows_per_lane == 1 ? 0 : (pl.rows_per_lane == 2 ? 1 : 2));
+    const int cell_blocks = (ca.cells + 8191) / 8192;
     ca.tile_cap = pl.tile_cap;
     switch (pl.w1) {
 #define PREP_CASE(W)                                                                                                      \
     case W:                                                                                                               \
-        hipLaunchKernelGGL(k_sig<W>, dim3(sig_blocks), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.kcap, key,           \
-                           pl.rowkey, pl.parent, pl.sigu1, pl.sigu2, pl.ctr);                                              \
-        hipLaunchKernelGGL(k_rowrank, dim3((n + 1023) / 1024), dim3(1024), 0, st, pl.rowkey, n, pl.hist3, pl.rowrank);     \
-        hipLaunchKernelGGL(k_cells, dim3((ca.cells + 8191) / 8192), dim3(1024), 0, st, ca);                               \
-        hipLaunchKernelGGL(k_place<W>, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap, pl.start3,          \
-                           pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2);              \
+        hipLaunchKernelGGL(k_sig<W>, dim3(sig_blocks), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.kcap, rpw,  \
+                           key,                                                                                           \
+                           pl.rowkey, pl.parent, pl.sigu1, pl.sigu2, pl.hist3, pl.rowrank, pl.ctr);                        \
+        hipLaunchKernelGGL(k_cells, dim3(cell_blocks), dim3(1024), 0, st, ca);                                            \
+        hipLaunchKernelGGL(k_place<W>, dim3((max(n, cell_blocks) + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap,   \
+                           pl.start3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2,    \
+                           pl.chain, cell_blocks);                                                                        \
         break;
         PREP_CASE(1)
         PREP_CASE(2)
