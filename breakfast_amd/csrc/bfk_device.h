@@ -10,6 +10,7 @@ constexpr int KEY_MAX_BINS3 = 1 << 24; // cap on (kmax+1)*fb*gb counters (64 MiB
 constexpr int SIG2_WORDS = 2;          // second-level signature: 64 bits (independent hash)
 constexpr int CAND_SHARDS = 512;       // candidate queue shards: returning atomics on one word serialise (~90/us)
 constexpr int PF_WAVES_MAX = 4;         // most waves per prefilter block (= waves sharing one tile: 2 or 4, Plan::pf_waves)
+constexpr int VERIFY_GRID_MAX = 8192;   // blocks of k_verify (per-block statistics buffer)
 constexpr int PF_LDS_QUEUE = 256;      // per-wave LDS coarse hit queue entries (2 KiB per wave)
 constexpr int PF_PAIR_LIST = 256;      // per-wave LDS list of exact pairs inside flush_hits (2 KiB per wave)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
@@ -41,12 +42,12 @@ struct Plan {
     int n, nnz, kcap, d, w1;
     int rows_per_lane, fb, gb;
     int shard, n_shards;
-    int verify_grid, union_grid;
+    int verify_grid;
     int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;
     const uint32_t *indices;
-    int *hist3, *start3, *rowkey, *rowrank, *tile_slots;
+    int *hist3, *start3, *rowkey, *rowrank, *tile_slots, *blk_stats;
     unsigned long long *chain;
     int *perm, *ksorted, *parent;
     uint32_t *gkey;

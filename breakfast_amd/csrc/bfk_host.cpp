@@ -163,7 +163,7 @@ struct bfk_ctx {
     // workspace
     char *d_head = nullptr;  // Counters | hist[bins]
     int64_t bins_cap = 0;
-    int *d_start3 = nullptr, *d_tile_slots = nullptr;
+    int *d_start3 = nullptr, *d_tile_slots = nullptr, *d_blk_stats = nullptr;
     unsigned long long *d_chain = nullptr;
     int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
     int64_t bins3 = 0;
@@ -233,10 +233,12 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
         return fail(BFK_EHIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess ||
+        hipMalloc((void **)&c->d_blk_stats, (size_t)VERIFY_GRID_MAX * 2 * sizeof(int)) != hipSuccess) {
         delete c;
         return fail(BFK_ENOMEM, "hipMalloc failed");
     }
+    (void)hipMemset(c->d_blk_stats, 0, (size_t)VERIFY_GRID_MAX * 2 * sizeof(int));
     *ctx_out = c;
     return BFK_OK;
 }
@@ -248,7 +250,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_gkey,   c->d_perm,   c->d_sigu1,
                     c->d_ksorted,  c->d_parent,    c->d_gcnt,   c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
                     c->d_rowrank,  c->d_tile_slots, c->d_cand,  c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
-                    c->d_chain};
+                    c->d_chain,    c->d_blk_stats};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -443,8 +445,9 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.gb = c->gb;
     pl.shard = shard;
     pl.n_shards = n_shards;
-    pl.verify_grid = 2048;
-    pl.union_grid = 512;
+    pl.verify_grid = 1536;  // x 16 groups, a multiple of CAND_SHARDS; 6 blocks per CU (measured best of 1024..4096 at 100k rows)
+    if (const char *e = getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, std::max(32, atoi(e) / 32 * 32));
+    pl.blk_stats = c->d_blk_stats;
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
     pl.pf_blocks = c->n_cus * 256;  // upper bound of the pair kernel's grid (it strides over the tile entries)
     pl.pf_waves = (c->rows_per_lane == 1 && c->n < 400000) ? 4 : 2;
@@ -517,6 +520,21 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
     return BFK_OK;
 }
 
+// k_verify leaves its per-block edge / candidate counts in plain stores (no same-word atomics): add them to
+// the counters read back from the device (n_edges already holds the edges of the long-pair kernel)
+static int ctx_pair_stats(bfk_ctx *c, Counters *h) {
+    std::vector<int> v((size_t)2 * c->plan.verify_grid);
+    HIP_TRY(hipMemcpy(v.data(), c->d_blk_stats, v.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long e = 0, k = 0;
+    for (size_t i = 0; i < v.size(); i += 2) {
+        e += (unsigned)v[i];
+        k += (unsigned)v[i + 1];
+    }
+    h->n_edges += e;
+    h->n_cand_total = k;
+    return BFK_OK;
+}
+
 // The candidate queue overflowed (very dense input: far more first-level hits than 32*N): the forest
 // already holds every edge that was verified, the dropped ones are recovered by re-running prefilter +
 // verify over slices of the work list small enough for the queue, halving a slice that still overflows.
@@ -557,6 +575,7 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
             }
             continue;
         }
+        if (int rc = ctx_pair_stats(c, h)) return rc;
         edges_acc += h->n_edges;
         cand_acc += h->n_cand_total;
     }
@@ -598,6 +617,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             }
         }
         int64_t retry_slices = 0;
+        if (!h.overflow)
+            if (int rc = ctx_pair_stats(c, &h)) return rc;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
             // the queue was too small for this input: double it so that the next run fits in one pass

@@ -13,7 +13,7 @@
 //                condition for |A delta B| <= d; survivors pass a 64-bit second level and are queued
 //   k_verify     one 16-lane group per candidate: signed counting of both rows' tokens in a hash table in
 //                the group's LDS slice -> exact multiset distance; k_verify_long for pairs > 192 tokens
-//   k_union      one verified edge per lane: lock-free union-find hook
+//                and lock-free union-find hooks of the verified edges (one edge per lane)
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
 //   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
 //
@@ -456,7 +456,7 @@ struct PairArgs {
     int2 *candk;  // {k_a, k_b}
     int cand_cap_shard;
     int d;
-    int n;
+    int n, nnz;
     int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
     Counters *ctr;
 };
@@ -805,7 +805,8 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
 // row A are inserted with +1 and those of row B with -1, 16 at a time (CAS on the key claims a slot, equal
 // tokens meet in the same slot, ds_add adds the sign); the distance is sum |count| over the table
 // (= sum_t |a_t - b_t|, exact for multisets).  Pairs with more than VERIFY_MAX_TOKENS tokens are left to
-// k_verify_long.  A pair farther apart than d is marked (row a = -1); k_union hooks the rest.
+// k_verify_long.  Edges are hooked into the union-find by the same kernel: lane i of a group keeps the group's
+// i-th edge and all lanes hook theirs together at the end (the find / CAS chains of a wave's edges overlap).
 // ------------------------------------------------------------------------------------------------
 // the shard queues seen as one index space: prefix of min(ncand[s], cap), built once per block in LDS
 // (first wave: 8 consecutive shards per lane, then a wave scan)
@@ -858,71 +859,187 @@ __device__ __forceinline__ void table_add(uint32_t *tkey, int *tcnt, uint32_t ma
     atomicAdd(&tcnt[s], sgn);
 }
 
-__global__ __launch_bounds__(256) void k_verify(PairArgs pa) {
-    __shared__ uint2 tab[16][VERIFY_TABLE];  // {token, signed count}
-    __shared__ int spre[CAND_SHARDS + 1];
-    const int l16 = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;           // 0..15 in the block
-    const int gg = blockIdx.x * 16 + grp, ng = gridDim.x * 16;
-    uint2 *mt = tab[grp];
-    shard_prefix(pa, spre);
-    const int total = spre[CAND_SHARDS];
-    for (int c = gg; c < total; c += ng) {
-        const size_t slot = shard_slot(spre, pa, c);
-        const int4 rec = pa.cand[slot];
-        const int2 kk = pa.candk[slot];
-        const int ka = kk.x, kb = kk.y, kt = ka + kb;
-        if (kt > VERIFY_MAX_TOKENS) continue;  // k_verify_long
-        const uint32_t *A = pa.rows + rec.z, *B = pa.rows + rec.w;
-        // all token loads of the pair are issued first (one round trip, not one per step)
-        constexpr int STEPS = VERIFY_MAX_TOKENS / 16;
-        uint32_t x[STEPS];
-#pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            const int j = s * 16 + l16;
-            x[s] = j < ka ? A[j] : (j < kt ? B[j - ka] : 0u);
+__device__ __forceinline__ void record_edge(const PairArgs &pa, int2 *edges, int edge_cap, int a, int b) {
+    const unsigned long long e = atomicAdd(&pa.ctr->n_edges_cap, 1ull);
+    if (e < (unsigned long long)edge_cap) edges[e] = make_int2(min(a, b), max(a, b));
+}
+
+// all-reduce over the 16 lanes of a DPP row (row_ror:1,2,4,8): every lane gets the result
+__device__ __forceinline__ int row16_allmin(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));
+    return x;
+}
+__device__ __forceinline__ int row16_allsum(int x) {
+    x += __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);
+    return x;
+}
+
+// exact multiset distance of one pair by signed counting in the group's LDS table (the general path); the rows
+// are already in registers: lane l16 holds positions 16 st + l16 of row A (a) and of row B (b0)
+template <int STEPS>
+__device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t (&a)[STEPS], const uint32_t (&b0)[STEPS],
+                                              int ka, int kb) {
+    // table size: power of two >= 2 * tokens (load <= 1/2), capped at VERIFY_TABLE (load <= 3/4)
+    const int kt = ka + kb;
+    uint32_t tsz = 16;
+    while ((int)tsz < 2 * kt && tsz < VERIFY_TABLE) tsz <<= 1;
+    const uint32_t mask = tsz - 1;
+    for (uint32_t t = l16; t < tsz; t += 16) mt[t] = make_uint2(0xFFFFFFFFu, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto add = [&](uint32_t x, int sgn) {
+        uint32_t p = hash3(x) & mask;
+        while (true) {
+            const uint32_t o = atomicCAS(&mt[p].x, 0xFFFFFFFFu, x);
+            if (o == 0xFFFFFFFFu || o == x) break;
+            p = (p + 1) & mask;  // occupied by another token: linear probing
         }
-        // table size: power of two >= 2 * tokens (load <= 1/2), capped at VERIFY_TABLE (load <= 3/4)
-        uint32_t tsz = 16;
-        while ((int)tsz < 2 * kt && tsz < VERIFY_TABLE) tsz <<= 1;
-        const uint32_t mask = tsz - 1;
-        for (uint32_t t = l16; t < tsz; t += 16) mt[t] = make_uint2(0xFFFFFFFFu, 0u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // first probe of every token: the CASes are independent, so they are all in flight together
-        uint32_t sl[STEPS], old[STEPS];
+        atomicAdd(reinterpret_cast<int *>(&mt[p].y), sgn);
+    };
+#pragma unroll 1
+    for (int st = 0; st < STEPS; st++) {
+        const int j = st * 16 + l16;
+        uint32_t xa = a[0], xb = b0[0];  // register arrays are indexed by constants only
 #pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            sl[s] = hash3(x[s]) & mask;
-            old[s] = 0xFFFFFFFFu;
-            if (s * 16 + l16 < kt) old[s] = atomicCAS(&mt[sl[s]].x, 0xFFFFFFFFu, x[s]);
+        for (int q = 1; q < STEPS; q++) {
+            xa = st == q ? a[q] : xa;
+            xb = st == q ? b0[q] : xb;
         }
+        if (j < ka) add(xa, 1);
+        if (j < kb) add(xb, -1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int dist = 0;
+    for (uint32_t t = l16; t < tsz; t += 16) dist += abs((int)mt[t].y);
+    dist = row16_allsum(dist);
+    __builtin_amdgcn_wave_barrier();
+    return dist;
+}
+
+// STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
+// all are left to k_verify_long).
+template <int STEPS>
+__global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap, int *blk_stats) {
+    __shared__ uint2 tab[4][VERIFY_TABLE];  // {token, signed count}: one table per WAVE (the table path is rare)
+    __shared__ unsigned int blk_edges, blk_cands;
+    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;  // 0..15 in the block
+    uint2 *mt = tab[threadIdx.x >> 6];
+    if (threadIdx.x == 0) blk_edges = blk_cands = 0;
+    __syncthreads();
+    // Group u of U (a multiple of CAND_SHARDS) works on queue shard u % CAND_SHARDS, entries j0, j0 + jstep, ..:
+    // the slot is computed, not searched, and the shards fill evenly (the prefilter rotates over them).
+    const int u = blockIdx.x * 16 + grp, U = gridDim.x * 16;
+    const int shard = u & (CAND_SHARDS - 1), j0 = u / CAND_SHARDS, jstep = U / CAND_SHARDS;
+    const int cnt = (int)min(pa.ctr->ncand[shard], (unsigned)pa.cand_cap_shard);
+    const size_t base = (size_t)shard * pa.cand_cap_shard;
+    int my_a = -1, my_b = -1;  // lane i of the group keeps the group's i-th edge; all are hooked together at the end
+    int nkept = 0;
+    if (j0 == 0 && l16 == 0 && cnt) atomicAdd(&blk_cands, (unsigned)cnt);
+    if (j0 < cnt) {
+        // A group has only ~2 candidates (32k groups are resident: 8 waves per SIMD), so latency is hidden by
+        // occupancy, not by a deep pipeline per group: only the next queue record is fetched ahead.
+        const int last = cnt - 1;
+        // lane l16 of the group holds, per step st, position j = 16 st + l16 of row A, of row B, and of row B
+        // shifted by the length difference s = k_b - k_a
+        auto tokens = [&](const int4 &rec, const int2 &kk, uint32_t(&a)[STEPS], uint32_t(&b0)[STEPS], uint32_t(&bs)[STEPS]) {
+            const int sft = kk.y - kk.x;
+            const uint32_t *A = pa.rows + rec.z + l16, *B = pa.rows + rec.w + l16;  // one address per row, then
+            const uint32_t *Bs = B + sft;                                           // constant offsets 64 st
 #pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            const int j = s * 16 + l16;
-            if (j < kt) {
-                uint32_t p = sl[s], o = old[s];
-                while (o != 0xFFFFFFFFu && o != x[s]) {  // occupied by another token: linear probing
-                    p = (p + 1) & mask;
-                    o = atomicCAS(&mt[p].x, 0xFFFFFFFFu, x[s]);
-                }
-                atomicAdd(reinterpret_cast<int *>(&mt[p].y), j < ka ? 1 : -1);
+            for (int st = 0; st < STEPS; st++) {
+                const int j = st * 16 + l16;
+                a[st] = j < kk.x ? A[st * 16] : 0u;
+                b0[st] = j < kk.y ? B[st * 16] : 0u;
+                bs[st] = (uint32_t)(j + sft) < (uint32_t)kk.y ? Bs[st * 16] : 0u;
             }
+        };
+        int4 rec = pa.cand[base + j0];
+        int2 kk = pa.candk[base + j0];
+        int4 rec_n = pa.cand[base + min(j0 + jstep, last)];
+        int2 kk_n = pa.candk[base + min(j0 + jstep, last)];
+        for (int e = j0; e < cnt; e += jstep) {
+            const int e2 = min(e + 2 * jstep, last);
+            const int4 rec_nn = pa.cand[base + e2];
+            const int2 kk_nn = pa.candk[base + e2];
+            uint32_t a[STEPS], b0[STEPS], bs[STEPS];
+            tokens(rec, kk, a, b0, bs);
+            const int ka = kk.x, kb = kk.y, kt = ka + kb;
+            bool is_edge = false;
+            if (kt <= VERIFY_MAX_TOKENS) {  // longer pairs: k_verify_long
+                // Certificate first.  Profiles list their mutations in a fixed order (by genome position), so two
+                // rows within d of each other are almost always the same sequence with a few tokens inserted: with
+                // t = first position where the rows differ and s = k_b - k_a, the pairs (i, i) for i < t and
+                // (i, i + s) for i >= max(t, t - s) with equal tokens are a matching of A into B (no position is
+                // used twice), so distance <= k_a + k_b - 2 * matched holds for ANY two rows, whatever their
+                // order.  If that bound is <= d the pair is an edge; otherwise it is counted exactly below.
+                const int sft = kb - ka, kmin = min(ka, kb);
+                uint32_t e0 = 0, es = 0;
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    const int j = st * 16 + l16;
+                    e0 |= (uint32_t)(j < kmin && a[st] == b0[st]) << st;
+                    es |= (uint32_t)(j < ka && (uint32_t)(j + sft) < (uint32_t)kb && a[st] == bs[st]) << st;
+                }
+                const int fst = __builtin_ctz(~e0);  // first step at which this lane's position differs (>= STEPS: none)
+                const int t = min(row16_allmin(fst * 16 + l16), kmin);
+                const int from = sft < 0 ? t - sft : t;              // first suffix position of row A
+                const int st0 = max(0, (from - l16 + 15) >> 4);        // first step of this lane inside the suffix
+                const int mine = st0 < STEPS ? __popc(es >> st0) : 0;
+                const int matched = t + row16_allsum(mine);
+                int dist = kt - 2 * matched;  // upper bound
+                // not certified: count exactly; the wave's groups that need the table take turns
+                unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
+                while (want != 0ull) {
+                    const int g = (int)(__builtin_ctzll(want) >> 4);
+                    if ((lane >> 4) == g) dist = table_distance<STEPS>(mt, l16, a, b0, ka, kb);
+                    want &= ~(0xFFFFull << (g * 16));
+                }
+                is_edge = dist <= pa.d;
+            }
+            if (is_edge) {  // group-uniform
+                if (l16 == (nkept & 15)) {
+                    my_a = rec.x;
+                    my_b = rec.y;
+                }
+                nkept++;
+                if ((nkept & 15) == 0) {  // every lane holds an edge: hook them now
+                    uf_union(pa.parent, my_a, my_b);
+                    if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
+                    my_a = my_b = -1;
+                }
+            }
+            rec = rec_n;
+            kk = kk_n;
+            rec_n = rec_nn;
+            kk_n = kk_nn;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int dist = 0;
-        for (uint32_t t = l16; t < tsz; t += 16) dist += abs((int)mt[t].y);
-        dist = row16_sum_to_lane15(dist);
-        __builtin_amdgcn_wave_barrier();
-        if (l16 == 15 && dist > pa.d) pa.cand[slot].x = -1;
+    }
+    // one edge per lane: the dependent find / CAS chains of all edges of the wave overlap
+    if (my_a >= 0) {
+        uf_union(pa.parent, my_a, my_b);
+        if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
+    }
+    if (l16 == 0 && nkept) atomicAdd(&blk_edges, (unsigned)nkept);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // plain stores, summed by the host (no same-word global atomics)
+        blk_stats[2 * blockIdx.x] = (int)blk_edges;
+        blk_stats[2 * blockIdx.x + 1] = (int)blk_cands;
     }
 }
 
 // k_verify_long: pairs with more tokens than a group table holds: one block per pair, table in dynamic LDS
 // (up to LONG_TABLE slots) or, beyond that, in the block's slice of a global scratch table.
-__global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey, int *gcnt, unsigned gslots) {
+__global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey, int *gcnt, unsigned gslots, int2 *edges,
+                                                     int edge_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldyn[];
     __shared__ int spre[CAND_SHARDS + 1];
     __shared__ int sdist;
@@ -968,37 +1085,12 @@ __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey
         for (uint32_t t = threadIdx.x; t < tsz; t += 256) dist += abs(__hip_atomic_load(&mc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (dist) atomicAdd(&sdist, dist);
         __syncthreads();
-        if (threadIdx.x == 0 && sdist > pa.d) pa.cand[slot].x = -1;
-        __syncthreads();
-    }
-}
-
-// k_union: one verified edge per lane -> lock-free hook (the dependent find/CAS chains of all edges overlap)
-__global__ __launch_bounds__(256) void k_union(PairArgs pa, int2 *edges, int edge_cap) {
-    const int gt = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
-    unsigned int my_edges = 0;
-    __shared__ int spre[CAND_SHARDS + 1];
-    shard_prefix(pa, spre);
-    const int total = spre[CAND_SHARDS];
-    for (int c = gt; c < total; c += nt) {
-        const int4 rec = pa.cand[shard_slot(spre, pa, c)];
-        if (rec.x < 0) continue;
-        uf_union(pa.parent, rec.x, rec.y);
-        my_edges++;
-        if (edges) {
-            unsigned long long e = atomicAdd(&pa.ctr->n_edges_cap, 1ull);
-            if (e < (unsigned long long)edge_cap) edges[e] = make_int2(min(rec.x, rec.y), max(rec.x, rec.y));
+        if (threadIdx.x == 0 && sdist <= pa.d) {
+            uf_union(pa.parent, rec.x, rec.y);
+            atomicAdd(&pa.ctr->n_edges, 1ull);
+            if (edges) record_edge(pa, edges, edge_cap, rec.x, rec.y);
         }
-    }
-    for (int sft = 32; sft > 0; sft >>= 1) my_edges += __shfl_xor(my_edges, sft);
-    __shared__ unsigned int blk_edges;
-    if (threadIdx.x == 0) blk_edges = 0;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && my_edges) atomicAdd(&blk_edges, my_edges);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (blk_edges) atomicAdd(&pa.ctr->n_edges, (unsigned long long)blk_edges);
-        if (blockIdx.x == 0 && total) atomicAdd(&pa.ctr->n_cand_total, (unsigned long long)total);
+        __syncthreads();
     }
 }
 
@@ -1083,6 +1175,7 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.ksorted = pl.ksorted;
     pa.sig2 = pl.sig2;
     pa.n = pl.n;
+    pa.nnz = pl.nnz;
     pa.dbg = pl.dbg;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
@@ -1101,7 +1194,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.start3 = pl.start3;
     ba.tiles = pl.tiles;
     ba.tile_slots = pl.tile_slots;
-    ba.dbg_t = pl.dbg_t;
+    ba.dbg_t = (pl.dbg & 4) ? pl.dbg_t : nullptr;
     ba.key.fb = pl.fb;
     ba.key.gb = pl.gb;
     ba.kcap = pl.kcap;
@@ -1134,15 +1227,22 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 #undef PF_CASE_PW
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_verify, dim3(pl.verify_grid), dim3(256), 0, st, pa);
+    {   // 16-token steps covering the longest row a pair of k_verify can have
+        const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
+#define VF_CASE(S) hipLaunchKernelGGL(k_verify<S>, dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap, pl.blk_stats)
+        if (steps <= 3) VF_CASE(3);
+        else if (steps <= 4) VF_CASE(4);
+        else if (steps <= 6) VF_CASE(6);
+        else if (steps <= 8) VF_CASE(8);
+        else VF_CASE(12);
+#undef VF_CASE
+    }
     LAUNCH_CHECK();
     if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table
         hipLaunchKernelGGL(k_verify_long, dim3(LONG_BLOCKS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey, pl.gcnt,
-                           pl.gslots);
+                           pl.gslots, pl.edges, pl.edge_cap);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_union, dim3(pl.union_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap);
-    LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     return 0;
 }
