@@ -445,7 +445,9 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.gb = c->gb;
     pl.shard = shard;
     pl.n_shards = n_shards;
-    pl.verify_grid = 1536;  // x 16 groups, a multiple of CAND_SHARDS; 6 blocks per CU (measured best of 1024..4096 at 100k rows)
+    // x 16 groups, a multiple of CAND_SHARDS; measured best of 1024..4096: 6 blocks per CU with the per-wave table
+    // (d <= 2, 100k rows), 2048 with per-group tables (d = 5, 1M rows)
+    pl.verify_grid = max_dist <= 2 ? 1536 : 2048;
     if (const char *e = getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, std::max(32, atoi(e) / 32 * 32));
     pl.blk_stats = c->d_blk_stats;
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);

@@ -882,7 +882,7 @@ __device__ __forceinline__ int row16_allsum(int x) {
 
 // exact multiset distance of one pair by signed counting in the group's LDS table (the general path); the rows
 // are already in registers: lane l16 holds positions 16 st + l16 of row A (a) and of row B (b0)
-template <int STEPS>
+template <int STEPS, bool UNROLL>
 __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t (&a)[STEPS], const uint32_t (&b0)[STEPS],
                                               int ka, int kb) {
     // table size: power of two >= 2 * tokens (load <= 1/2), capped at VERIFY_TABLE (load <= 3/4)
@@ -902,17 +902,26 @@ __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t
         }
         atomicAdd(reinterpret_cast<int *>(&mt[p].y), sgn);
     };
-#pragma unroll 1
-    for (int st = 0; st < STEPS; st++) {
-        const int j = st * 16 + l16;
-        uint32_t xa = a[0], xb = b0[0];  // register arrays are indexed by constants only
+    if (UNROLL) {  // the common path of this instantiation: straight-line code
 #pragma unroll
-        for (int q = 1; q < STEPS; q++) {
-            xa = st == q ? a[q] : xa;
-            xb = st == q ? b0[q] : xb;
+        for (int st = 0; st < STEPS; st++) {
+            const int j = st * 16 + l16;
+            if (j < ka) add(a[st], 1);
+            if (j < kb) add(b0[st], -1);
         }
-        if (j < ka) add(xa, 1);
-        if (j < kb) add(xb, -1);
+    } else {  // the rare path: compact code
+#pragma unroll 1
+        for (int st = 0; st < STEPS; st++) {
+            const int j = st * 16 + l16;
+            uint32_t xa = a[0], xb = b0[0];  // register arrays are indexed by constants only
+#pragma unroll
+            for (int q = 1; q < STEPS; q++) {
+                xa = st == q ? a[q] : xa;
+                xb = st == q ? b0[q] : xb;
+            }
+            if (j < ka) add(xa, 1);
+            if (j < kb) add(xb, -1);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -925,14 +934,17 @@ __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t
 }
 
 // STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
-// all are left to k_verify_long).
-template <int STEPS>
+// all are left to k_verify_long).  WAVE_TABLE: one hash table per wave, its groups take turns (small d: nearly
+// every candidate is certified without the table, and 8 KiB of LDS per block keeps 6+ blocks per CU resident);
+// otherwise one table per group, all four groups of a wave count in parallel (larger d: pairs with several
+// separate insertions fail the single-shift certificate).
+template <int STEPS, bool WAVE_TABLE>
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap, int *blk_stats) {
-    __shared__ uint2 tab[4][VERIFY_TABLE];  // {token, signed count}: one table per WAVE (the table path is rare)
+    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}
     __shared__ unsigned int blk_edges, blk_cands;
     const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;  // 0..15 in the block
-    uint2 *mt = tab[threadIdx.x >> 6];
+    uint2 *mt = tab[WAVE_TABLE ? (threadIdx.x >> 6) : grp];
     if (threadIdx.x == 0) blk_edges = blk_cands = 0;
     __syncthreads();
     // Group u of U (a multiple of CAND_SHARDS) works on queue shard u % CAND_SHARDS, entries j0, j0 + jstep, ..:
@@ -996,12 +1008,16 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                 const int mine = st0 < STEPS ? __popc(es >> st0) : 0;
                 const int matched = t + row16_allsum(mine);
                 int dist = kt - 2 * matched;  // upper bound
-                // not certified: count exactly; the wave's groups that need the table take turns
-                unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
-                while (want != 0ull) {
-                    const int g = (int)(__builtin_ctzll(want) >> 4);
-                    if ((lane >> 4) == g) dist = table_distance<STEPS>(mt, l16, a, b0, ka, kb);
-                    want &= ~(0xFFFFull << (g * 16));
+                // not certified: count exactly
+                if (WAVE_TABLE) {  // the wave's groups that need the table take turns
+                    unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
+                    while (want != 0ull) {
+                        const int g = (int)(__builtin_ctzll(want) >> 4);
+                        if ((lane >> 4) == g) dist = table_distance<STEPS, false>(mt, l16, a, b0, ka, kb);
+                        want &= ~(0xFFFFull << (g * 16));
+                    }
+                } else if (dist > pa.d) {
+                    dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);
                 }
                 is_edge = dist <= pa.d;
             }
@@ -1229,12 +1245,18 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     if (ev) (void)hipEventRecord(ev[2], st);
     {   // 16-token steps covering the longest row a pair of k_verify can have
         const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
-#define VF_CASE(S) hipLaunchKernelGGL(k_verify<S>, dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap, pl.blk_stats)
-        if (steps <= 3) VF_CASE(3);
-        else if (steps <= 4) VF_CASE(4);
-        else if (steps <= 6) VF_CASE(6);
-        else if (steps <= 8) VF_CASE(8);
-        else VF_CASE(12);
+#define VF_CASE(S)                                                                                                        \
+    if (pl.d <= 2)                                                                                                        \
+        hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
+                           pl.blk_stats);                                                                                 \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((k_verify<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,       \
+                           pl.blk_stats)
+        if (steps <= 3) { VF_CASE(3); }
+        else if (steps <= 4) { VF_CASE(4); }
+        else if (steps <= 6) { VF_CASE(6); }
+        else if (steps <= 8) { VF_CASE(8); }
+        else { VF_CASE(12); }
 #undef VF_CASE
     }
     LAUNCH_CHECK();
