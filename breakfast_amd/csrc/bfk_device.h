@@ -47,7 +47,8 @@ struct Plan {
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;
     const uint32_t *indices;
-    int *hist3, *start3, *rowkey, *rowrank, *tile_slots, *blk_stats;
+    int *hist3, *start3, *start3c, *rowkey, *rowrank, *tile_slots, *blk_stats;
+    int hist_copies;  // 8 or 1: copies of the cell histogram (k_sig block b counts into copy b % copies)
     unsigned long long *chain;
     int *perm, *ksorted, *parent;
     uint32_t *gkey;

@@ -165,6 +165,8 @@ struct bfk_ctx {
     int64_t bins_cap = 0;
     int *d_start3 = nullptr, *d_tile_slots = nullptr, *d_blk_stats = nullptr;
     unsigned long long *d_chain = nullptr;
+    int *d_start3c = nullptr;
+    int hist_copies = 1;
     int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
     int64_t bins3 = 0;
     uint32_t *d_gkey = nullptr;
@@ -250,7 +252,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_gkey,   c->d_perm,   c->d_sigu1,
                     c->d_ksorted,  c->d_parent,    c->d_gcnt,   c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
                     c->d_rowrank,  c->d_tile_slots, c->d_cand,  c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
-                    c->d_chain,    c->d_blk_stats};
+                    c->d_chain,    c->d_blk_stats, c->d_start3c};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -306,15 +308,19 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     if (bins3 > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the sort-key index");
     c->bins3 = bins3;
     if (bins3 > c->bins_cap || !c->d_head) {
-        for (void *q : {(void *)c->d_head, (void *)c->d_start3, (void *)c->d_chain})
+        for (void *q : {(void *)c->d_head, (void *)c->d_start3, (void *)c->d_start3c, (void *)c->d_chain})
             if (q) (void)hipFree(q);
         c->d_head = nullptr;
         c->d_start3 = nullptr;
+        c->d_start3c = nullptr;
         c->d_chain = nullptr;
         c->bins_cap = 0;
-        size_t head = sizeof(Counters) + (size_t)bins3 * 4;
+        // the histogram is kept in 8 copies while that is cheap (<= 32 MiB): see k_cells
+        c->hist_copies = bins3 <= (1 << 20) ? 8 : 1;
+        size_t head = sizeof(Counters) + (size_t)bins3 * 4 * c->hist_copies;
         if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start3, (size_t)bins3 * 4) != hipSuccess ||
-            hipMalloc((void **)&c->d_chain, (size_t)(bins3 / 8192 + 2) * 8) != hipSuccess)
+            hipMalloc((void **)&c->d_start3c, (size_t)bins3 * 4 * c->hist_copies) != hipSuccess ||
+            hipMalloc((void **)&c->d_chain, (size_t)(bins3 / 1024 + 2) * 8) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins3;
         c->need_zero = true;
@@ -485,6 +491,8 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.rowrank = c->d_rowrank;
     pl.tile_slots = c->d_tile_slots;
     pl.chain = c->d_chain;
+    pl.start3c = c->d_start3c;
+    pl.hist_copies = c->hist_copies;
     pl.perm = c->d_perm;
     pl.ksorted = c->d_ksorted;
     pl.parent = c->d_parent;
@@ -499,8 +507,8 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.labels = (int *)d_labels_out;
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
-        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->bins3 * 4, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_chain, 0, (size_t)(c->bins3 / 8192 + 2) * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->bins_cap * 4 * c->hist_copies, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_chain, 0, (size_t)(c->bins_cap / 1024 + 2) * 8, c->stream));
         c->need_zero = false;
     }
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;

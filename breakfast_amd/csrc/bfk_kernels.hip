@@ -128,8 +128,9 @@ __device__ __forceinline__ void key_band(int rlo, int rhi, int k, int kp, int am
 }
 
 struct CellArgs {
-    int *hist3;     // (kcap+1)*fb*gb cell counters, re-zeroed here
+    int *hist3;     // copies x cells cell counters (copy-major), re-zeroed here
     int *start3;    // cells + 1: first sorted position of every (k,f,g) cell
+    int *start3c;   // copies x cells: first sorted position of the rows counted in each histogram copy
     int4 *tiles;    // {first sorted row, rows, cell key, 0}: tiles never cross a cell boundary
     unsigned long long *chain;  // one status word per block of k_cells (zeroed again by k_place)
     Counters *ctr;
@@ -148,17 +149,21 @@ __device__ __forceinline__ int wave_incl_scan_add(int x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_cells: exclusive scan of the (k,f,g) cell counters -> start3, and the tile list: every non-empty cell is
+// k_cells<C>: exclusive scan of the (k,f,g) cell counters -> start3, and the tile list: every non-empty cell is
 // cut into tiles of at most TR = 2^tr_shift rows (a tile never crosses a cell boundary, so its band is as
-// tight as the sort key allows).  One block per 8192 cells.  Cross-block offsets by decoupled look-back on
-// aggregates: a block publishes (tiles, rows) of its own cells as soon as its local scan is done (one 64-bit
-// status word, value + 1, agent-scope release) and then sums the words of ALL its predecessors, 64 per wave
-// step, so the chain costs one round trip instead of one per block.  Grids larger than the guaranteed
+// tight as the sort key allows).  One cell per thread, 1024 cells per block.
+// The histogram comes in C copies (k_sig block b counts into copy b % C: the returning atomics of the hub
+// cells are what k_sig waits for, and they serialise per address); a cell's count is the sum of its copies,
+// and the rows counted in copy q start at start3c[q][cell] = start3[cell] + the copies before q.
+// Cross-block offsets by decoupled look-back: a block publishes the (tiles, rows) total of its own cells as
+// soon as its local scan is done (status word: flag 1 + value, agent-scope release), looks back over its
+// predecessors 64 at a time, adding aggregates until it meets a block that already published its INCLUSIVE
+// prefix (flag 2), and then publishes its own inclusive prefix.  Grids larger than the guaranteed
 // co-residency take their logical index from an arrival ticket (a block then only ever waits for blocks that
 // have started).  The histogram and the per-step counters are re-zeroed here, the status words by k_place.
 // ------------------------------------------------------------------------------------------------
+template <int C>
 __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
-    __shared__ int s_cnt[8192];
     __shared__ int s_wr[16], s_wt[16];  // per-wave totals: rows, tiles
     __shared__ int s_base_r, s_base_t, s_bid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,31 +180,24 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         if (threadIdx.x == 64) {
             a.ctr->err = 0;
             a.ctr->overflow = 0;
-
             a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
         }
     }
-    const int base = bid * 8192;
+    const int c = bid * 1024 + threadIdx.x;
+    int part[C];
+    int rows = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int c = base + j * 1024 + threadIdx.x;
-        int v = 0;
+    for (int q = 0; q < C; q++) {
+        part[q] = 0;
         if (c < a.cells) {
-            v = a.hist3[c];
-            a.hist3[c] = 0;
+            int *h = a.hist3 + (size_t)q * a.cells + c;
+            part[q] = *h;
+            *h = 0;
         }
-        s_cnt[j * 1024 + threadIdx.x] = v;
+        rows += part[q];
     }
-    __syncthreads();
     const int trm = (1 << a.tr_shift) - 1;
-    int cnt[8];
-    int rows = 0, tl = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        cnt[j] = s_cnt[threadIdx.x * 8 + j];
-        rows += cnt[j];
-        tl += (cnt[j] + trm) >> a.tr_shift;
-    }
+    const int tl = (rows + trm) >> a.tr_shift;
     const int inc_r = wave_incl_scan_add(rows), inc_t = wave_incl_scan_add(tl);
     if (lane == 63) {
         s_wr[wave] = inc_r;
@@ -215,31 +213,37 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
             s_wt[lane] = it - wt;
         }
         const int tot_r = __builtin_amdgcn_readlane(ir, 15), tot_t = __builtin_amdgcn_readlane(it, 15);
-        if (lane == 0)
-            __hip_atomic_store(&a.chain[bid], ((((unsigned long long)(unsigned)tot_t) << 32) | (unsigned)tot_r) + 1ull,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        // look-back: sum the aggregates of all predecessors
+        const unsigned long long FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VAL = (1ull << 62) - 1ull;
+        auto pack = [](int t, int r) { return (((unsigned long long)(unsigned)t) << 32) | (unsigned)r; };
+        if (lane == 0 && bid > 0)
+            __hip_atomic_store(&a.chain[bid], FLAG_AGG | pack(tot_t, tot_r), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int before_r = 0, before_t = 0;
         for (int w0 = bid - 1; w0 >= 0; w0 -= 64) {
             const int p = w0 - lane;
-            unsigned long long v = 1ull;
+            unsigned long long v = 0ull;
             if (p >= 0) {
                 int spins = 0;
-                while ((v = __hip_atomic_load(&a.chain[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                while (((v = __hip_atomic_load(&a.chain[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 22)) {  // never expected: bound the spin
                         atomicOr(&a.ctr->err, ERR_WORKCAP);
-                        v = 1ull;
+                        v = FLAG_INC;
                         break;
                     }
                 }
             }
-            v -= 1ull;
-            before_r += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(unsigned)(v & 0xffffffffull)), 63);
-            before_t += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(v >> 32)), 63);
+            // nearest predecessor (lowest lane) that already knows its inclusive prefix: nothing beyond it counts
+            const unsigned long long inc_mask = __builtin_amdgcn_ballot_w64(p >= 0 && (v >> 62) == 2ull);
+            const int stop = inc_mask ? (int)__builtin_ctzll(inc_mask) : 64;
+            const unsigned long long val = (p >= 0 && lane <= stop) ? (v & VAL) : 0ull;
+            before_r += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(unsigned)(val & 0xffffffffull)), 63);
+            before_t += __builtin_amdgcn_readlane(wave_incl_scan_add((int)(val >> 32)), 63);
+            if (inc_mask) break;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lane == 0) {
+            __hip_atomic_store(&a.chain[bid], FLAG_INC | pack(before_t + tot_t, before_r + tot_r), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
             s_base_r = before_r;
             s_base_t = before_t;
             if (bid + 1 == (int)gridDim.x) {
@@ -252,16 +256,21 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         }
     }
     __syncthreads();
-    int pos = s_base_r + s_wr[wave] + inc_r - rows;
+    const int pos = s_base_r + s_wr[wave] + inc_r - rows;
     int t = s_base_t + s_wt[wave] + inc_t - tl;
-    const int tr = 1 << a.tr_shift;
+    if (c < a.cells) {
+        a.start3[c] = pos;
+        if (C > 1) {
+            int run = pos;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int c = base + threadIdx.x * 8 + j;
-        if (c < a.cells) a.start3[c] = pos;
-        for (int r0 = 0; r0 < cnt[j]; r0 += tr, t++)
-            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, cnt[j] - r0), c, 0);
-        pos += cnt[j];
+            for (int q = 0; q < C; q++) {
+                a.start3c[(size_t)q * a.cells + c] = run;
+                run += part[q];
+            }
+        }
+        const int tr = 1 << a.tr_shift;
+        for (int r0 = 0; r0 < rows; r0 += tr, t++)
+            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, rows - r0), c, 0);
     }
     if (bid + 1 == (int)gridDim.x) PLAN_STAMP(1)
 }
@@ -303,9 +312,9 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                                                int nnz, int kcap, int rpw, KeyCfg key, int *__restrict__ rowkey,
                                                int *__restrict__ parent, uint32_t *__restrict__ sigu1,
                                                uint32_t *__restrict__ sigu2, int *hist3, int *__restrict__ rowrank,
-                                               Counters *ctr) {
+                                               Counters *ctr, int dbg, int cells, int copies) {
     constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
-    constexpr int MAXR = 256, SLOTS = 512;
+    constexpr int MAXRPW = 16, MAXR = 16 * MAXRPW, SLOTS = 512;
     __shared__ int s_k[MAXR], s_f[MAXR], s_g[MAXR];
     __shared__ uint32_t s_s1[MAXR * W1], s_s2[MAXR * SIG2_WORDS];
     __shared__ int t_key[SLOTS], t_cnt[SLOTS];
@@ -320,18 +329,24 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
     const int base = blockIdx.x * rows_per_block;
     const int r0 = base + wave * rpw;
     const int nr = max(0, min(rpw, n - r0));
-    if (nr > 0 && nnz > 0) {
+    if (nr > 0 && nnz > 0 && !(dbg & 32)) {
         // extents of all rows of this wave: lane l holds indptr[r0 + l]
         const int ext = indptr[min(r0 + min(lane, rpw), n)];
-        int b = __builtin_amdgcn_readlane(ext, 0), e = __builtin_amdgcn_readlane(ext, 1);
-        // token prefetches are unconditional loads from a clamped address (a lane past the row reads a
-        // neighbour's token and contributes nothing): a predicated load would sit in a branch and force a
-        // full vmcnt(0) wait in front of every row
-        uint32_t xfirst = indices[min(b + lane, nnz - 1)];
-        for (int t = 0; t < nr; t++) {
-            const int nb = e;
-            const int ne = (t + 1 < nr) ? __builtin_amdgcn_readlane(ext, t + 2) : e;
-            const uint32_t xnext = indices[min(nb + lane, nnz - 1)];
+        // The first 64 tokens of ALL the wave's rows are requested up front (one register per row): with one row
+        // fetched ahead, every row still waited for most of a ~2 us round trip (70% of the wave cycles were waits).
+        // Unconditional loads from clamped addresses: a lane past its row reads a neighbour's token and
+        // contributes nothing.
+        uint32_t xs[MAXRPW];
+#pragma unroll
+        for (int t = 0; t < MAXRPW; t++) {
+            const int bt = __builtin_amdgcn_readlane(ext, t);
+            xs[t] = indices[min(max(bt, 0) + lane, nnz - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < MAXRPW; t++) {
+            if (t >= nr) continue;  // wave-uniform
+            const int b = __builtin_amdgcn_readlane(ext, t), e = __builtin_amdgcn_readlane(ext, t + 1);
+            const uint32_t xfirst = xs[t];
             int k = e - b;
             if (k < 0 || k > kcap) {
                 if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
@@ -378,9 +393,6 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                 s_f[lr] = f;
                 s_g[lr] = g;
             }
-            b = nb;
-            e = ne;
-            xfirst = xnext;
         }
     } else if (nr > 0 && lane == 0) {  // no tokens at all: every row is empty
         for (int t = 0; t < nr; t++) {
@@ -414,7 +426,8 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
     __syncthreads();
     if (tr < SLOTS) {
         const int c = t_cnt[tr];
-        if (c) t_cnt[tr] = atomicAdd(&hist3[t_key[tr]], c);  // base of this block's range in the cell
+        // base of this block's range among the rows of its histogram copy in the cell
+        if (c && !(dbg & 16)) t_cnt[tr] = atomicAdd(&hist3[(size_t)(blockIdx.x & (copies - 1)) * cells + t_key[tr]], c);
     }
     __syncthreads();
     if (live) rowrank[i] = t_cnt[slot] + lrk;
@@ -428,11 +441,13 @@ __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, i
                                                 const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
                                                 const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
                                                 int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
-                                                uint32_t *__restrict__ sig2, unsigned long long *chain, int n_chain) {
+                                                uint32_t *__restrict__ sig2, unsigned long long *chain, int n_chain,
+                                                int cells, int copies, int sig_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_chain) chain[i] = 0ull;  // k_cells' status words: clean for the next step
     if (i >= n) return;
-    const int p = start3[rowkey[i]] + rowrank[i];
+    // start3 is start3c when copies > 1: the row was ranked inside histogram copy (its k_sig block) % copies
+    const int p = start3[(size_t)((i / sig_rows) & (copies - 1)) * cells + rowkey[i]] + rowrank[i];
     const int k = indptr[i + 1] - indptr[i];
     perm[p] = i;
     ksorted[p] = k < 0 ? 0 : (k > kcap ? kcap : k);
@@ -1295,18 +1310,24 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     ca.n = n;
     ca.cells = (pl.kcap + 1) * pl.fb * pl.gb;
     ca.tr_shift = 6 + (pl.rows_per_lane == 1 ? 0 : (pl.rows_per_lane == 2 ? 1 : 2));
-    const int cell_blocks = (ca.cells + 8191) / 8192;
+    ca.start3c = pl.start3c;
+    const int cell_blocks = (ca.cells + 1023) / 1024;
+    const int copies = pl.hist_copies;
     ca.tile_cap = pl.tile_cap;
     switch (pl.w1) {
 #define PREP_CASE(W)                                                                                                      \
     case W:                                                                                                               \
         hipLaunchKernelGGL(k_sig<W>, dim3(sig_blocks), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.kcap, rpw,  \
                            key,                                                                                           \
-                           pl.rowkey, pl.parent, pl.sigu1, pl.sigu2, pl.hist3, pl.rowrank, pl.ctr);                        \
-        hipLaunchKernelGGL(k_cells, dim3(cell_blocks), dim3(1024), 0, st, ca);                                            \
+                           pl.rowkey, pl.parent, pl.sigu1, pl.sigu2, pl.hist3, pl.rowrank, pl.ctr, pl.dbg, ca.cells,       \
+                           copies);                                                                                       \
+        if (copies == 8)                                                                                                  \
+            hipLaunchKernelGGL(k_cells<8>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
+        else                                                                                                              \
+            hipLaunchKernelGGL(k_cells<1>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
         hipLaunchKernelGGL(k_place<W>, dim3((max(n, cell_blocks) + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap,   \
-                           pl.start3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm, pl.ksorted, pl.sig1, pl.sig2,    \
-                           pl.chain, cell_blocks);                                                                        \
+                           copies > 1 ? pl.start3c : pl.start3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm,        \
+                           pl.ksorted, pl.sig1, pl.sig2, pl.chain, cell_blocks, ca.cells, copies, rpw * 16);               \
         break;
         PREP_CASE(1)
         PREP_CASE(2)

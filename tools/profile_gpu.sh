@@ -1,5 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's roofline block is checked against (run through gpurun on a GPU box):
+# Everything lands in gpurun_out/profiles/ (gpurun merges only gpurun_out/ back); copy the files into profiles/.
 #   1. kernel trace + stats of `python3 bench.py`  -> profiles/<tag>_kernel_stats.csv
 #   2. PMC passes (separate runs, never combined with traces): FETCH_SIZE / WRITE_SIZE, then the SQ counters
 #      -> profiles/<tag>_pmc_per_launch.json (per-kernel means per launch; FETCH_SIZE/WRITE_SIZE in KiB as
@@ -11,15 +12,16 @@ tag=${1:?tag}
 shift || true
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/prof_$tag
-mkdir -p "$out" "$root/profiles"
+dst=$root/gpurun_out/profiles
+mkdir -p "$out" "$dst"
 cd /tmp
 export TMPDIR=/tmp
 
-python3 "$root/bench.py" "$@" > "$root/profiles/${tag}_bench.json"
+python3 "$root/bench.py" "$@" > "$dst/${tag}_bench.json"
 echo "[profile] bench line written"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- \
-    python3 "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline "$@" > "$root/profiles/${tag}_bench_under_rocprof.json"
+    python3 "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline "$@" > "$dst/${tag}_bench_under_rocprof.json"
 echo "[profile] kernel trace done"
 
 i=0
@@ -31,7 +33,7 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES S
     echo "[profile] pmc pass $i done"
 done
 
-python3 - "$out" "$root/profiles/$tag" <<'EOF'
+python3 - "$out" "$dst/$tag" <<'EOF'
 import csv, glob, json, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
 st = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)[0]
