@@ -188,6 +188,20 @@ def main():
         cyc_per_slot = w * (2.6 + 4.3) + 4.3
         slots_ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
         slots_rate = st["pairs_filtered"] / t_pf if t_pf > 0 else None
+        # measured HBM bytes per launch of the pair kernel: bench.py cannot collect PMC counters itself, so the
+        # figure comes from the committed rocprofv3 passes of this same command (tools/profile_gpu.sh), FETCH_SIZE
+        # doubled per the gfx950 note of the microarchitecture guide (an upper bound for 4-byte-per-lane reads)
+        traffic, traffic_src = None, None
+        if world == 1 and n_rows == 100000 and d == 1 and not a.indels:
+            import glob
+            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                   "*_pmc_per_launch.json")), reverse=True):
+                pm = json.load(open(f))
+                hit = [v for kk, v in pm.items() if "k_prefilter" in kk and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+                if hit:
+                    traffic = (2.0 * hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0
+                    traffic_src = f"{os.path.basename(f)}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+                    break
         out = {
             "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step)",
             "value": resolved * a.steps / elapsed,
@@ -217,7 +231,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": b_alg / world,
                 "kernel_ms": st["ms_prefilter"],
                 "note": "SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "

@@ -5,15 +5,16 @@
 //                (a token repeated an even number of times cancels itself, so the bound holds for multisets
 //                without sorting or ranking repeats); parent[i] = i
 //                + (k,f,g) cell histogram and rank of every row inside its cell (LDS hash aggregation per block)
-//   k_cells      chained multi-block scan of the cell counters -> start3, tile list (tiles never cross cells);
-//                re-zeroes histogram and counters for the next step
+//   k_cells      sum of the histogram copies, scan with decoupled look-back -> start3 / start3c, tile list
+//                (tiles never cross cells); re-zeroes histogram and counters for the next step
 //   k_place      counting-sort scatter of row ids / lengths / signatures into (k,f,g) order
 //   k_prefilter  the pair kernel: one block per tile; the columns that can be within d of the tile's rows are
 //                a few contiguous ranges (the (k,f,g) band); popcount(sig_row ^ sig_col) <= d is a necessary
 //                condition for |A delta B| <= d; survivors pass a 64-bit second level and are queued
-//   k_verify     one 16-lane group per candidate: signed counting of both rows' tokens in a hash table in
-//                the group's LDS slice -> exact multiset distance; k_verify_long for pairs > 192 tokens
-//                and lock-free union-find hooks of the verified edges (one edge per lane)
+//   k_verify     one 16-lane group per candidate: matching certificate (prefix + shifted suffix) or, when it
+//                fails, signed counting of both rows' tokens in an LDS hash table -> exact multiset distance;
+//                lock-free union-find hooks of the verified edges (one edge per lane);
+//                k_verify_long for pairs > 192 tokens
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
 //   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
 //

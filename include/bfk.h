@@ -55,9 +55,9 @@ typedef struct bfk_stats {
     int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
     int32_t n_work_items;    /* (row tile, column chunk) items in the band */
     int32_t profiled;        /* number of steps the ms fields below are averaged over (0 = profiling off) */
-    float ms_prep;           /* histogram + scan + scatter + row canonicalisation/signatures */
+    float ms_prep;           /* row keys + signatures + cell histogram/ranks, scan, scatter */
     float ms_prefilter;      /* all-pairs signature kernel (the dominant kernel) */
-    float ms_verify;         /* exact merge of candidates + union-find hooks */
+    float ms_verify;         /* exact check of the candidates + union-find hooks */
     float ms_flatten;        /* label flatten */
     float ms_total;          /* first launch to last launch completion */
 } bfk_stats;
