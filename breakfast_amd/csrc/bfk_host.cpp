@@ -636,7 +636,20 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         }
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
-        s.pairs_in_band = (int64_t)h.pairs_in_band;
+        if (out) {  // pairs of the reference's length band (|k_i - k_j| <= d): row counts per length from start3
+            const int planes = c->kcap + 2;
+            const size_t pitch = (size_t)c->fb * c->gb * sizeof(int);
+            std::vector<int> sk((size_t)planes);
+            HIP_TRY(hipMemcpy2D(sk.data(), sizeof(int), c->d_start3, pitch, sizeof(int), (size_t)planes, hipMemcpyDeviceToHost));
+            const int d = c->last_d;
+            long double acc = 0;
+            for (int k = 0; k + 1 < planes; k++) {
+                const long double ck = (long double)(sk[(size_t)k + 1] - sk[(size_t)k]);
+                acc += ck * (ck - 1) / 2;
+                for (int dl = 1; dl <= d && k + dl + 1 < planes; dl++) acc += ck * (long double)(sk[(size_t)k + dl + 1] - sk[(size_t)k + dl]);
+            }
+            s.pairs_in_band = (int64_t)acc;
+        }
         {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
             std::vector<int> ts((size_t)h.n_work * c->plan.pf_waves);
             if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));

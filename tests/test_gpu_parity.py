@@ -388,3 +388,18 @@ def test_cache_incremental_on_synthetic(tmp_path):
     _run_cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "ob"), "--input-cache", str(cache)])
     _run_cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "fresh")])
     assert (tmp_path / "ob" / "clusters.tsv").read_bytes() == (tmp_path / "fresh" / "clusters.tsv").read_bytes()
+
+
+def test_stats_pairs_in_band_matches_the_reference_band():
+    """bfk_stats.pairs_in_band = unordered pairs with |k_i - k_j| <= d, the pairs the reference merges (:250)"""
+    rows = generate_profiles(3000, p_del=0.05, p_ins=0.02)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    k = np.diff(indptr).astype(np.int64)
+    cnt = np.bincount(k)
+    for d in (1, 3):
+        want = int(sum(cnt[a] * (cnt[a] - 1) // 2 + sum(cnt[a] * cnt[a + dl] for dl in range(1, d + 1) if a + dl < len(cnt))
+                       for a in range(len(cnt))))
+        _, st = _lib.cluster_csr(indptr, indices, d)
+        assert st["pairs_in_band"] == want
+        assert st["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
