@@ -119,10 +119,18 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # rehearsal of the N > 1 path on a one-GPU box: BFK_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and the
+    # label exchange on gloo (RCCL refuses two ranks on one device); the driver's runs never set it
+    one_device = os.environ.get("BFK_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_rows = a.rows or int(round(100000 * math.sqrt(world)))
     kw = dict(p_del=0.05, p_ins=0.01) if a.indels else {}

@@ -654,8 +654,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             std::vector<int> ts((size_t)h.n_work * c->plan.pf_waves);
             if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
             int64_t acc = 0;
-            for (size_t t = (size_t)c->plan.shard; t < (size_t)h.n_work; t += (size_t)c->plan.n_shards)
-                for (int w = 0; w < c->plan.pf_waves; w++) acc += ts[t * (size_t)c->plan.pf_waves + w];
+            for (size_t t = 0; t < ts.size(); t++) acc += ts[t];  // tiles of other ranks' cells hold 0
             s.pairs_filtered = acc;
         }
         s.n_candidates = (int64_t)h.n_cand_total;

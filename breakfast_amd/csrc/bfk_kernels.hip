@@ -132,7 +132,7 @@ struct CellArgs {
     int *hist3;     // copies x cells cell counters (copy-major), re-zeroed here
     int *start3;    // cells + 1: first sorted position of every (k,f,g) cell
     int *start3c;   // copies x cells: first sorted position of the rows counted in each histogram copy
-    int4 *tiles;    // {first sorted row, rows, cell key, 0}: tiles never cross a cell boundary
+    int4 *tiles;    // {first sorted row, rows, cell key, first tile of the cell}: tiles never cross a cell boundary
     unsigned long long *chain;  // one status word per block of k_cells (zeroed again by k_place)
     Counters *ctr;
     int n, cells, tr_shift, tile_cap;
@@ -270,8 +270,9 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
             }
         }
         const int tr = 1 << a.tr_shift;
+        const int t_first = t;  // every tile carries the index of its cell's first tile: the multi-GPU owner key
         for (int r0 = 0; r0 < rows; r0 += tr, t++)
-            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, rows - r0), c, 0);
+            if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, rows - r0), c, t_first);
     }
     if (bid + 1 == (int)gridDim.x) PLAN_STAMP(1)
 }
@@ -640,17 +641,24 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     uint32_t *myrow = srow[wave];
     // Work items = (tile, wave slot) pairs of this shard, taken by WAVES, grid-stride: the host launches one
     // block per expected tile (the count lives on the device; any grid is correct).
-    const int n_entries = n_tiles > t_begin + shard0 ? (n_tiles - t_begin - shard0 + nshards - 1) / nshards : 0;
-    const int n_items = n_entries * PW;
+    // Multi-GPU: a CELL belongs to one rank (owner = index of the cell's first tile mod ranks), never a tile.
+    // The order of the rows inside a cell comes from atomics and differs from rank to rank, so which rows sit in
+    // "tile 3 of the cell" differs too; whole cells and whole column cells are the same sets on every rank.
+    const int n_items = max(n_tiles - t_begin, 0) * PW;
     int item = (int)blockIdx.x * PW + wave;
     while (item < n_items) {
-    const int t = t_begin + (item / PW) * nshards + shard0;
+    const int t = t_begin + item / PW;
     const int wslot = item & (PW - 1);
     const unsigned long long t_start = ba.dbg_t ? wall_clock64() : 0ull;
     unsigned long long t_rng = 0, t_main = 0;
     int dbg_hits = 0, dbg_chunks = 0;
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
     const int4 tile = ba.tiles[t];
+    if (nshards > 1 && (tile.w % nshards) != shard0) {  // another rank's cell
+        if (lane == 0) ba.tile_slots[t * PW + wslot] = 0;
+        item += (int)gridDim.x * PW;
+        continue;
+    }
     const int row0 = tile.x, nrows = tile.y;
     const int fb = ba.key.fb, gb = ba.key.gb;
     const int k0 = tile.z / (fb * gb), f0 = (tile.z / gb) % fb, g0 = tile.z % gb;
@@ -1234,7 +1242,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
     // previous step's count (tile_hint) and the kernel strides over whatever the count turns out to be
     const long long span = (long long)std::min(std::min(t_end, pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
-    const int grid = std::max(1, (int)std::min<long long>((span + pl.n_shards - 1) / pl.n_shards, pl.pf_blocks));
+    const int grid = std::max(1, (int)std::min<long long>(span, pl.pf_blocks));  // every rank walks all tiles, skips foreign cells
 
 #define PF_CASE_PW(W, R, PW)                                                                                       \
     hipLaunchKernelGGL((k_prefilter<W, R, PW>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard, pl.n_shards,  \

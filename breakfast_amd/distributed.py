@@ -1,8 +1,10 @@
 """One-process-per-GPU driver for the row-sharded path.
 
-Every rank holds the full CSR (<= 180 MB at 1M rows) and runs the prep kernels on it; the band work
-items (row tile x column chunk) are dealt round-robin over the ranks, so each rank evaluates 1/world of
-the pair tiles and hooks the edges it finds into a LOCAL union-find forest over all N rows.  The only
+Every rank holds the full CSR (<= 180 MB at 1M rows) and runs the prep kernels on it; the (k,f,g) CELLS of
+the sorted order are dealt round-robin over the ranks (owner = index of the cell's first tile mod world —
+cells, not tiles: the order of the rows inside a cell comes from atomics and differs from rank to rank, whole
+cells are the same sets everywhere), so each rank evaluates ~1/world of the pair tiles and hooks the edges it
+finds into a LOCAL union-find forest over all N rows.  The only
 exchange step is the label merge, over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests):
 

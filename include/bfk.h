@@ -119,7 +119,7 @@ int bfk_ctx_upload_csr(bfk_ctx *ctx, const int32_t *indptr, const int32_t *indic
  * sizes the workspace (synchronous: reads indptr[n_rows] and the longest row back) */
 int bfk_ctx_bind_csr_device(bfk_ctx *ctx, const void *d_indptr, const void *d_indices, int64_t n_rows);
 
-/* enqueue CSR -> labels for shard `shard` of `n_shards` (work items are dealt round-robin; 0,1 = all).
+/* enqueue CSR -> labels for shard `shard` of `n_shards` (the cells of the sorted order are dealt round-robin; 0,1 = all).
  * d_labels_out: device int32[n_rows]; with n_shards > 1 these are the labels of the LOCAL forest.
  * Asynchronous: returns after the launches are enqueued.                                            */
 int bfk_ctx_cluster(bfk_ctx *ctx, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out);

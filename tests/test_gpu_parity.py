@@ -403,3 +403,32 @@ def test_stats_pairs_in_band_matches_the_reference_band():
         _, st = _lib.cluster_csr(indptr, indices, d)
         assert st["pairs_in_band"] == want
         assert st["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
+
+
+@pytest.mark.parametrize("n_shards,d", [(2, 1), (3, 2), (8, 1)])
+def test_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d):
+    """the N-GPU path on one GPU: every shard of the tile list clustered into its own local forest
+    (bfk_ctx_cluster(shard, n_shards)), the label arrays merged with bfk_ctx_merge_labels like after an
+    all_gather — must give the 1-shard labels bit for bit"""
+    rows = generate_profiles(20000, p_del=0.03, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n = len(uf)
+    want, _ = _lib.cluster_csr(indptr, indices, d)
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_local = ctx.alloc(4 * n)
+    d_gath = ctx.alloc(4 * n * n_shards)
+    d_out = ctx.alloc(4 * n)
+    edges = 0
+    for s in range(n_shards):  # shard s last => the forest in the context is shard n_shards-1's
+        ctx.cluster(d, d_gath + 4 * n * s, s, n_shards)
+        st = ctx.sync()
+        edges += st["n_edges"]
+    ctx.merge_labels(d_gath, n_shards, d_out)
+    ctx.sync()
+    got = ctx.download_i32(d_out, n)
+    ctx.close()
+    assert np.array_equal(got, want)
+    _, st1 = _lib.cluster_csr(indptr, indices, d)
+    assert edges == st1["n_edges"]  # every edge found by exactly one shard
