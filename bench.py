@@ -228,7 +228,7 @@ def main():
                             f"{', indels kept' if a.indels else ''}), N_u={n_u} unique, k_mean={nnz / n_u:.1f}, "
                             f"max-dist {d}",
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
-                "sharding": f"band work items round-robin over {world} rank(s)" +
+                "sharding": f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)" +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM",
             },
