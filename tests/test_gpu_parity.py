@@ -432,3 +432,42 @@ def test_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d):
     assert np.array_equal(got, want)
     _, st1 = _lib.cluster_csr(indptr, indices, d)
     assert edges == st1["n_edges"]  # every edge found by exactly one shard
+
+
+@pytest.mark.parametrize("seed,d", [(1, 1), (2, 2), (3, 4), (4, 6)])
+def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
+    """the verify kernel's certificate path: rows that keep a common token order (like real profiles), with
+    repeated tokens, insertions at both ends and in the middle, substitutions, and length differences of either
+    sign — the prefix / shifted-suffix matching must never accept a pair the exact count rejects"""
+    rng = np.random.default_rng(seed)
+    base = [np.sort(rng.integers(0, 60, size=int(rng.integers(5, 50)))) for _ in range(40)]  # repeats likely
+    rows = []
+    for _ in range(3000):
+        r = list(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, d + 2))):
+            op = rng.random()
+            pos = int(rng.integers(0, len(r) + 1))
+            if op < 0.4 and r:
+                r.pop(min(pos, len(r) - 1))
+            elif op < 0.8:
+                r.insert(pos, int(rng.integers(0, 60)))       # not necessarily in order: a substitution-like edit
+            elif r:
+                r.insert(pos, r[min(pos, len(r) - 1)])          # duplicate a neighbour
+        rows.append(np.array(r, dtype=np.int32))
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows) if indptr[-1] else np.zeros(0, np.int32)
+    labels, st = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(labels, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
+    # the exact edge set, by brute force on the dense count matrix
+    from scipy.spatial.distance import cdist
+
+    dense = np.zeros((len(rows), 60), np.int32)
+    for i, r in enumerate(rows):
+        np.add.at(dense[i], r, 1)
+    dist = cdist(dense, dense, "cityblock")
+    want_edges = int((np.triu(dist <= d, 1)).sum())
+    assert st["n_edges"] == want_edges
+    ptr, idx = _lib.neighbours_csr(indptr, indices, d)
+    for i in rng.integers(0, len(rows), size=200):
+        assert np.array_equal(idx[ptr[i]: ptr[i + 1]], np.flatnonzero(dist[i] <= d))
