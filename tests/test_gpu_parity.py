@@ -471,3 +471,20 @@ def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
     ptr, idx = _lib.neighbours_csr(indptr, indices, d)
     for i in rng.integers(0, len(rows), size=200):
         assert np.array_equal(idx[ptr[i]: ptr[i + 1]], np.flatnonzero(dist[i] <= d))
+
+
+@pytest.mark.parametrize("env", [{"BFK_PF_ROWS": "2"}, {"BFK_PF_ROWS": "4"}, {"BFK_PF_WAVES": "2"}, {"BFK_PF_WAVES": "4"},
+                                 {"BFK_VERIFY_GRID": "32"}, {"BFK_VERIFY_GRID": "8192"}])
+@pytest.mark.parametrize("d", [1, 4])
+def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monkeypatch):
+    """128- and 256-row tiles (chosen above 2M / 8M rows), 2 and 4 waves per tile, extreme verify grids: the
+    template instantiations that the default sizes of the test inputs never pick"""
+    rows = generate_profiles(6000, p_del=0.05, p_ins=0.02)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want, st0 = _lib.cluster_csr(indptr, indices, d)
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    got, st = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(got, want)
+    assert st["n_edges"] == st0["n_edges"] and st["n_candidates"] >= st["n_edges"]
