@@ -4,12 +4,13 @@ there is no CPU fallback anywhere in the product path."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libbfk.so"
+LIB_PATH = Path(os.environ["BFK_LIB"]) if os.environ.get("BFK_LIB") else _HERE / "libbfk.so"  # BFK_LIB: A/B builds
 _lib = None
 
 c_i32p = C.POINTER(C.c_int32)
