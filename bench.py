@@ -156,7 +156,12 @@ def main():
         for _ in range(max(a.warmup, 1)):
             sc.step(d)
         st0 = eng.sync()
-        if st0["n_retry_slices"] == 0:
+        again = int(st0["n_retry_slices"] != 0)
+        if world > 1:  # every rank must run the same number of steps (each step holds a collective)
+            tt = torch.tensor([again], dtype=torch.int32, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            again = int(tt.item())
+        if not again:
             break
     barrier()
     t0 = time.perf_counter()
