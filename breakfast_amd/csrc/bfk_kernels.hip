@@ -112,6 +112,7 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 
 struct KeyCfg {
     int fb, gb;  // buckets per row length for f and g (powers of two; 1 = key unused)
+    int fb_log, gb_log;
 };
 __device__ __forceinline__ int key_center(int k, int nb) { return (k >> 1) - (nb >> 1); }
 __device__ __forceinline__ int key_bucket(int v, int k, int nb) { return min(max(v - key_center(k, nb), 0), nb - 1); }
@@ -592,7 +593,7 @@ struct BandArgs {
     const int4 *tiles;
     int *tile_slots;  // per tile: pair slots evaluated (statistics, summed by the host)
     KeyCfg key;
-    int kcap, d;
+    int kcap, d, inv_d1;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -619,7 +620,7 @@ struct BandArgs {
 // round), s_setprio for waves with long scans (no effect), issuing the tiles of big cells several times with
 // the columns divided (helps at 100k, costs 40% at 1M rows).
 // ------------------------------------------------------------------------------------------------
-template <int W, int R, int PW>
+template <int W, int R, int PW, bool DBG>
 __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
                                                               int shard0, int nshards, int t_begin, int t_end,
                                                               PairArgs pa) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     while (item < n_items) {
     const int t = t_begin + item / PW;
     const int wslot = item & (PW - 1);
-    const unsigned long long t_start = ba.dbg_t ? wall_clock64() : 0ull;
+    const unsigned long long t_start = DBG ? wall_clock64() : 0ull;
     unsigned long long t_rng = 0, t_main = 0;
     int dbg_hits = 0, dbg_chunks = 0;
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     }
     const int row0 = tile.x, nrows = tile.y;
     const int fb = ba.key.fb, gb = ba.key.gb;
-    const int k0 = tile.z / (fb * gb), f0 = (tile.z / gb) % fb, g0 = tile.z % gb;
+    // fb, gb are powers of two
+    const int k0 = tile.z >> (ba.key.fb_log + ba.key.gb_log), f0 = (tile.z >> ba.key.gb_log) & (fb - 1), g0 = tile.z & (gb - 1);
     // the tile's row signatures -> LDS (rows past the tile are padding: they are compared but never pushed)
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -679,7 +681,8 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         const int c = cbase + lane;
         int my_cb = 0, my_ce = 0;
         if (c < ncand) {
-            const int delta = split_f ? c / D1 : c;
+            const int cq = (c * ba.inv_d1) >> 16;  // c / D1 for c < 64 (inv_d1 = ceil(65536 / D1))
+            const int delta = split_f ? cq : c;
             const int kp = k0 + delta;
             if (kp <= ba.kcap) {
                 const int amax = (D - delta) >> 1, bmax = amax + delta;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                 key_band(f0, f0, k0, kp, amax, bmax, fb, &fa, &fz);
                 key_band(g0, g0, k0, kp, amax, bmax, gb, &ga, &gz);
                 if (split_f) {
-                    const int fp = fa + c % D1;
+                    const int fp = fa + (c - cq * D1);
                     if (fp <= fz) {
                         my_cb = ba.start3[(kp * fb + fp) * gb + ga];
                         my_ce = ba.start3[(kp * fb + fp) * gb + gz + 1];
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (ba.dbg_t) t_rng = wall_clock64() + (unsigned long long)(my_cb & 0);  // after the range look-ups landed
+        if (DBG) t_rng = wall_clock64() + (unsigned long long)(my_cb & 0);  // after the range look-ups landed
         long long slots = 0;
         const int nc = min(64, ncand - cbase);
         // Chunk iterator over all ranges of this round: this wave takes the chunks whose running number is
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         while (va) {
             const int q = q0a + lane;                      // this lane's column
             const bool colok = q >= cta && q < cea;         // inside the range (chunks are aligned down/up)
-            dbg_chunks++;
+            if (DBG) dbg_chunks++;
             slots += (long long)nsb * SB * (min(cea, q0a + CC) - max(cta, q0a));
 #pragma unroll 1
             for (int sb = 0; sb < nsb; sb++) {
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                 // flush_hits, lane-parallel.  The queue is private to the wave: the slot comes from the ballot
                 // (v_mbcnt), the fill level is a wave-uniform register — no LDS atomic, no rescan.
                 const bool h = m <= d && colok;
-                const unsigned long long act = (pa.dbg & 2) ? 0ull : __builtin_amdgcn_ballot_w64(h);
+                const unsigned long long act = (DBG && (pa.dbg & 2)) ? 0ull : __builtin_amdgcn_ballot_w64(h);
                 if (act != 0ull) {
                     if (qn > QCAP - 64) {  // make room
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                     }
                     if (h) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = make_int2(row0 + sb * SB, q);
                     qn += __popcll(act);
-                    dbg_hits += __popcll(act);
+                    if (DBG) dbg_hits += __popcll(act);
                 }
             }
             // rotate the pipeline and fetch one more chunk
@@ -802,9 +805,9 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (ba.dbg_t) t_main = wall_clock64();
-    if (qn > 0 && !(pa.dbg & 1)) flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
-    if (ba.dbg_t && lane == 0) {
+    if (DBG) t_main = wall_clock64();
+    if (qn > 0 && !(DBG && (pa.dbg & 1))) flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
+    if (DBG && ba.dbg_t && lane == 0) {
         unsigned long long *o = ba.dbg_t + (size_t)(t * PW + wslot) * 8;
         o[0] = t_start;
         o[1] = t_rng;
@@ -1237,6 +1240,9 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.dbg_t = (pl.dbg & 4) ? pl.dbg_t : nullptr;
     ba.key.fb = pl.fb;
     ba.key.gb = pl.gb;
+    ba.key.fb_log = __builtin_ctz((unsigned)pl.fb);
+    ba.key.gb_log = __builtin_ctz((unsigned)pl.gb);
+    ba.inv_d1 = (65536 + pl.d) / (pl.d + 1);  // ceil(65536 / (d + 1)); only used while (d+1)^2 <= 64
     ba.kcap = pl.kcap;
     ba.d = pl.d;
     // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
@@ -1245,21 +1251,25 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     const int grid = std::max(1, (int)std::min<long long>(span, pl.pf_blocks));  // every rank walks all tiles, skips foreign cells
 
 #define PF_CASE_PW(W, R, PW)                                                                                       \
-    hipLaunchKernelGGL((k_prefilter<W, R, PW>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard, pl.n_shards,  \
-                       t_begin, t_end, pa)
+    if (pl.dbg)                                                                                                    \
+        hipLaunchKernelGGL((k_prefilter<W, R, PW, true>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard,      \
+                           pl.n_shards, t_begin, t_end, pa);                                                       \
+    else                                                                                                           \
+        hipLaunchKernelGGL((k_prefilter<W, R, PW, false>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard,     \
+                           pl.n_shards, t_begin, t_end, pa)
 #define PF_CASE(W, R) PF_CASE_PW(W, R, 2)
     // waves per tile: 2, or 4 for 64-row tiles of small inputs (there a tile is ~8 chunks and the kernel time is
     // set by the busiest SIMD: four waves on four SIMDs per tile even that out; large inputs are throughput-
     // bound and the extra per-wave set-up only costs)
     const bool pw4 = pl.pf_waves == 4;
     switch (pl.w1 * 10 + pl.rows_per_lane) {
-        case 11: if (pw4) PF_CASE_PW(1, 1, 4); else PF_CASE(1, 1); break;
+        case 11: if (pw4) { PF_CASE_PW(1, 1, 4); } else { PF_CASE(1, 1); } break;
         case 12: PF_CASE(1, 2); break;
         case 14: PF_CASE(1, 4); break;
-        case 21: if (pw4) PF_CASE_PW(2, 1, 4); else PF_CASE(2, 1); break;
+        case 21: if (pw4) { PF_CASE_PW(2, 1, 4); } else { PF_CASE(2, 1); } break;
         case 22: PF_CASE(2, 2); break;
         case 24: PF_CASE(2, 4); break;
-        case 41: if (pw4) PF_CASE_PW(4, 1, 4); else PF_CASE(4, 1); break;
+        case 41: if (pw4) { PF_CASE_PW(4, 1, 4); } else { PF_CASE(4, 1); } break;
         case 42: PF_CASE(4, 2); break;
         default: PF_CASE(4, 4); break;
     }
@@ -1306,6 +1316,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     KeyCfg key;
     key.fb = pl.fb;
     key.gb = pl.gb;
+    key.fb_log = __builtin_ctz((unsigned)pl.fb);
+    key.gb_log = __builtin_ctz((unsigned)pl.gb);
     // rows per wave of k_sig: at most 16, and for small inputs few enough that every CU holds two blocks
     // (512 blocks x 16 waves co-resident): block-granular imbalance would otherwise cost up to 30%
     const int rpw = max(1, min(16, (n + 8191) / 8192));
