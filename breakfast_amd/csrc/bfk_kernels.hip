@@ -729,25 +729,25 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
             }
         };
         advance();
-        // Column signatures: one coalesced load per chunk (64 columns, one per lane), FOUR chunks in flight
-        // (a chunk's compare is ~0.3 us, a load from L2 1-2 us).
-        int q0a = 0, cta = 0, cea = 0, q0b = 0, ctb = 0, ceb = 0, q0c = 0, ctc = 0, cec = 0, q0d = 0, ctd = 0, ced = 0;
-        bool va = false, vb = false, vc = false, vd = false;
-        uint32_t xa[W], xb[W], xc[W], xd[W];
+        // Column signatures: one coalesced load per chunk (64 columns, one per lane).  The NEXT chunk is requested
+        // before this chunk is compared and first touched after it (the register hand-over at the bottom of the
+        // loop), so its round trip overlaps the compare.  (An earlier version kept four chunks in flight but
+        // rotated them through registers at the top of the loop: the rotation reads every pending register, so
+        // the wave waited for the chunk it had requested a moment before — no overlap at all.)  The load is
+        // unconditional from a clamped address, so nothing sits in a branch.
+        int q0a = 0, cta = 0, cea = 0, q0b = 0, ctb = 0, ceb = 0;
+        bool va = false, vb = false;
+        uint32_t xa[W], xb[W];
 #define PF_FETCH(q0x, ctx, cex, valid, xx)                                                \
     valid = it_ci < nc;                                                                   \
-    if (valid) {                                                                          \
-        q0x = it_q0;                                                                      \
-        ctx = it_ctrue;                                                                   \
-        cex = it_cend;                                                                    \
-        _Pragma("unroll") for (int x = 0; x < W; x++) xx[x] = sig1[(size_t)min(it_q0 + lane, n) * W + x]; \
-        advance();                                                                        \
-    }
+    q0x = it_q0;                                                                          \
+    ctx = it_ctrue;                                                                       \
+    cex = it_cend;                                                                        \
+    _Pragma("unroll") for (int x = 0; x < W; x++) xx[x] = sig1[(size_t)min(max(it_q0, 0) + lane, n) * W + x]; \
+    if (valid) advance();
         PF_FETCH(q0a, cta, cea, va, xa)
-        PF_FETCH(q0b, ctb, ceb, vb, xb)
-        PF_FETCH(q0c, ctc, cec, vc, xc)
-        PF_FETCH(q0d, ctd, ced, vd, xd)
         while (va) {
+            PF_FETCH(q0b, ctb, ceb, vb, xb)
             const int q = q0a + lane;                      // this lane's column
             const bool colok = q >= cta && q < cea;         // inside the range (chunks are aligned down/up)
             if (DBG) dbg_chunks++;
@@ -777,6 +777,10 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);
+                        // drain: with an unknown number of stores in flight the compiler would wait for ALL loads
+                        // (vmcnt(0)) at every sub-batch, i.e. for the chunk requested a moment ago; after a full
+                        // drain it can count again
+                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                         qn = 0;
                     }
                     if (h) myq[qn + __popcll(act & ((1ull << lane) - 1ull))] = make_int2(row0 + sb * SB, q);
@@ -784,17 +788,10 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                     if (DBG) dbg_hits += __popcll(act);
                 }
             }
-            // rotate the pipeline and fetch one more chunk
+            // hand over the chunk that was in flight during the compare
             q0a = q0b; cta = ctb; cea = ceb; va = vb;
-            q0b = q0c; ctb = ctc; ceb = cec; vb = vc;
-            q0c = q0d; ctc = ctd; cec = ced; vc = vd;
 #pragma unroll
-            for (int x = 0; x < W; x++) {
-                xa[x] = xb[x];
-                xb[x] = xc[x];
-                xc[x] = xd[x];
-            }
-            PF_FETCH(q0d, ctd, ced, vd, xd)
+            for (int x = 0; x < W; x++) xa[x] = xb[x];
         }
 #undef PF_FETCH
         if (lane == 0) {  // plain store (no statistics atomics); later rounds (d >= 64) accumulate
