@@ -597,12 +597,12 @@ struct BandArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_prefilter<W, R, PW>: the all-pairs kernel.  One BLOCK of PW waves per tile.  A tile is up to 64*R sorted
+// k_prefilter<W, R, PW, DBG>: the all-pairs kernel.  One BLOCK of PW waves per tile.  A tile is up to 64*R sorted
 // rows of ONE (k,f,g) cell.  The columns that can be within d of those rows are, per column length
 // k' = k + delta and per column f' bucket, one contiguous range of the sorted order (the g band): every
 // lane turns one (delta, f') candidate into a column range with two start3 look-ups (all in flight at once).
-// Orientation: the COLUMNS sit in the lanes (one signature per lane, 64 consecutive columns per chunk, four
-// chunks in flight per wave) and the tile's ROWS are broadcast — cells are small (~25 rows at 100k rows), a
+// Orientation: the COLUMNS sit in the lanes (one signature per lane, 64 consecutive columns per chunk, the next
+// chunk in flight while this one is compared) and the tile's ROWS are broadcast — cells are small (~25 rows at 100k rows), a
 // column range is several cells wide, so this keeps the lanes full where rows-in-lanes would leave 60% idle.
 // The tile's row signatures are parked once in the wave's LDS slice and re-read as wave-uniform
 // ds_read_b128 broadcasts (v_xor with VGPR operands runs at full rate; an SGPR operand halves it on gfx950).
