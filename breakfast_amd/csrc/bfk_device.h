@@ -40,9 +40,9 @@ struct Counters {
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
 struct Plan {
     int n, nnz, kcap, d, w1;
-    int rows_per_lane, fb, gb;
+    int rows_per_lane, fb, gb, hb;
     int shard, n_shards;
-    int verify_grid;
+    int verify_grid, wave_table_d;  // k_verify: per-wave hash table up to this max_dist, per-group tables beyond
     int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;

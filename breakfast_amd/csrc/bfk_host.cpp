@@ -167,7 +167,8 @@ struct bfk_ctx {
     unsigned long long *d_chain = nullptr;
     int *d_start3c = nullptr;
     int hist_copies = 1;
-    int fb = KEY_BUCKETS, gb = KEY_BUCKETS;
+    int64_t hist_ints_cap = 0;
+    int fb = KEY_BUCKETS, gb = KEY_BUCKETS, hb = 1;
     int64_t bins3 = 0;
     uint32_t *d_gkey = nullptr;
     int *d_gcnt = nullptr;
@@ -302,12 +303,23 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     const int64_t n = c->n, nnz = c->nnz;
     // (k,f,g) sort key: KEY_BUCKETS f- and g-buckets per row length, halved (g first) for very long rows
     c->fb = c->gb = KEY_BUCKETS;
+    // third key h: only while the (d+1)^3 candidate ranges of a tile fit the 64 lanes (d <= 3) — with wider
+    // bands it would only cut the cells smaller — and only for large inputs: 16x the cells cost ~20 us more in
+    // k_sig / k_cells and make the tiles small (measured: 0.113 vs 0.079 ms at 100k rows, 0.299 vs 0.237 ms at
+    // 400k, but 0.533 vs 0.697 ms at 1M rows, where the pair kernel is throughput-bound)
+    c->hb = (n >= 600000 && (int64_t)(d_hint + 1) * (d_hint + 1) * (d_hint + 1) <= 64) ? KEY_BUCKETS : 1;
+    if (const char *e = getenv("BFK_KEY_H")) c->hb = atoi(e) > 1 ? KEY_BUCKETS : 1;
+    while (((int64_t)c->kcap + 1) * c->fb * c->gb * c->hb > KEY_MAX_BINS3 && c->hb > 1) c->hb >>= 1;
     while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->gb > 1) c->gb >>= 1;
     while (((int64_t)c->kcap + 1) * c->fb * c->gb > KEY_MAX_BINS3 && c->fb > 1) c->fb >>= 1;
-    const int64_t bins3 = ((int64_t)c->kcap + 1) * c->fb * c->gb + 2;
+    const int64_t bins3 = ((int64_t)c->kcap + 1) * c->fb * c->gb * c->hb + 2;
     if (bins3 > (int64_t)INT32_MAX / 2) return fail(BFK_EARG, "row too long for the sort-key index");
     c->bins3 = bins3;
-    if (bins3 > c->bins_cap || !c->d_head) {
+    // the cell histogram is kept in several copies (k_sig block b counts into copy b % copies: the returning
+    // atomics of the hub cells serialise per address): 8 while the cells are few and the hubs big, 2 with the
+    // third key (16x the cells, hubs ~5x smaller), 1 beyond 2M cells
+    const int want_copies = bins3 <= (1 << 16) ? 8 : (bins3 <= (1 << 21) ? 2 : 1);
+    if (bins3 > c->bins_cap || (int64_t)want_copies * bins3 > c->hist_ints_cap || !c->d_head) {
         for (void *q : {(void *)c->d_head, (void *)c->d_start3, (void *)c->d_start3c, (void *)c->d_chain})
             if (q) (void)hipFree(q);
         c->d_head = nullptr;
@@ -315,16 +327,17 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         c->d_start3c = nullptr;
         c->d_chain = nullptr;
         c->bins_cap = 0;
-        // the histogram is kept in 8 copies while that is cheap (<= 32 MiB): see k_cells
-        c->hist_copies = bins3 <= (1 << 20) ? 8 : 1;
-        size_t head = sizeof(Counters) + (size_t)bins3 * 4 * c->hist_copies;
+        c->hist_ints_cap = (int64_t)want_copies * bins3;
+        size_t head = sizeof(Counters) + (size_t)c->hist_ints_cap * 4;
         if (hipMalloc((void **)&c->d_head, head) != hipSuccess || hipMalloc((void **)&c->d_start3, (size_t)bins3 * 4) != hipSuccess ||
-            hipMalloc((void **)&c->d_start3c, (size_t)bins3 * 4 * c->hist_copies) != hipSuccess ||
+            hipMalloc((void **)&c->d_start3c, (size_t)c->hist_ints_cap * 4) != hipSuccess ||
             hipMalloc((void **)&c->d_chain, (size_t)(bins3 / 1024 + 2) * 8) != hipSuccess)
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins3;
         c->need_zero = true;
     }
+    if (c->hist_copies != want_copies) c->need_zero = true;  // another stride: the copies must be clean
+    c->hist_copies = want_copies;
     (void)nnz;
     {   // k_verify_long: pairs of very long rows that do not fit the 64 KiB LDS table use a global scratch table
         c->gslots = 0;
@@ -449,11 +462,14 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.rows_per_lane = c->rows_per_lane;
     pl.fb = c->fb;
     pl.gb = c->gb;
+    pl.hb = c->hb;
     pl.shard = shard;
     pl.n_shards = n_shards;
     // x 16 groups, a multiple of CAND_SHARDS; measured best of 1024..4096: 6 blocks per CU with the per-wave table
     // (d <= 2, 100k rows), 2048 with per-group tables (d = 5, 1M rows)
-    pl.verify_grid = max_dist <= 2 ? 1536 : 2048;
+    pl.wave_table_d = 1;  // d = 2: pairs with two separate insertions fail the certificate (0.17 vs 0.26 ms at 100k rows)
+    if (const char *e = getenv("BFK_WAVE_TABLE_D")) pl.wave_table_d = atoi(e);
+    pl.verify_grid = max_dist <= pl.wave_table_d ? 1536 : 2048;
     if (const char *e = getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, std::max(32, atoi(e) / 32 * 32));
     pl.blk_stats = c->d_blk_stats;
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
@@ -507,7 +523,7 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.labels = (int *)d_labels_out;
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
-        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->bins_cap * 4 * c->hist_copies, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->hist_ints_cap * 4, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_chain, 0, (size_t)(c->bins_cap / 1024 + 2) * 8, c->stream));
         c->need_zero = false;
     }
@@ -638,7 +654,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
         if (out) {  // pairs of the reference's length band (|k_i - k_j| <= d): row counts per length from start3
             const int planes = c->kcap + 2;
-            const size_t pitch = (size_t)c->fb * c->gb * sizeof(int);
+            const size_t pitch = (size_t)c->fb * c->gb * c->hb * sizeof(int);
             std::vector<int> sk((size_t)planes);
             HIP_TRY(hipMemcpy2D(sk.data(), sizeof(int), c->d_start3, pitch, sizeof(int), (size_t)planes, hipMemcpyDeviceToHost));
             const int d = c->last_d;

@@ -108,16 +108,19 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
 // (The reference bands by length only: np.isclose(n, q, atol=d), breakfast.py:250.)  f, g ~ Binomial(k, 1/2)
 // (sigma ~ 3 at k = 40), so each of the two keys cuts the pair slots by ~2.5x at d = 1.
 // f and g are stored as buckets: v - (k/2 - nb/2) clamped to [0, nb) (a window centred on the mean).
+// For small d — while the (d+1)^3 candidate ranges of a tile still fit the 64 lanes — a third statistic h of
+// the same kind is the least significant part of the key (k, f, g, h): another ~3x fewer pair slots (measured
+// on the 100k / 400k benchmark inputs: 7.9e7 -> 2.5e7, 9.9e8 -> 2.5e8 tile-padded slots).
 // ------------------------------------------------------------------------------------------------
 
 struct KeyCfg {
-    int fb, gb;  // buckets per row length for f and g (powers of two; 1 = key unused)
-    int fb_log, gb_log;
+    int fb, gb, hb;  // buckets per row length for f, g and h (powers of two; 1 = key unused)
+    int fb_log, gb_log, hb_log;
 };
 __device__ __forceinline__ int key_center(int k, int nb) { return (k >> 1) - (nb >> 1); }
 __device__ __forceinline__ int key_bucket(int v, int k, int nb) { return min(max(v - key_center(k, nb), 0), nb - 1); }
-__device__ __forceinline__ int key3_of(const KeyCfg &c, int k, int f, int g) {
-    return (k * c.fb + key_bucket(f, k, c.fb)) * c.gb + key_bucket(g, k, c.gb);
+__device__ __forceinline__ int key_of(const KeyCfg &c, int k, int f, int g, int h) {
+    return ((k * c.fb + key_bucket(f, k, c.fb)) * c.gb + key_bucket(g, k, c.gb)) * c.hb + key_bucket(h, k, c.hb);
 }
 
 // bucket range [lo, hi] a column of length kp can have in one key, given the rows' bucket range [rlo, rhi]
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                                                Counters *ctr, int dbg, int cells, int copies) {
     constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
     constexpr int MAXRPW = 16, MAXR = 16 * MAXRPW, SLOTS = 512;
-    __shared__ int s_k[MAXR], s_f[MAXR], s_g[MAXR];
+    __shared__ int s_k[MAXR], s_f[MAXR], s_g[MAXR], s_h[MAXR];
     __shared__ uint32_t s_s1[MAXR * W1], s_s2[MAXR * SIG2_WORDS];
     __shared__ int t_key[SLOTS], t_cnt[SLOTS];
     static_assert(SIG2_WORDS == 2, "second-level signature = 64 bits");
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
             uint32_t s1[W1], s2all = 0, s2hi = 0;
 #pragma unroll
             for (int w = 0; w < W1; w++) s1[w] = 0;
-            int f = 0, g = 0;
+            int f = 0, g = 0, hc = 0;
             for (int j0 = 0; j0 < k; j0 += 64) {
                 const int rem = k - j0;  // wave-uniform
                 const uint32_t x = j0 == 0 ? xfirst : ((lane < rem) ? indices[b + j0 + lane] : 0u);
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                 const uint32_t h1 = sig_h1(x), h2 = sig_h2(h1);
                 f += __popcll(__builtin_amdgcn_ballot_w64((int)h2 < 0) & vm);
                 g += __popcll(__builtin_amdgcn_ballot_w64((h2 & 0x40000000u) != 0u) & vm);
+                hc += __popcll(__builtin_amdgcn_ballot_w64((h1 & 0x00100000u) != 0u) & vm);
                 const uint32_t b1 = h1 >> (32 - LOG1);
                 const uint32_t bit1 = one << (b1 & 31);
                 if (W1 == 1) {
@@ -395,12 +399,13 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                 s_k[lr] = k;
                 s_f[lr] = f;
                 s_g[lr] = g;
+                s_h[lr] = hc;
             }
         }
     } else if (nr > 0 && lane == 0) {  // no tokens at all: every row is empty
         for (int t = 0; t < nr; t++) {
             const int lr = wave * rpw + t;
-            s_k[lr] = s_f[lr] = s_g[lr] = 0;
+            s_k[lr] = s_f[lr] = s_g[lr] = s_h[lr] = 0;
             for (int w = 0; w < W1; w++) s_s1[lr * W1 + w] = 0;
             s_s2[lr * 2] = s_s2[lr * 2 + 1] = 0;
         }
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
     const bool live = tr < rows_per_block && i < n;
     int slot = 0, lrk = 0;
     if (live) {
-        const int key3 = key3_of(key, s_k[tr], s_f[tr], s_g[tr]);
+        const int key3 = key_of(key, s_k[tr], s_f[tr], s_g[tr], s_h[tr]);
         rowkey[i] = key3;
         parent[i] = i;
 #pragma unroll
@@ -593,7 +598,7 @@ struct BandArgs {
     const int4 *tiles;
     int *tile_slots;  // per tile: pair slots evaluated (statistics, summed by the host)
     KeyCfg key;
-    int kcap, d, inv_d1;
+    int kcap, d, inv_d1, inv_d2;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -661,9 +666,11 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         continue;
     }
     const int row0 = tile.x, nrows = tile.y;
-    const int fb = ba.key.fb, gb = ba.key.gb;
-    // fb, gb are powers of two
-    const int k0 = tile.z >> (ba.key.fb_log + ba.key.gb_log), f0 = (tile.z >> ba.key.gb_log) & (fb - 1), g0 = tile.z & (gb - 1);
+    const int fb = ba.key.fb, gb = ba.key.gb, hb = ba.key.hb;
+    // fb, gb, hb are powers of two
+    const int h0 = tile.z & (hb - 1), g0 = (tile.z >> ba.key.hb_log) & (gb - 1);
+    const int f0 = (tile.z >> (ba.key.hb_log + ba.key.gb_log)) & (fb - 1);
+    const int k0 = tile.z >> (ba.key.hb_log + ba.key.gb_log + ba.key.fb_log);
     // the tile's row signatures -> LDS (rows past the tile are padding: they are compared but never pushed)
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -672,32 +679,49 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         for (int x = 0; x < W; x++) myrow[(r * 64 + lane) * W + x] = sig1[(size_t)p * W + x];
     }
     const int nsb = (nrows + SB - 1) / SB;
-    // Candidate column ranges, one per lane (all look-ups in flight together): candidate c = (delta, f' slot);
-    // with (d+1)^2 > 64 candidates the f' split is dropped (one range per column length, all g).
+    // Candidate column ranges, one per lane (all look-ups in flight together).  The finest split that fits the
+    // 64 lanes is used: mode 3 = one range per (delta, f', g') with the h band contiguous inside (needs the
+    // third key and (d+1)^3 <= 64), mode 2 = one per (delta, f') covering the g band and every h,
+    // mode 1 = one per column length.
     const int D = (int)d, D1 = D + 1;
-    const bool split_f = D1 * D1 <= 64;
-    const int ncand = split_f ? D1 * D1 : D1;
+    const int mode = (hb > 1 && D1 * D1 * D1 <= 64) ? 3 : (D1 * D1 <= 64 ? 2 : 1);
+    const int ncand = mode == 3 ? D1 * D1 * D1 : (mode == 2 ? D1 * D1 : D1);
     for (int cbase = 0; cbase < ncand; cbase += 64) {  // more than 64 candidates only when d >= 64
         const int c = cbase + lane;
         int my_cb = 0, my_ce = 0;
         if (c < ncand) {
-            const int cq = (c * ba.inv_d1) >> 16;  // c / D1 for c < 64 (inv_d1 = ceil(65536 / D1))
-            const int delta = split_f ? cq : c;
+            // c -> (delta, fi, gi) without divisions: 16-bit reciprocals of D1 and D1^2 (c < 64)
+            int delta = c, fi = 0, gi = 0;
+            if (mode == 3) {
+                delta = (c * ba.inv_d2) >> 16;
+                const int r = c - delta * D1 * D1;
+                fi = (r * ba.inv_d1) >> 16;
+                gi = r - fi * D1;
+            } else if (mode == 2) {
+                delta = (c * ba.inv_d1) >> 16;
+                fi = c - delta * D1;
+            }
             const int kp = k0 + delta;
             if (kp <= ba.kcap) {
                 const int amax = (D - delta) >> 1, bmax = amax + delta;
-                int fa, fz, ga, gz;
+                int fa, fz, ga, gz, ha, hz;
                 key_band(f0, f0, k0, kp, amax, bmax, fb, &fa, &fz);
                 key_band(g0, g0, k0, kp, amax, bmax, gb, &ga, &gz);
-                if (split_f) {
-                    const int fp = fa + (c - cq * D1);
+                key_band(h0, h0, k0, kp, amax, bmax, hb, &ha, &hz);
+                const int fp = fa + fi, gp = ga + gi;
+                if (mode == 3) {
+                    if (fp <= fz && gp <= gz) {
+                        my_cb = ba.start3[((kp * fb + fp) * gb + gp) * hb + ha];
+                        my_ce = ba.start3[((kp * fb + fp) * gb + gp) * hb + hz + 1];
+                    }
+                } else if (mode == 2) {
                     if (fp <= fz) {
-                        my_cb = ba.start3[(kp * fb + fp) * gb + ga];
-                        my_ce = ba.start3[(kp * fb + fp) * gb + gz + 1];
+                        my_cb = ba.start3[((kp * fb + fp) * gb + ga) * hb];
+                        my_ce = ba.start3[((kp * fb + fp) * gb + gz + 1) * hb];
                     }
                 } else {
-                    my_cb = ba.start3[(kp * fb + fa) * gb];
-                    my_ce = ba.start3[(kp * fb + fz + 1) * gb];
+                    my_cb = ba.start3[(kp * fb + fa) * gb * hb];
+                    my_ce = ba.start3[(kp * fb + fz + 1) * gb * hb];
                 }
                 my_cb = max(my_cb, row0);  // q > p >= row0
             }
@@ -958,9 +982,9 @@ __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t
 }
 
 // STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
-// all are left to k_verify_long).  WAVE_TABLE: one hash table per wave, its groups take turns (small d: nearly
+// all are left to k_verify_long).  WAVE_TABLE: one hash table per wave, its groups take turns (d <= 1: nearly
 // every candidate is certified without the table, and 8 KiB of LDS per block keeps 6+ blocks per CU resident);
-// otherwise one table per group, all four groups of a wave count in parallel (larger d: pairs with several
+// otherwise one table per group, all four groups of a wave count in parallel (d >= 2: pairs with several
 // separate insertions fail the single-shift certificate).
 template <int STEPS, bool WAVE_TABLE>
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap, int *blk_stats) {
@@ -1237,9 +1261,15 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.dbg_t = (pl.dbg & 4) ? pl.dbg_t : nullptr;
     ba.key.fb = pl.fb;
     ba.key.gb = pl.gb;
+    ba.key.hb = pl.hb;
     ba.key.fb_log = __builtin_ctz((unsigned)pl.fb);
     ba.key.gb_log = __builtin_ctz((unsigned)pl.gb);
+    ba.key.hb_log = __builtin_ctz((unsigned)pl.hb);
     ba.inv_d1 = (65536 + pl.d) / (pl.d + 1);  // ceil(65536 / (d + 1)); only used while (d+1)^2 <= 64
+    {
+        const long long d2 = (long long)(pl.d + 1) * (pl.d + 1);
+        ba.inv_d2 = (int)((65536 + d2 - 1) / d2);  // only used while (d+1)^3 <= 64
+    }
     ba.kcap = pl.kcap;
     ba.d = pl.d;
     // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
@@ -1277,7 +1307,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     {   // 16-token steps covering the longest row a pair of k_verify can have
         const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
 #define VF_CASE(S)                                                                                                        \
-    if (pl.d <= 2)                                                                                                        \
+    if (pl.d <= pl.wave_table_d)                                                                                          \
         hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
                            pl.blk_stats);                                                                                 \
     else                                                                                                                  \
@@ -1313,8 +1343,10 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     KeyCfg key;
     key.fb = pl.fb;
     key.gb = pl.gb;
+    key.hb = pl.hb;
     key.fb_log = __builtin_ctz((unsigned)pl.fb);
     key.gb_log = __builtin_ctz((unsigned)pl.gb);
+    key.hb_log = __builtin_ctz((unsigned)pl.hb);
     // rows per wave of k_sig: at most 16, and for small inputs few enough that every CU holds two blocks
     // (512 blocks x 16 waves co-resident): block-granular imbalance would otherwise cost up to 30%
     const int rpw = max(1, min(16, (n + 8191) / 8192));
@@ -1326,7 +1358,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     ca.chain = pl.chain;
     ca.ctr = pl.ctr;
     ca.n = n;
-    ca.cells = (pl.kcap + 1) * pl.fb * pl.gb;
+    ca.cells = (pl.kcap + 1) * pl.fb * pl.gb * pl.hb;
     ca.tr_shift = 6 + (pl.rows_per_lane == 1 ? 0 : (pl.rows_per_lane == 2 ? 1 : 2));
     ca.start3c = pl.start3c;
     const int cell_blocks = (ca.cells + 1023) / 1024;
@@ -1341,6 +1373,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
                            copies);                                                                                       \
         if (copies == 8)                                                                                                  \
             hipLaunchKernelGGL(k_cells<8>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
+        else if (copies == 2)                                                                                             \
+            hipLaunchKernelGGL(k_cells<2>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
         else                                                                                                              \
             hipLaunchKernelGGL(k_cells<1>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
         hipLaunchKernelGGL(k_place<W>, dim3((max(n, cell_blocks) + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap,   \
