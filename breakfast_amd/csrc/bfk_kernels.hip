@@ -48,6 +48,20 @@ __device__ __forceinline__ void st_lazy(int *p, int v) {
 // Lock-free union-find, hooks always go from the larger index to a smaller one, so a root is the
 // smallest index of its tree and parent[x] <= x.  Loads may be stale (other XCD's L2): a stale value
 // is an older, still valid ancestor or "x is a root", and the deciding step is always the CAS.
+
+// find, continuing from the already loaded cur = parent[x]
+__device__ __forceinline__ int uf_find_from(int *parent, int x, int cur) {
+    if (cur != x) {
+        int prev = x, next;
+        while (cur > (next = ld_agent(parent + cur))) {
+            st_lazy(parent + prev, next);  // path halving; only ever writes an ancestor to a non-root
+            prev = cur;
+            cur = next;
+        }
+    }
+    return cur;
+}
+
 __device__ __forceinline__ int uf_find(int *parent, int x) {
     int cur = ld_agent(parent + x);
     if (cur != x) {
@@ -62,7 +76,11 @@ __device__ __forceinline__ int uf_find(int *parent, int x) {
 }
 
 __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
-    int ra = uf_find(parent, a), rb = uf_find(parent, b);
+    // both first hops in flight together; equal parents = same tree already (in a dense graph most edges are
+    // redundant and, once the trees are compressed, end here without walking to the root)
+    const int pa = ld_agent(parent + a), pb = ld_agent(parent + b);
+    if (pa == pb) return false;
+    int ra = uf_find_from(parent, a, pa), rb = uf_find_from(parent, b, pb);
     while (ra != rb) {
         if (ra < rb) {
             int t = ra;
@@ -920,6 +938,13 @@ __device__ __forceinline__ int row16_allmin(int x) {
     x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));
     return x;
 }
+__device__ __forceinline__ int row16_allmax(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));
+    return x;
+}
 __device__ __forceinline__ int row16_allsum(int x) {
     x += __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false);
     x += __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false);
@@ -1064,8 +1089,37 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                         if ((lane >> 4) == g) dist = table_distance<STEPS, false>(mt, l16, a, b0, ka, kb);
                         want &= ~(0xFFFFull << (g * 16));
                     }
+                } else if (dist > pa.d && pa.d > 3) {
+                    dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
                 } else if (dist > pa.d) {
-                    dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);
+                    // Second certificate (d = 2, 3; with more edits allowed it rarely holds and only costs): pairs with two separate edits — e.g. one token inserted near
+                    // the front and one near the end — match under shift 0 before the first edit, under shift s
+                    // after the last, and under ONE other shift in between.  With r = last position of A that does
+                    // not match under shift s, the middle segment [t, r] is tried with shifts -1 and +1; its pairs
+                    // (i, i + sigma) are kept only while t <= i + sigma <= r + s, i.e. between the B positions
+                    // the prefix and the suffix use, so the three segments together are still a matching.
+                    int hi = -1;
+#pragma unroll
+                    for (int st = 0; st < STEPS; st++) {
+                        const int j = st * 16 + l16;
+                        if (j >= from && j < ka && !((es >> st) & 1u)) hi = j;
+                    }
+                    const int r = max(row16_allmax(hi), from - 1);
+                    const uint32_t *Bn = pa.rows + rec.w + l16;
+                    int cm = 0, cp = 0;
+#pragma unroll
+                    for (int st = 0; st < STEPS; st++) {
+                        const int j = st * 16 + l16;
+                        const bool mid = j >= t && j <= r && j < ka;
+                        const bool vm = mid && j - 1 >= t && j - 1 <= r + sft && j - 1 < kb;
+                        const bool vp = mid && j + 1 >= t && j + 1 <= r + sft && j + 1 < kb;
+                        const uint32_t xm = vm ? Bn[st * 16 - 1] : 0u, xp = vp ? Bn[st * 16 + 1] : 0u;
+                        cm += (int)(vm && a[st] == xm);
+                        cp += (int)(vp && a[st] == xp);
+                    }
+                    const int matched2 = t + max(row16_allsum(cm), row16_allsum(cp)) + (ka - 1 - r);
+                    dist = min(dist, kt - 2 * matched2);
+                    if (dist > pa.d) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
                 }
                 is_edge = dist <= pa.d;
             }
