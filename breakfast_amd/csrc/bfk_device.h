@@ -50,10 +50,11 @@ struct Plan {
     int *hist3, *start3, *start3c, *rowkey, *rowrank, *tile_slots, *blk_stats;
     int hist_copies;  // 8 or 1: copies of the cell histogram (k_sig block b counts into copy b % copies)
     unsigned long long *chain;
-    int *perm, *ksorted, *parent;
+    int *parent;
+    int4 *srec;  // per sorted position: {row, length, second-level signature lo, hi}
     uint32_t *gkey;
     int *gcnt;
-    uint32_t *sig1, *sig2, *sigu1, *sigu2;
+    uint32_t *sig1, *sigu1, *sigu2;
     int4 *tiles;
     int4 *cand;
     int2 *candk;

@@ -173,8 +173,9 @@ struct bfk_ctx {
     uint32_t *d_gkey = nullptr;
     int *d_gcnt = nullptr;
     int64_t gslots = 0, gkey_cap = 0, gcnt_cap = 0;
-    int *d_perm = nullptr, *d_ksorted = nullptr, *d_parent = nullptr;
-    uint32_t *d_sig1 = nullptr, *d_sig2 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
+    int *d_parent = nullptr;
+    int4 *d_srec = nullptr;
+    uint32_t *d_sig1 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
     bool need_zero = true;  // head (counters + histogram) must be memset before the next run
     int64_t rows_cap = 0;
     int4 *d_tiles = nullptr;
@@ -250,10 +251,10 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,   c->d_start3,   c->d_gkey,   c->d_perm,   c->d_sigu1,
-                    c->d_ksorted,  c->d_parent,    c->d_gcnt,   c->d_sig1,   c->d_sig2,   c->d_tiles,  c->d_rowkey,
-                    c->d_rowrank,  c->d_tile_slots, c->d_cand,  c->d_candk,    c->d_edges,  c->d_small,  c->d_sigu2,
-                    c->d_chain,    c->d_blk_stats, c->d_start3c};
+    void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,       c->d_start3, c->d_gkey,  c->d_srec,  c->d_sigu1,
+                    c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
+                    c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
+                    c->d_blk_stats, c->d_start3c};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -352,20 +353,17 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
     if (n + SIG_PAD_ROWS > c->rows_cap) {
         int64_t cap = 0, want = n + SIG_PAD_ROWS;
         int rc = 0;
-        cap = 0; rc |= dev_realloc(&c->d_perm, &cap, want);
-        cap = 0; rc |= dev_realloc(&c->d_ksorted, &cap, want);
+        cap = 0; rc |= dev_realloc(&c->d_srec, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_parent, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowkey, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_rowrank, &cap, want);
         cap = 0; rc |= dev_realloc(&c->d_sig1, &cap, want * 4);
-        cap = 0; rc |= dev_realloc(&c->d_sig2, &cap, want * SIG2_WORDS);
         cap = 0; rc |= dev_realloc(&c->d_sigu1, &cap, want * 4);
         cap = 0; rc |= dev_realloc(&c->d_sigu2, &cap, want * SIG2_WORDS);
         if (rc) return BFK_ENOMEM;
         c->rows_cap = want;
         // padded signature rows are read (never trusted): give them defined contents once
         HIP_TRY(hipMemsetAsync(c->d_sig1, 0xFF, (size_t)(want * 4 + 16) * 4, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_sig2, 0xFF, (size_t)(want * SIG2_WORDS + 16) * 4, c->stream));
     }
     {   // rows per lane of the prefilter tile: cells hold ~N/(lengths x f x g buckets) rows, a tile never crosses
         // a cell, so small inputs use 64-row tiles and only very large ones 256-row tiles
@@ -509,11 +507,9 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.chain = c->d_chain;
     pl.start3c = c->d_start3c;
     pl.hist_copies = c->hist_copies;
-    pl.perm = c->d_perm;
-    pl.ksorted = c->d_ksorted;
+    pl.srec = c->d_srec;
     pl.parent = c->d_parent;
     pl.sig1 = c->d_sig1;
-    pl.sig2 = c->d_sig2;
     pl.sigu1 = c->d_sigu1;
     pl.sigu2 = c->d_sigu2;
     pl.tiles = c->d_tiles;

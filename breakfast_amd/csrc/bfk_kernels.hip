@@ -465,9 +465,8 @@ template <int W1>
 __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, int n, int kcap,
                                                 const int *__restrict__ start3, const int *__restrict__ rowkey,
                                                 const int *__restrict__ rowrank, const uint32_t *__restrict__ sigu1,
-                                                const uint32_t *__restrict__ sigu2, int *__restrict__ perm,
-                                                int *__restrict__ ksorted, uint32_t *__restrict__ sig1,
-                                                uint32_t *__restrict__ sig2, unsigned long long *chain, int n_chain,
+                                                const uint32_t *__restrict__ sigu2, int4 *__restrict__ srec,
+                                                uint32_t *__restrict__ sig1, unsigned long long *chain, int n_chain,
                                                 int cells, int copies, int sig_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_chain) chain[i] = 0ull;  // k_cells' status words: clean for the next step
@@ -475,12 +474,13 @@ __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, i
     // start3 is start3c when copies > 1: the row was ranked inside histogram copy (its k_sig block) % copies
     const int p = start3[(size_t)((i / sig_rows) & (copies - 1)) * cells + rowkey[i]] + rowrank[i];
     const int k = indptr[i + 1] - indptr[i];
-    perm[p] = i;
-    ksorted[p] = k < 0 ? 0 : (k > kcap ? kcap : k);
+    // one 16-byte record per sorted position {row, length, 64-bit second-level signature}: a scattered store
+    // costs a whole 64-byte sector whatever its width, so the three fields travel together
+    static_assert(SIG2_WORDS == 2, "the record holds a 64-bit second-level signature");
+    const uint2 s2 = *reinterpret_cast<const uint2 *>(sigu2 + (size_t)i * 2);
+    srec[p] = make_int4(i, k < 0 ? 0 : (k > kcap ? kcap : k), (int)s2.x, (int)s2.y);
 #pragma unroll
     for (int w = 0; w < W1; w++) sig1[(size_t)p * W1 + w] = sigu1[(size_t)i * W1 + w];
-#pragma unroll
-    for (int w = 0; w < SIG2_WORDS; w++) sig2[(size_t)p * SIG2_WORDS + w] = sigu2[(size_t)i * SIG2_WORDS + w];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,9 +489,7 @@ __global__ __launch_bounds__(256) void k_place(const int *__restrict__ indptr, i
 struct PairArgs {
     const int *indptr;
     const uint32_t *rows;  // the raw CSR indices (unsorted rows, repeats kept)
-    const int *perm;
-    const int *ksorted;
-    const uint32_t *sig2;
+    const int4 *srec;  // per sorted position: {row, length, second-level signature lo, hi}
     int *parent;
     int4 *cand;   // {row a, row b, cols offset a, cols offset b}
     int2 *candk;  // {k_a, k_b}
@@ -515,14 +513,11 @@ __device__ __forceinline__ void flush_pairs(const PairArgs &a, const int2 *sbuf,
             const int2 pq = sbuf[i];
             const int p = pq.x, q = pq.y;
             if (q > p && q < a.n && p < a.n) {
-                const int kp = a.ksorted[p], kq = a.ksorted[q];
-                static_assert(SIG2_WORDS == 2, "second-level signature is read as one 64-bit word pair");
-                const uint2 x = *reinterpret_cast<const uint2 *>(a.sig2 + (size_t)p * SIG2_WORDS);
-                const uint2 y = *reinterpret_cast<const uint2 *>(a.sig2 + (size_t)q * SIG2_WORDS);
-                ra = a.perm[p];
-                rb = a.perm[q];
-                const int c = __popc(x.x ^ y.x) + __popc(x.y ^ y.y);
-                pass = (kq - kp <= a.d) && (c <= a.d);
+                const int4 rp = a.srec[p], rq = a.srec[q];
+                ra = rp.x;
+                rb = rq.x;
+                const int c = __popc((uint32_t)(rp.z ^ rq.z)) + __popc((uint32_t)(rp.w ^ rq.w));
+                pass = (rq.y - rp.y <= a.d) && (c <= a.d);
             }
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
@@ -1289,9 +1284,7 @@ static PairArgs make_pair_args(const Plan &pl) {
     PairArgs pa;
     pa.indptr = pl.indptr;
     pa.rows = pl.indices;
-    pa.perm = pl.perm;
-    pa.ksorted = pl.ksorted;
-    pa.sig2 = pl.sig2;
+    pa.srec = pl.srec;
     pa.n = pl.n;
     pa.nnz = pl.nnz;
     pa.dbg = pl.dbg;
@@ -1432,8 +1425,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         else                                                                                                              \
             hipLaunchKernelGGL(k_cells<1>, dim3(cell_blocks), dim3(1024), 0, st, ca);                                     \
         hipLaunchKernelGGL(k_place<W>, dim3((max(n, cell_blocks) + 255) / 256), dim3(256), 0, st, pl.indptr, n, pl.kcap,   \
-                           copies > 1 ? pl.start3c : pl.start3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.perm,        \
-                           pl.ksorted, pl.sig1, pl.sig2, pl.chain, cell_blocks, ca.cells, copies, rpw * 16);               \
+                           copies > 1 ? pl.start3c : pl.start3, pl.rowkey, pl.rowrank, pl.sigu1, pl.sigu2, pl.srec,        \
+                           pl.sig1, pl.chain, cell_blocks, ca.cells, copies, rpw * 16);                                   \
         break;
         PREP_CASE(1)
         PREP_CASE(2)
