@@ -33,8 +33,11 @@ namespace bfk {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
+// loads of the union-find forest: system scope (sc0 sc1), i.e. past this XCD's L2.  With agent scope a node
+// hooked by another XCD kept looking like a root here, which cost a failed CAS per such node (measured: -7% on
+// the verify kernel at d = 2, 3; nothing at d = 1, where every node is hooked once)
 __device__ __forceinline__ int ld_agent(const int *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ uint32_t ld_agent_u(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
