@@ -479,6 +479,8 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.tile_hint = (int)std::min<int64_t>(pl.tile_cap, c->last_tiles > 0 ? c->last_tiles + c->last_tiles / 8 + 64
                                                                           : std::max<int64_t>(4096, c->n / 8));
     pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
+    if (const char *e = getenv("BFK_CAND_CAP_SHARD"))  // test knob: a small queue forces the overflow recovery path
+        pl.cand_cap_shard = std::max(1, std::min(pl.cand_cap_shard, atoi(e)));
     pl.edge_cap = (int)std::min<int64_t>(c->edge_cap, INT32_MAX);
     pl.gkey = c->d_gkey;
     pl.gcnt = c->d_gcnt;

@@ -493,3 +493,23 @@ def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monk
     got, st = _lib.cluster_csr(indptr, indices, d)
     assert np.array_equal(got, want)
     assert st["n_edges"] == st0["n_edges"] and st["n_candidates"] >= st["n_edges"]
+
+
+@pytest.mark.parametrize("cap,d", [(64, 2), (16, 3), (4, 1)])
+def test_candidate_queue_overflow_is_recovered(cap, d, monkeypatch):
+    """a queue far too small for the input: dropped candidates raise the device flag, bfk_ctx_sync re-runs
+    prefilter + verify over slices of the tile list until every slice fits (unions are idempotent), and the
+    labels, the edge count and the neighbour lists must come out as with a queue that fits"""
+    rows = generate_profiles(12000, p_del=0.05, p_ins=0.02)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want, st0 = _lib.cluster_csr(indptr, indices, d)
+    assert st0["n_retry_slices"] == 0
+    ptr0, idx0 = _lib.neighbours_csr(indptr, indices, d)
+    monkeypatch.setenv("BFK_CAND_CAP_SHARD", str(cap))
+    got, st = _lib.cluster_csr(indptr, indices, d)
+    assert st["n_retry_slices"] > 0
+    assert np.array_equal(got, want)
+    assert st["n_edges"] == st0["n_edges"]
+    ptr, idx = _lib.neighbours_csr(indptr, indices, d)
+    assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
