@@ -71,6 +71,7 @@ EXPORTS = {
     "bfk_ctx_merge_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "bfk_ctx_sync": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "bfk_ctx_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "bfk_ctx_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "bfk_ctx_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "bfk_ctx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bfk_ctx_set_edge_capture": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -372,6 +373,10 @@ class Context:
         st = Stats()
         _check(self.lib.bfk_ctx_sync(self.h, C.byref(st)))
         return st.as_dict()
+
+    def upload_i32(self, h: np.ndarray, d_ptr: int):
+        h = np.ascontiguousarray(h, dtype=np.int32)
+        _check(self.lib.bfk_ctx_upload(self.h, h.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr), h.size * 4))
 
     def download_i32(self, d_ptr: int, n: int) -> np.ndarray:
         out = np.empty(max(n, 1), dtype=np.int32)

@@ -705,6 +705,15 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
     return BFK_OK;
 }
 
+extern "C" int bfk_ctx_upload(bfk_ctx *c, const void *h_src, void *d_dst, int64_t bytes) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (bytes < 0 || (bytes > 0 && (!h_src || !d_dst))) return fail(BFK_EARG, "bad upload arguments");
+    if (bytes == 0) return BFK_OK;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFK_OK;
+}
+
 extern "C" int bfk_ctx_download(bfk_ctx *c, const void *d_src, void *h_dst, int64_t bytes) {
     if (int rc = ctx_enter(c)) return rc;
     if (bytes < 0 || (bytes > 0 && (!d_src || !h_dst))) return fail(BFK_EARG, "bad download arguments");

@@ -135,6 +135,7 @@ int bfk_ctx_sync(bfk_ctx *ctx, bfk_stats *stats_out);
 
 /* device <-> host helpers on the ctx stream (synchronous) */
 int bfk_ctx_download(bfk_ctx *ctx, const void *d_src, void *h_dst, int64_t bytes);
+int bfk_ctx_upload(bfk_ctx *ctx, const void *h_src, void *d_dst, int64_t bytes);
 int bfk_ctx_device_alloc(bfk_ctx *ctx, int64_t bytes, void **d_out);
 int bfk_ctx_device_free(bfk_ctx *ctx, void *d_ptr);
 

@@ -513,3 +513,42 @@ def test_candidate_queue_overflow_is_recovered(cap, d, monkeypatch):
     assert st["n_edges"] == st0["n_edges"]
     ptr, idx = _lib.neighbours_csr(indptr, indices, d)
     assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
+
+
+def test_allreduce_min_merge_reaches_the_fix_point():
+    """the north-star merge form on one GPU: elementwise MIN of the shards' label arrays (what all_reduce(MIN)
+    delivers), united into the forest with bfk_ctx_merge_labels(n_parts=1) until the changed flag stays 0"""
+    rows = generate_profiles(15000, p_del=0.03, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n, d, n_shards = len(uf), 2, 4
+    want, _ = _lib.cluster_csr(indptr, indices, d)
+    # every "rank" = one context with its own local forest
+    ctxs, local = [], []
+    for s in range(n_shards):
+        c = _lib.Context(0)
+        c.upload_csr(indptr, indices)
+        dl = c.alloc(4 * n)
+        c.cluster(d, dl, s, n_shards)
+        c.sync()
+        ctxs.append(c)
+        local.append(c.download_i32(dl, n).copy())
+    cur = local
+    for rounds in range(1, 20):
+        red = np.minimum.reduce(cur).astype(np.int32)  # all_reduce(MIN)
+        nxt, changed = [], 0
+        for c in ctxs:
+            d_red, d_out, d_flag = c.alloc(4 * n), c.alloc(4 * n), c.alloc(4)
+            c.upload_i32(red, d_red)
+            c.merge_labels(d_red, 1, d_out, d_flag)
+            c.sync()
+            nxt.append(c.download_i32(d_out, n).copy())
+            changed |= int(c.download_i32(d_flag, 1)[0])
+        cur = nxt
+        if not changed:
+            break
+    for c in ctxs:
+        c.close()
+    assert rounds >= 2  # at least one confirming round
+    for l in cur:
+        assert np.array_equal(l, want)
