@@ -590,10 +590,13 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
                 const int mid = b + (e - b) / 2;
                 todo.push_back({mid, e});
                 todo.push_back({b, mid});
-            } else {  // cannot happen with the sizing rule of ctx_size_workspace; grow and retry anyway
-                if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
-                pl.cand = c->d_cand;
-                pl.candk = c->d_candk;
+            } else {  // one tile alone overflows the queue in use: use all of the allocation, grow it if that was all
+                const int full = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
+                if (pl.cand_cap_shard >= full) {
+                    if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
+                    pl.cand = c->d_cand;
+                    pl.candk = c->d_candk;
+                }
                 pl.cand_cap_shard = (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS);
                 todo.push_back({b, e});
             }
@@ -645,8 +648,11 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             if (int rc = ctx_pair_stats(c, &h)) return rc;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
-            // the queue was too small for this input: double it so that the next run fits in one pass
-            if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
+            // the queue was too small for this input: double it so that the next run fits in one pass (not when
+            // the run was held below the allocation by the test knob, and never beyond 256 slots per row)
+            if (c->plan.cand_cap_shard >= (int)std::min<int64_t>(c->cand_cap_shard, INT32_MAX / CAND_SHARDS) &&
+                c->cand_cap_total < 256 * std::max<int64_t>(c->n, 4096))
+                if (int rc = ctx_size_cand(c, c->cand_cap_total * 2)) return rc;
         }
         const int64_t n = c->n;
         s.pairs_resolved = n * (n - 1) / 2 / c->last_shards;
