@@ -328,12 +328,13 @@ __device__ __forceinline__ uint32_t sig_h1(uint32_t x) { return __umul24(x, 0x9E
 __device__ __forceinline__ uint32_t sig_h2(uint32_t h1) { return __umul24(h1 >> 8, 0x85EBCBu); }
 
 // One block = 16 waves = up to 256 consecutive rows (rpw rows per wave).  Phase 1: one wave per row, 64 tokens
-// per step, rows software-pipelined (all extents of the wave's rows in one load, the next row's first 64
-// tokens in flight while this row is reduced).  Phase 2 (one thread per row): key3, the coalesced row-order
-// stores, and the histogram of the (k,f,g) cells + every row's rank inside its cell.  Hub cells (the children
-// of a common ancestor: thousands of rows in 4 cells) make per-row returning atomics on one word serialise
-// (~90/us), so the block first aggregates its rows in an LDS hash table keyed by cell and reserves one range
-// per distinct cell with a single global atomic.
+// per step; the extents of all the wave's rows come in one load and the first 64 tokens of ALL its rows are
+// requested before the first row is reduced.  Phase 2, per wave (no block barrier): lane t finishes row t of the
+// wave — key, the row-order stores, and one returning atomic on the block's copy of the cell histogram, which
+// is the cell count and the row's rank inside its cell at once.  (Aggregating a block's rows per cell in an LDS
+// hash table first saved 4% of the atomics — 208 consecutive input rows rarely share a cell — for three block
+// barriers; the per-address serialisation of hub cells, ~90 returning atomics per us, is handled by the
+// histogram copies instead.)
 template <int W1>
 __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
                                                int nnz, int kcap, int rpw, KeyCfg key, int *__restrict__ rowkey,
@@ -341,17 +342,12 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
                                                uint32_t *__restrict__ sigu2, int *hist3, int *__restrict__ rowrank,
                                                Counters *ctr, int dbg, int cells, int copies) {
     constexpr int LOG1 = 5 + (W1 == 1 ? 0 : (W1 == 2 ? 1 : 2));  // bits of the first-level signature index
-    constexpr int MAXRPW = 16, MAXR = 16 * MAXRPW, SLOTS = 512;
+    constexpr int MAXRPW = 16, MAXR = 16 * MAXRPW;
     __shared__ int s_k[MAXR], s_f[MAXR], s_g[MAXR], s_h[MAXR];
     __shared__ uint32_t s_s1[MAXR * W1], s_s2[MAXR * SIG2_WORDS];
-    __shared__ int t_key[SLOTS], t_cnt[SLOTS];
     static_assert(SIG2_WORDS == 2, "second-level signature = 64 bits");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < SLOTS) {
-        t_key[threadIdx.x] = -1;
-        t_cnt[threadIdx.x] = 0;
-    }
     const int rows_per_block = rpw * 16;
     const int base = blockIdx.x * rows_per_block;
     const int r0 = base + wave * rpw;
@@ -431,35 +427,24 @@ __global__ __launch_bounds__(1024) void k_sig(const int *__restrict__ indptr, co
             s_s2[lr * 2] = s_s2[lr * 2 + 1] = 0;
         }
     }
-    __syncthreads();
-    // phase 2: one thread per row of the block
-    const int tr = threadIdx.x;
-    const int i = base + tr;  // row (wave, t) was parked at wave * rpw + t = its offset in the block
-    const bool live = tr < rows_per_block && i < n;
-    int slot = 0, lrk = 0;
-    if (live) {
+    // phase 2, per wave (no block barrier): lane t finishes row t of this wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < nr) {
+        const int tr = wave * rpw + lane;
+        const int i = r0 + lane;
         const int key3 = key_of(key, s_k[tr], s_f[tr], s_g[tr], s_h[tr]);
         rowkey[i] = key3;
         parent[i] = i;
 #pragma unroll
         for (int w = 0; w < W1; w++) sigu1[(size_t)i * W1 + w] = s_s1[tr * W1 + w];
         *reinterpret_cast<uint2 *>(sigu2 + (size_t)i * 2) = make_uint2(s_s2[tr * 2], s_s2[tr * 2 + 1]);
-        slot = (int)(((uint32_t)key3 * 0x9E3779B1u) >> 23);  // 9 bits
-        while (true) {
-            const int old = atomicCAS(&t_key[slot], -1, key3);
-            if (old == -1 || old == key3) break;
-            slot = (slot + 1) & (SLOTS - 1);
-        }
-        lrk = atomicAdd(&t_cnt[slot], 1);
+        // rank inside the cell: one returning atomic per row on the block's histogram copy
+        int rk = 0;
+        if (!(dbg & 16)) rk = atomicAdd(&hist3[(size_t)(blockIdx.x & (copies - 1)) * cells + key3], 1);
+        rowrank[i] = rk;
     }
-    __syncthreads();
-    if (tr < SLOTS) {
-        const int c = t_cnt[tr];
-        // base of this block's range among the rows of its histogram copy in the cell
-        if (c && !(dbg & 16)) t_cnt[tr] = atomicAdd(&hist3[(size_t)(blockIdx.x & (copies - 1)) * cells + t_key[tr]], c);
-    }
-    __syncthreads();
-    if (live) rowrank[i] = t_cnt[slot] + lrk;
 }
 
 // k_place: counting-sort scatter.  Row i goes to sorted position start3[key] + rank; its length and its two
