@@ -1008,8 +1008,16 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     // the slot is computed, not searched, and the shards fill evenly (the prefilter rotates over them).
     const int u = blockIdx.x * 16 + grp, U = gridDim.x * 16;
     const int shard = u & (CAND_SHARDS - 1), j0 = u / CAND_SHARDS, jstep = U / CAND_SHARDS;
-    const int cnt = (int)min(pa.ctr->ncand[shard], (unsigned)pa.cand_cap_shard);
     const size_t base = (size_t)shard * pa.cand_cap_shard;
+    // the shard's fill level and the group's first two queue records are requested together (the slots exist
+    // whatever the fill level; records beyond it are never used)
+    const int capm1 = pa.cand_cap_shard - 1;
+    const unsigned cnt_raw = pa.ctr->ncand[shard];
+    int4 rec = pa.cand[base + min(j0, capm1)];
+    int2 kk = pa.candk[base + min(j0, capm1)];
+    int4 rec_n = pa.cand[base + min(j0 + jstep, capm1)];
+    int2 kk_n = pa.candk[base + min(j0 + jstep, capm1)];
+    const int cnt = (int)min(cnt_raw, (unsigned)pa.cand_cap_shard);
     // lane i of the group keeps the group's i-th edge of the current batch; a batch is hooked when it is full and
     // at the end.  Batches of 8 at d = 2, 3, where a group sees ~10 edges: the hooks then interleave with the
     // checks of other waves instead of arriving in one burst at the end of the kernel (100k rows, d = 3: 0.35 vs
@@ -1036,10 +1044,6 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                 bs[st] = (uint32_t)(j + sft) < (uint32_t)kk.y ? Bs[st * 16] : 0u;
             }
         };
-        int4 rec = pa.cand[base + j0];
-        int2 kk = pa.candk[base + j0];
-        int4 rec_n = pa.cand[base + min(j0 + jstep, last)];
-        int2 kk_n = pa.candk[base + min(j0 + jstep, last)];
         for (int e = j0; e < cnt; e += jstep) {
             const int e2 = min(e + 2 * jstep, last);
             const int4 rec_nn = pa.cand[base + e2];
