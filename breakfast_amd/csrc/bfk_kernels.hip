@@ -90,9 +90,14 @@ __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
             ra = rb;
             rb = t;
         }
-        int old = atomicCAS(parent + ra, ra, rb);  // ra > rb
+        // Hook by atomicMin (ra > rb): it never fails.  If ra was a root (old == ra) it now hangs under rb.  If ra
+        // had been hooked under `old` meanwhile, parent[ra] becomes min(old, rb) — either way a node of the set
+        // that ra, old and rb end up in, because what is left to do is to unite old with rb, and this thread
+        // goes on to do exactly that.  (Every value ever stored in parent[x] is <= x and belongs to x's final
+        // component, also under concurrent path halving, so chains still end and labels stay canonical.)
+        const int old = atomicMin(parent + ra, rb);
         if (old == ra) return true;
-        ra = uf_find(parent, old);  // ra was no longer a root: go to the current root (cheap loads, not CASes)
+        ra = uf_find(parent, old);
     }
     return false;
 }
