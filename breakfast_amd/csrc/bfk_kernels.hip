@@ -49,8 +49,8 @@ __device__ __forceinline__ void st_lazy(int *p, int v) {
 }
 
 // Lock-free union-find, hooks always go from the larger index to a smaller one, so a root is the
-// smallest index of its tree and parent[x] <= x.  Loads may be stale (other XCD's L2): a stale value
-// is an older, still valid ancestor or "x is a root", and the deciding step is always the CAS.
+// smallest index of its tree and parent[x] <= x.  A stale load is an older, still valid ancestor or "x is a
+// root"; the deciding step is the memory-side atomic of the hook (see uf_union).
 
 // find, continuing from the already loaded cur = parent[x]
 __device__ __forceinline__ int uf_find_from(int *parent, int x, int cur) {
