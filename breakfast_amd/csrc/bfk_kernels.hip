@@ -1,13 +1,14 @@
 // bfk_kernels.hip — HIP kernels for gfx950 (MI355X, CDNA4): the breakfast clustering hot path.
 //
 // Pipeline (one stream, no host round trip and no memset between kernels):
-//   k_sig        one wave per row: sort key (k, f, g) and two XOR-parity signatures of the UNSORTED row
+//   k_sig        one wave per row: sort key (k, f, g[, h]) and two XOR-parity signatures of the UNSORTED row
 //                (a token repeated an even number of times cancels itself, so the bound holds for multisets
-//                without sorting or ranking repeats); parent[i] = i
-//                + (k,f,g) cell histogram and rank of every row inside its cell (LDS hash aggregation per block)
+//                without sorting or ranking repeats); parent[i] = i; cell histogram (in copies) and the rank of
+//                every row inside its cell by one returning atomic per row
 //   k_cells      sum of the histogram copies, scan with decoupled look-back -> start3 / start3c, tile list
 //                (tiles never cross cells); re-zeroes histogram and counters for the next step
-//   k_place      counting-sort scatter of row ids / lengths / signatures into (k,f,g) order
+//   k_place      counting-sort scatter into sort-key order: one 16-byte record {row, length, second-level
+//                signature} and the first-level signature per row
 //   k_prefilter  the pair kernel: one block per tile; the columns that can be within d of the tile's rows are
 //                a few contiguous ranges (the (k,f,g) band); popcount(sig_row ^ sig_col) <= d is a necessary
 //                condition for |A delta B| <= d; survivors pass a 64-bit second level and are queued
@@ -34,8 +35,8 @@ namespace bfk {
 // small device helpers
 // ------------------------------------------------------------------------------------------------
 // loads of the union-find forest: system scope (sc0 sc1), i.e. past this XCD's L2.  With agent scope a node
-// hooked by another XCD kept looking like a root here, which cost a failed CAS per such node (measured: -7% on
-// the verify kernel at d = 2, 3; nothing at d = 1, where every node is hooked once)
+// hooked by another XCD kept looking like a root here, which cost a wasted hook attempt per such node (measured:
+// -7% on the verify kernel at d = 2, 3; nothing at d = 1, where every node is hooked once)
 __device__ __forceinline__ int ld_agent(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
