@@ -433,7 +433,13 @@ extern "C" int bfk_ctx_upload_csr(bfk_ctx *c, const int32_t *indptr, const int32
     return ctx_after_bind(c);
 }
 
-static int sig_words_for(int d) { return d <= 2 ? 1 : (d <= 5 ? 2 : 4); }
+static int sig_words_for(int d) {
+    if (const char *e = getenv("BFK_SIG_WORDS")) {
+        const int w = atoi(e);
+        if (w == 1 || w == 2 || w == 4) return w;
+    }
+    return d <= 2 ? 1 : (d <= 5 ? 2 : 4);
+}
 
 extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out) {
     if (int rc = ctx_enter(c)) return rc;
