@@ -477,7 +477,8 @@ def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
                                  {"BFK_VERIFY_GRID": "32"}, {"BFK_VERIFY_GRID": "8192"}, {"BFK_KEY_H": "16"},
                                  {"BFK_KEY_H": "16", "BFK_PF_ROWS": "2"}, {"BFK_UNION_BATCH": "2"},
                                  {"BFK_UNION_BATCH": "4"}, {"BFK_UNION_BATCH": "16"}, {"BFK_WAVE_TABLE_D": "3"},
-                                 {"BFK_WAVE_TABLE_D": "0"}])
+                                 {"BFK_WAVE_TABLE_D": "0"}, {"BFK_SIG_WORDS": "1"}, {"BFK_SIG_WORDS": "2"},
+                                 {"BFK_SIG_WORDS": "4", "BFK_PF_ROWS": "2"}])
 @pytest.mark.parametrize("d", [1, 2, 3, 4])
 def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monkeypatch):
     """128- and 256-row tiles (chosen above 2M / 8M rows), 2 and 4 waves per tile, extreme verify grids, the
