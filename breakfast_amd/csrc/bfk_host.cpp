@@ -492,6 +492,14 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     pl.gcnt = c->d_gcnt;
     pl.gslots = (unsigned)c->gslots;
     pl.dbg = getenv("BFK_PF_DEBUG") ? atoi(getenv("BFK_PF_DEBUG")) : 0;
+#ifndef BFK_WITH_PF_DEBUG
+    if (pl.dbg & 7) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "[bfk] BFK_PF_DEBUG needs a library built with `make PF_DEBUG=1`; ignored\n");
+        told = true;
+        pl.dbg &= ~7;
+    }
+#endif
     pl.dbg_t = nullptr;
     if (pl.dbg & 4) {
         static unsigned long long *dbg_buf = nullptr;

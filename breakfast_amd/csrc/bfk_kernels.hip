@@ -1332,6 +1332,9 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     const long long span = (long long)std::min(std::min(t_end, pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
     const int grid = std::max(1, (int)std::min<long long>(span, pl.pf_blocks));  // every rank walks all tiles, skips foreign cells
 
+// the instrumented instantiations (BFK_PF_DEBUG: per-wave stamps, phase switches) double the code of the pair
+// kernel: they are compiled only with `make PF_DEBUG=1`
+#ifdef BFK_WITH_PF_DEBUG
 #define PF_CASE_PW(W, R, PW)                                                                                       \
     if (pl.dbg)                                                                                                    \
         hipLaunchKernelGGL((k_prefilter<W, R, PW, true>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard,      \
@@ -1339,6 +1342,11 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     else                                                                                                           \
         hipLaunchKernelGGL((k_prefilter<W, R, PW, false>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard,     \
                            pl.n_shards, t_begin, t_end, pa)
+#else
+#define PF_CASE_PW(W, R, PW)                                                                                       \
+    hipLaunchKernelGGL((k_prefilter<W, R, PW, false>), dim3(grid), dim3(PW * 64), 0, st, pl.sig1, ba, n, pl.shard,         \
+                       pl.n_shards, t_begin, t_end, pa)
+#endif
 #define PF_CASE(W, R) PF_CASE_PW(W, R, 2)
     // waves per tile: 2, or 4 for 64-row tiles of small inputs (there a tile is ~8 chunks and the kernel time is
     // set by the busiest SIMD: four waves on four SIMDs per tile even that out; large inputs are throughput-
