@@ -18,6 +18,8 @@ constexpr int VERIFY_TABLE = 256;       // hash-table slots per 16-lane group in
 constexpr int VERIFY_MAX_TOKENS = 192;  // pairs with more tokens (both rows) go to k_verify_long
 constexpr int LONG_TABLE = 4096;        // hash-table slots in LDS per block of k_verify_long (32 KiB)
 constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long (each owns a slice of the global scratch table)
+constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-join table {tag : row}
+constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 
@@ -27,7 +29,8 @@ struct Counters {
     int err_rows;  // set by k_sig (row longer than at bind time); cleared by the host only
     unsigned int n_work;   // tiles
     unsigned int ticket;   // arrival order of the k_cells blocks
-    unsigned int pad0;
+    unsigned int n_dup;    // variant join: entries of the dup list (k_jhash fills, k_join reads, k_flatten resets)
+    int join_fail;         // variant join gave up (probe chain too long): the host re-runs on the all-pairs path
     int overflow;
     unsigned long long pairs_in_band;
     unsigned long long pairs_filtered;
@@ -35,6 +38,19 @@ struct Counters {
     unsigned long long n_edges;
     unsigned long long n_edges_cap;
     unsigned long long dbg[8];  // phase stamps of k_plan (s_memrealtime, 100 MHz), printed with BFK_DEBUG=1
+};
+
+// variant join (max_dist == 1): table / bitmap of this step, the set to clear for the next step, row hashes
+struct JoinArgs {
+    unsigned long long *tab, *tab_next;  // mask + 1 slots
+    uint32_t *bits, *bits_next;          // bmask + 1 bits, index = low bits of H.x
+    uint2 *rowhash;
+    int2 *dups;  // pairs of rows with one H, found while inserting
+    int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
+    uint32_t mask, bmask;
+    int dup_cap;
+    int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no bitmap test,
+              // 8 no table insert, 16 no clearing, 32 no unions
 };
 
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
@@ -62,6 +78,9 @@ struct Plan {
     int *labels;
     Counters *ctr;
     unsigned long long *dbg_t;
+    int join_grid;  // most blocks of k_join (it strides over the blocks of rows)
+    int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
+    JoinArgs ja;
 };
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);

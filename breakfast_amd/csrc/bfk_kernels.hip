@@ -1214,11 +1214,432 @@ __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey
 }
 
 // ------------------------------------------------------------------------------------------------
+// The variant join (max_dist == 1): sub-quadratic candidate generation.
+//   Two rows are within distance 1 iff they are equal as multisets or one is the other plus ONE token occurrence.
+//   With an additive multiset hash H(row) = (sum h1(t), sum h2(t)) mod 2^32 each, B = A + {t} implies
+//   H(A) = H(B) - h(t) EXACTLY, so: k_jhash puts every row into a hash table keyed by H (and sets one bit of a
+//   presence bitmap); k_join looks up H(B) - h(t) for every token occurrence t of every row B (first the bitmap —
+//   one dependent load, 97% of the lookups end there — then the table), plus H(B) itself for equal multisets.
+//   No pair within distance 1 can be missed; every table match goes through the same exact check as the
+//   all-pairs path (k_verify), so hash collisions cost time, never results.  O(nnz) lookups instead of O(N^2)
+//   signature compares.  A lookup chain longer than JOIN_MAX_PROBE (hundreds of rows that are the same multiset
+//   in different orders) raises Counters::join_fail and the host re-runs the step on the all-pairs path.
+//   The table and bitmap exist twice: the set of the NEXT step is cleared by this step's k_jhash.
+// ------------------------------------------------------------------------------------------------
+// token hashes of the row hash: NONLINEAR (with plain multiplicative hashes the additive row hash would be a
+// function of the token sum and rows with equal sums would all look alike) and built from v_mul_u32_u24, which
+// issues at full rate (v_mul_lo_u32 is quarter rate; with two 32-bit multiplies per hash the hashing alone was
+// ~8 us of k_jhash at 100k rows).  Only the low 24 bits of a token id enter: ids that differ above bit 23 share
+// their hashes, which costs false candidates and never a result.
+__device__ __forceinline__ uint32_t jh_stage(uint32_t x) {
+    uint32_t a = __umul24(x, 0xB5297Au);
+    return a ^ (a >> 16);
+}
+__device__ __forceinline__ uint32_t jh1_of(uint32_t a) {
+    a = __umul24(a, 0x68E31Du) + (a >> 9);
+    return a ^ (a >> 15);
+}
+__device__ __forceinline__ uint32_t jh2_of(uint32_t a) {
+    a = __umul24(a ^ 0x5BD1E9u, 0x1B873Bu) + (a >> 7);
+    return a ^ (a >> 13);
+}
+__device__ __forceinline__ uint32_t jh1(uint32_t x) { return jh1_of(jh_stage(x)); }
+__device__ __forceinline__ uint32_t jh2(uint32_t x) { return jh2_of(jh_stage(x)); }
+
+// sum over the 64 lanes, valid in lane 63 (same DPP pattern as wave_xor_to_lane63)
+__device__ __forceinline__ uint32_t wave_add_to_lane63(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);
+    return x;
+}
+
+// k_jhash: same row-to-wave layout as k_sig.  H of every row -> rowhash[i], bitmap bit, table entry
+// {H.y (tag) : row} by linear probing (load <= 1/8: 94% of the inserts take one CAS); parent[i] = i; counters
+// reset; next step's table set cleared.  A failed CAS returns the entry in the way: if its tag is this row's, the
+// two rows are (up to a 64-bit hash collision) the same multiset — the pair goes to the dup list, so k_join needs
+// no lookup of H itself.  Entries with one H start probing at the same slot, so the later row passes every
+// earlier one: each such pair is listed exactly once.
+__global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
+                                                 int nnz, int kcap, int rpw, JoinArgs ja, int *__restrict__ parent,
+                                                 Counters *ctr) {
+    constexpr int MAXRPW = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (!(ja.dbg & 16)) {  // clear the other table set for the next step (this step never touches it)
+        const size_t tid = (size_t)blockIdx.x * 1024 + threadIdx.x, nth = (size_t)gridDim.x * 1024;
+        ulonglong2 *t2 = reinterpret_cast<ulonglong2 *>(ja.tab_next);
+        for (size_t i = tid; i < ((size_t)ja.mask + 1) / 2; i += nth) t2[i] = make_ulonglong2(JOIN_EMPTY, JOIN_EMPTY);
+        uint4 *b4 = reinterpret_cast<uint4 *>(ja.bits_next);
+        for (size_t i = tid; i < ((size_t)ja.bmask + 1) / 128; i += nth) b4[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (blockIdx.x == 0) {  // what k_cells does on the all-pairs path
+        if (threadIdx.x < CAND_SHARDS) ctr->ncand[threadIdx.x] = 0;
+        if (threadIdx.x == 64) {
+            ctr->err = 0;
+            ctr->overflow = 0;
+            ctr->n_work = 0;
+            ctr->n_edges = ctr->n_cand_total = ctr->n_edges_cap = 0;
+        }
+    }
+    const int r0 = blockIdx.x * rpw * 16 + wave * rpw;
+    const int nr = max(0, min(rpw, n - r0));
+    if (nr <= 0) return;
+    uint32_t my1 = 0, my2 = 0;  // lane t: H of row r0 + t
+    if (nnz > 0) {
+        const int ext = indptr[min(r0 + min(lane, rpw), n)];
+        uint32_t xs[MAXRPW];
+#pragma unroll
+        for (int t = 0; t < MAXRPW; t++) {
+            const int bt = __builtin_amdgcn_readlane(ext, t);
+            xs[t] = indices[min(max(bt, 0) + lane, nnz - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < MAXRPW; t++) {
+            if (t >= nr) continue;  // wave-uniform
+            const int b = __builtin_amdgcn_readlane(ext, t), e = __builtin_amdgcn_readlane(ext, t + 1);
+            int k = e - b;
+            if (k < 0 || k > kcap) {
+                if (lane == 0) atomicOr(&ctr->err_rows, ERR_ROWLEN);
+                k = k < 0 ? 0 : kcap;
+            }
+            uint32_t a1 = 0, a2 = 0;
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int rem = k - j0;
+                const uint32_t x = j0 == 0 ? xs[t] : ((lane < rem) ? indices[b + j0 + lane] : 0u);
+                const uint32_t hs = jh_stage(x);
+                a1 += lane < rem ? jh1_of(hs) : 0u;
+                a2 += lane < rem ? jh2_of(hs) : 0u;
+            }
+            a1 = wave_add_to_lane63(a1);
+            a2 = wave_add_to_lane63(a2);
+            const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)a1, 63), t2 = (uint32_t)__builtin_amdgcn_readlane((int)a2, 63);
+            if (lane == t) {
+                my1 = t1;
+                my2 = t2;
+            }
+        }
+    }
+    if (lane < nr) {
+        const int i = r0 + lane;
+        ja.rowhash[i] = make_uint2(my1, my2);
+        parent[i] = i;
+        atomicOr(&ja.bits[(my1 & ja.bmask) >> 5], 1u << (my1 & 31u));
+        const unsigned long long ent = ((unsigned long long)my2 << 32) | (unsigned long long)(uint32_t)i;
+        uint32_t s = my1 & ja.mask;
+        for (int probes = 0; !(ja.dbg & 8); probes++) {
+            const unsigned long long old = atomicCAS(&ja.tab[s], JOIN_EMPTY, ent);
+            if (old == JOIN_EMPTY) break;
+            if ((uint32_t)(old >> 32) == my2) {  // an earlier row with this H: (up to a hash collision) the same multiset
+                const unsigned q = atomicAdd(&ctr->n_dup, 1u);
+                if (q < (unsigned)ja.dup_cap) ja.dups[q] = make_int2((int)(uint32_t)old, i);
+                else ctr->join_fail = 1;
+            }
+            if (probes >= JOIN_MAX_PROBE) {
+                ctr->join_fail = 1;
+                break;
+            }
+            s = (s + 1) & ja.mask;
+        }
+    }
+}
+
+// k_join: the lookups, the check of the matches and the unions.  Per wave:
+//   phase A requests the first 64 tokens and the bitmap words of all its rows;
+//   phase B turns bitmap hits into entries of the wave's LDS queue {key1, key2, row, position} (a token that occurs
+//     twice in a row is looked up once: the pair would be found twice);
+//   drain() probes the table for a whole queue at once, one lookup per lane, two slots per step;
+//   settle() takes the matches (A, B, p) — B minus its token at position p hashes like A — and checks them right
+//     here: profiles list their mutations in one order, so A is almost always B with position p deleted, i.e.
+//     A[j] == B[j + (j >= p)] for all j, a 64-lane compare of two coalesced loads (four matches in flight); a
+//     certified pair is hooked into the union-find at once, one edge per lane.  Whatever fails that test (other
+//     token order, rows over 64 tokens, a hash collision) goes to the candidate queue and k_verify's exact count.
+__global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
+                                                int nnz, int rpw, JoinArgs ja, PairArgs pa, int shard0, int nshards,
+                                                int2 *edges, int edge_cap) {
+    constexpr int QCAP = 128, MCAP = 64;
+    __shared__ uint32_t q_k1[16][QCAP], q_k2[16][QCAP];
+    __shared__ int q_b[16][QCAP];             // row of the wave (4 bits) | token position << 4
+    __shared__ int m_a[16][MCAP], m_b[16][MCAP];  // matches: row A, q_b of the lookup
+    __shared__ unsigned s_edges, s_cands;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rows_per_block = rpw * 16;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cshard = (blockIdx.x * 16 + wave) & (CAND_SHARDS - 1);
+    if (threadIdx.x == 0) s_edges = s_cands = 0;
+    __syncthreads();
+
+    // append (A, B) to the candidate queue of k_verify; `want` lanes hold one pair each (wave-uniform call)
+    auto enqueue = [&](bool want, int A, int B, int ba, int bb, int ka, int kb) {
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(want);
+        if (mm == 0ull) return;
+        cshard = (cshard + 1) & (CAND_SHARDS - 1);
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&pa.ctr->ncand[cshard], (unsigned)__popcll(mm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (want) {
+            const int idx = base + __popcll(mm & lt);
+            if (idx < pa.cand_cap_shard) {
+                const size_t o = (size_t)cshard * pa.cand_cap_shard + idx;
+                pa.cand[o] = make_int4(A, B, ba, bb);
+                pa.candk[o] = make_int2(ka, kb);
+            } else {
+                pa.ctr->overflow = 1;
+            }
+        }
+    };
+
+    {   // rows k_jhash found to share one H: the block of the later row owns the pair (the same on every rank)
+        const int ndup = (int)min(pa.ctr->n_dup, (unsigned)ja.dup_cap);
+        const int per = (int)gridDim.x * 1024;
+        for (int i0 = (int)blockIdx.x * 1024 + wave * 64; i0 < ndup; i0 += per) {  // wave-uniform trip count
+            const int i = i0 + lane;
+            bool mine = false;
+            int A = 0, B = 0, ba = 0, bb = 0, ea = 0, eb = 0;
+            if (i < ndup) {
+                const int2 pr = ja.dups[i];
+                A = min(pr.x, pr.y);
+                B = max(pr.x, pr.y);
+                mine = (B / rows_per_block) % nshards == shard0;
+                if (mine) {
+                    ba = indptr[A];
+                    ea = indptr[A + 1];
+                    bb = indptr[B];
+                    eb = indptr[B + 1];
+                }
+            }
+            enqueue(mine, A, B, ba, bb, ea - ba, eb - bb);
+        }
+    }
+    // the grid strides over blocks of rows_per_block rows; multi-GPU: those are dealt round-robin; without any token
+    // there is nothing to look up
+    uint32_t *qk1 = q_k1[wave], *qk2 = q_k2[wave];
+    int *qb = q_b[wave], *ma = m_a[wave], *mb = m_b[wave];
+    unsigned my_edges = 0, my_cands = 0;
+    const int nvb = nnz > 0 ? (n + rows_per_block - 1) / rows_per_block : 0;
+#pragma unroll 1
+    for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        if (vb % nshards != shard0) continue;
+        const int r0 = vb * rows_per_block + wave * rpw;
+        const int nr = max(0, min(rpw, n - r0));
+        if (nr <= 0) continue;
+        int nq = 0, nm = 0;  // wave-uniform
+        const int ext = indptr[min(r0 + min(lane, rpw), n)];
+
+        auto settle = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (ja.dbg & 1) nm = 0;
+            const bool have = lane < nm;
+            const int A = have ? ma[lane] : 0;
+            const int tb = have ? mb[lane] : 0;
+            const int t = tb & 15, p = tb >> 4;
+            const int B = r0 + t;
+            const int bb = __shfl(ext, t), eb = __shfl(ext, t + 1);
+            const int ba = have ? indptr[A] : 0, ea = have ? indptr[A + 1] : 0;
+            const uint32_t tok = have ? indices[min(bb + p, nnz - 1)] : 0u;  // the token whose deletion was looked up
+            const int ka = ea - ba, kb = eb - bb;
+            // B minus one token has k_b - 1 tokens: anything else is a hash collision
+            const bool live = have && kb == ka + 1;
+            const bool simple = live && ka <= 64;
+            bool cert = false, dup = false;
+            for (int m0 = 0; m0 < nm; m0 += 4) {  // four matches in flight
+                uint32_t av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int m = min(m0 + u, nm - 1);
+                    const int ba_m = __builtin_amdgcn_readlane(ba, m), bb_m = __builtin_amdgcn_readlane(bb, m);
+                    const int p_m = __builtin_amdgcn_readlane(p, m);
+                    av[u] = indices[min(max(ba_m, 0) + lane, nnz - 1)];
+                    bv[u] = indices[min(max(bb_m, 0) + lane + (lane >= p_m ? 1 : 0), nnz - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int m = min(m0 + u, nm - 1);
+                    const int ka_m = __builtin_amdgcn_readlane(ka, m), p_m = __builtin_amdgcn_readlane(p, m);
+                    const uint32_t tok_m = (uint32_t)__builtin_amdgcn_readlane((int)tok, m);
+                    const bool ok = __builtin_amdgcn_ballot_w64(lane < ka_m && av[u] != bv[u]) == 0ull;
+                    // a token that occurs more than once in B is looked up at every occurrence: the pair counts at
+                    // the first one only (lanes below p hold B[lane])
+                    const bool again = __builtin_amdgcn_ballot_w64(lane < p_m && bv[u] == tok_m) != 0ull;
+                    if (lane == m) {
+                        cert = ok;
+                        dup = again;
+                    }
+                }
+            }
+            if (live && !simple) {  // rows over 64 tokens: the first-occurrence test token by token, the check by k_verify
+                dup = false;
+                for (int j = 0; j < p && !dup; j++) dup = indices[bb + j] == tok;
+            }
+            cert = cert && simple && !dup;
+            if (cert && !(ja.dbg & 32)) {
+                uf_union(pa.parent, A, B);
+                if (edges) record_edge(pa, edges, edge_cap, A, B);
+            }
+            const int nc = __popcll(__builtin_amdgcn_ballot_w64(cert));
+            my_edges += (unsigned)nc;
+            my_cands += (unsigned)nc;
+            enqueue(live && !cert && !dup, A, B, ba, bb, ka, kb);
+            __builtin_amdgcn_wave_barrier();
+            nm = 0;
+        };
+
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (ja.dbg & 2) nq = 0;
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int i = q0 + lane;
+                bool active = i < nq;
+                const uint32_t k2 = active ? qk2[i] : 0u;
+                const int bt = active ? qb[i] : 0;
+                uint32_t s = (active ? qk1[i] : 0u) & ja.mask;
+                int probes = 0;
+                while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+                    unsigned long long e0 = JOIN_EMPTY, e1 = JOIN_EMPTY;
+                    if (active) {  // two slots per step: at load 1/8 nearly every chain ends inside them
+                        e0 = ja.tab[s];
+                        e1 = ja.tab[(s + 1) & ja.mask];
+                    }
+                    const bool m0 = active && e0 != JOIN_EMPTY && (uint32_t)(e0 >> 32) == k2;
+                    const bool m1 = active && e0 != JOIN_EMPTY && e1 != JOIN_EMPTY && (uint32_t)(e1 >> 32) == k2;
+                    if (active) {
+                        if (e0 == JOIN_EMPTY || e1 == JOIN_EMPTY) active = false;
+                        s = (s + 2) & ja.mask;
+                        probes += 2;
+                        if (probes > JOIN_MAX_PROBE) {
+                            pa.ctr->join_fail = 1;
+                            active = false;
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const bool mt = h ? m1 : m0;
+                        const unsigned long long mm = __builtin_amdgcn_ballot_w64(mt);
+                        if (mm == 0ull) continue;
+                        if (nm + __popcll(mm) > MCAP) settle();
+                        if (mt) {
+                            const int pos = nm + __popcll(mm & lt);
+                            ma[pos] = (int)(uint32_t)(h ? e1 : e0);
+                            mb[pos] = bt;
+                        }
+                        nm += __popcll(mm);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            nq = 0;
+        };
+
+        // hits of one 64-token chunk of row t -> queue (hs = first hash stage of the lane's token)
+        auto push_hits = [&](int t, int j0, bool valid, uint32_t hs, uint32_t k1, uint32_t w, uint32_t S2) {
+            unsigned long long hm = __builtin_amdgcn_ballot_w64(valid && ((w >> (k1 & 31u)) & 1u));
+            if (ja.dbg & 4) hm = 0ull;
+            if ((hm >> lane) & 1ull) {
+                const int pos = nq + __popcll(hm & lt);
+                qk1[pos] = k1;
+                qk2[pos] = S2 - jh2_of(hs);
+                qb[pos] = t | ((j0 + lane) << 4);
+            }
+            nq += __popcll(hm);
+        };
+
+        uint2 hv = make_uint2(0u, 0u);
+        if (lane < nr) hv = ja.rowhash[r0 + lane];
+        unsigned slow = 0;  // rows left to the generic loop below: longer than 64 tokens, or the queue was nearly full
+#pragma unroll 1
+        for (int t0 = 0; t0 < nr; t0 += 8) {  // eight rows in flight (sixteen do not fit 64 VGPRs = two blocks per CU)
+            uint32_t xs[8], wv[8];  // xs: the token, then its first hash stage (tokens are not needed again)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int bt = __builtin_amdgcn_readlane(ext, t0 + u);
+                xs[u] = indices[min(max(bt, 0) + lane, nnz - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t S1 = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, t0 + u);
+                const int k = __builtin_amdgcn_readlane(ext, t0 + u + 1) - __builtin_amdgcn_readlane(ext, t0 + u);
+                xs[u] = jh_stage(xs[u]);
+                const uint32_t k1 = S1 - jh1_of(xs[u]);
+                // a scattered load costs one cache-line request per distinct line: lanes past the row all ask for
+                // word 0 (an UNCONDITIONAL load of a selected address — a load under a lane mask made the compiler
+                // wait for each load before issuing the next)
+                wv[u] = ja.bits[lane < k ? ((k1 & ja.bmask) >> 5) : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u;
+                if (t >= nr) continue;  // wave-uniform
+                const int b = __builtin_amdgcn_readlane(ext, t), e = __builtin_amdgcn_readlane(ext, t + 1);
+                const int k = e - b;  // (k_jhash has flagged malformed extents)
+                if (k <= 0) continue;
+                if (k > 64 || nq > QCAP - 64) {
+                    slow |= 1u << t;
+                    continue;
+                }
+                const uint32_t S1 = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, t);
+                const uint32_t S2 = (uint32_t)__builtin_amdgcn_readlane((int)hv.y, t);
+                push_hits(t, 0, lane < k, xs[u], S1 - jh1_of(xs[u]), wv[u], S2);
+            }
+        }
+        // the one drain site: after the fast loop, whenever a chunk of a slow row could overfill the queue, at the end
+        int st = -1, sb = 0, sk = 0, sj = 0;
+        uint32_t sS1 = 0, sS2 = 0;
+        bool first = true, fin = false;
+        while (true) {
+            if (first || fin || nq > QCAP - 64) {
+                drain();
+                first = false;
+                if (fin) break;
+            }
+            if (st < 0 || sj >= sk) {  // next slow row
+                if (slow == 0u) {
+                    fin = true;
+                    continue;
+                }
+                st = (int)__builtin_ctz(slow);
+                slow &= slow - 1u;
+                sb = __shfl(ext, st);
+                sk = __shfl(ext, st + 1) - sb;
+                sS1 = (uint32_t)__shfl((int)hv.x, st);
+                sS2 = (uint32_t)__shfl((int)hv.y, st);
+                sj = 0;
+                continue;
+            }
+            const bool valid = lane < sk - sj;
+            const uint32_t hs = jh_stage(valid ? indices[sb + sj + lane] : 0u);
+            const uint32_t k1 = sS1 - jh1_of(hs);
+            const uint32_t w = ja.bits[valid ? ((k1 & ja.bmask) >> 5) : 0u];
+            push_hits(st, sj, valid, hs, k1, w, sS2);
+            sj += 64;
+        }
+        settle();
+    }
+    if (lane == 0 && (my_edges | my_cands)) {
+        atomicAdd(&s_edges, my_edges);
+        atomicAdd(&s_cands, my_cands);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // plain stores, summed by the host
+        ja.stats[2 * blockIdx.x] = (int)s_edges;
+        ja.stats[2 * blockIdx.x + 1] = (int)s_cands;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
 // (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
-__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels) {
+__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && ctr) ctr->n_dup = 0;  // the dup list of the variant join: consumed, empty for the next step
     if (i >= n) return;
     int cur = parent[i], next;
     while (cur > (next = parent[cur])) cur = next;
@@ -1305,6 +1726,34 @@ static PairArgs make_pair_args(const Plan &pl) {
     return pa;
 }
 
+// exact check + union of everything in the candidate queue
+static int launch_verify(const Plan &pl, const PairArgs &pa, hipStream_t st, hipEvent_t *ev) {
+    {   // 16-token steps covering the longest row a pair of k_verify can have
+        const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
+#define VF_CASE(S)                                                                                                        \
+    if (pl.d <= pl.wave_table_d)                                                                                          \
+        hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
+                           pl.blk_stats);                                                                                 \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((k_verify<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,       \
+                           pl.blk_stats)
+        if (steps <= 3) { VF_CASE(3); }
+        else if (steps <= 4) { VF_CASE(4); }
+        else if (steps <= 6) { VF_CASE(6); }
+        else if (steps <= 8) { VF_CASE(8); }
+        else { VF_CASE(12); }
+#undef VF_CASE
+    }
+    LAUNCH_CHECK();
+    if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table
+        hipLaunchKernelGGL(k_verify_long, dim3(LONG_BLOCKS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey, pl.gcnt,
+                           pl.gslots, pl.edges, pl.edge_cap);
+        LAUNCH_CHECK();
+    }
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return 0;
+}
+
 // prefilter + verify + union over tiles [t_begin, t_end) (whole list for a normal run; slices in recovery)
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev) {
     const int n = pl.n;
@@ -1367,34 +1816,11 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 #undef PF_CASE_PW
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    {   // 16-token steps covering the longest row a pair of k_verify can have
-        const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
-#define VF_CASE(S)                                                                                                        \
-    if (pl.d <= pl.wave_table_d)                                                                                          \
-        hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
-                           pl.blk_stats);                                                                                 \
-    else                                                                                                                  \
-        hipLaunchKernelGGL((k_verify<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,       \
-                           pl.blk_stats)
-        if (steps <= 3) { VF_CASE(3); }
-        else if (steps <= 4) { VF_CASE(4); }
-        else if (steps <= 6) { VF_CASE(6); }
-        else if (steps <= 8) { VF_CASE(8); }
-        else { VF_CASE(12); }
-#undef VF_CASE
-    }
-    LAUNCH_CHECK();
-    if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table
-        hipLaunchKernelGGL(k_verify_long, dim3(LONG_BLOCKS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey, pl.gcnt,
-                           pl.gslots, pl.edges, pl.edge_cap);
-        LAUNCH_CHECK();
-    }
-    if (ev) (void)hipEventRecord(ev[3], st);
-    return 0;
+    return launch_verify(pl, pa, st, ev);
 }
 
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
-    hipLaunchKernelGGL(k_flatten, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels);
+    hipLaunchKernelGGL(k_flatten, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels, pl.ctr);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return 0;
@@ -1403,6 +1829,21 @@ int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/) {
     const int n = pl.n;
     if (ev) (void)hipEventRecord(ev[0], st);
+    if (pl.join) {  // max_dist == 1: hash join instead of the all-pairs kernels
+        const int rpw = max(1, min(16, (n + 8191) / 8192));
+        const int blocks = (n + rpw * 16 - 1) / (rpw * 16);
+        const PairArgs pa = make_pair_args(pl);
+        hipLaunchKernelGGL(k_jhash, dim3(blocks), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.kcap, rpw, pl.ja,
+                           pl.parent, pl.ctr);
+        LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[1], st);
+        hipLaunchKernelGGL(k_join, dim3(std::min(blocks, pl.join_grid)), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, rpw,
+                           pl.ja, pa, pl.shard, pl.n_shards, pl.edges, pl.edge_cap);
+        LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[2], st);
+        if (int e = launch_verify(pl, pa, st, ev)) return e;
+        return launch_flatten(pl, st, ev);
+    }
     KeyCfg key;
     key.fb = pl.fb;
     key.gb = pl.gb;
@@ -1467,7 +1908,7 @@ int launch_lists(int *parent, int n, const long long *off, const int *flat, long
                            n_lists, n, ctr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels);
+    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1478,7 +1919,7 @@ int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labe
     dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_flatten, g, b, 0, st, parent, n, labels);
+    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr);
     LAUNCH_CHECK();
     if (changed) {
         hipLaunchKernelGGL(k_changed, g, b, 0, st, (const int *)labels, gathered, n, changed);

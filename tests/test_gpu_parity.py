@@ -491,6 +491,7 @@ def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monk
     want, st0 = _lib.cluster_csr(indptr, indices, d)
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
+    monkeypatch.setenv("BFK_JOIN", "0")  # d = 1: these knobs configure the all-pairs kernels (want: the default path)
     got, st = _lib.cluster_csr(indptr, indices, d)
     assert np.array_equal(got, want)
     assert st["n_edges"] == st0["n_edges"] and st["n_candidates"] >= st["n_edges"]
@@ -508,12 +509,104 @@ def test_candidate_queue_overflow_is_recovered(cap, d, monkeypatch):
     assert st0["n_retry_slices"] == 0
     ptr0, idx0 = _lib.neighbours_csr(indptr, indices, d)
     monkeypatch.setenv("BFK_CAND_CAP_SHARD", str(cap))
+    monkeypatch.setenv("BFK_JOIN", "0")  # d = 1: the all-pairs kernels (the join certifies ordered profiles without the queue)
     got, st = _lib.cluster_csr(indptr, indices, d)
     assert st["n_retry_slices"] > 0
     assert np.array_equal(got, want)
     assert st["n_edges"] == st0["n_edges"]
     ptr, idx = _lib.neighbours_csr(indptr, indices, d)
     assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
+
+
+def _join_cases():
+    rng = np.random.default_rng(77)
+    cases = {}
+    # small alphabet: repeated tokens inside rows, many rows that are one multiset in different orders
+    cases["small_alphabet"] = _random_multisets(3000, 31, 6, 9)
+    cases["medium"] = _random_multisets(2500, 32, 300, 30, p_empty=0.0)
+    # rows longer than one 64-token chunk, with the inserted / repeated token before and after the chunk border
+    base = rng.choice(5000, size=150, replace=False).astype(np.int32)
+    rows = [base]
+    for pos in (0, 10, 63, 64, 65, 127, 128, 149, 150):
+        rows.append(np.insert(base, pos, 9999).astype(np.int32))            # base + new token
+        rows.append(np.insert(base, pos, base[3]).astype(np.int32))          # base + repeat of an early token
+        rows.append(np.insert(base, pos, base[140]).astype(np.int32))        # base + repeat of a late token
+    rows += [rng.permutation(base).astype(np.int32) for _ in range(5)]      # same multiset, other orders
+    rows.append(np.delete(base, 70).astype(np.int32))
+    rows.append(np.append(np.append(base, 7), 8).astype(np.int32))          # distance 2
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    cases["long_rows"] = (indptr, np.concatenate(rows).astype(np.int32))
+    # 100 orders of one multiset (inside the probe limit of the join) and 400 of another (beyond it: fallback)
+    for name, m in (("perms100", 100), ("perms400", 400)):
+        row = rng.choice(1000, size=12, replace=False).astype(np.int32)
+        rows = [rng.permutation(row) for _ in range(m)] + [np.append(row, 5000 + i).astype(np.int32) for i in range(50)]
+        rows += [rng.choice(1000, size=10, replace=False).astype(np.int32) for _ in range(500)]
+        indptr = np.zeros(len(rows) + 1, np.int32)
+        indptr[1:] = np.cumsum([len(r) for r in rows])
+        cases[name] = (indptr, np.concatenate(rows).astype(np.int32))
+    uf = list(dict.fromkeys(generate_profiles(30000, p_del=0.05, p_ins=0.02)))
+    cases["profiles30k"] = _lib.build_csr(uf, " ")[:2]
+    return cases
+
+
+@pytest.mark.parametrize("name", ["small_alphabet", "medium", "long_rows", "perms100", "perms400", "profiles30k"])
+def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
+    """max_dist 1 is served by the hash join (H(B) - h(t) lookups): labels, edge count and neighbour
+    lists must equal those of the all-pairs kernels and of the oracle — repeated tokens (a pair must be found once),
+    equal multisets in other orders, rows over several 64-token chunks, and the give-up path (probe chain beyond the
+    limit -> the step is redone by the all-pairs kernels)"""
+    indptr, indices = _join_cases()[name]
+    monkeypatch.setenv("BFK_JOIN", "0")
+    want, st0 = _lib.cluster_csr(indptr, indices, 1)
+    ptr0, idx0 = _lib.neighbours_csr(indptr, indices, 1)
+    monkeypatch.setenv("BFK_JOIN", "1")
+    got, st = _lib.cluster_csr(indptr, indices, 1)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, orc.cluster_csr(indptr, indices, 1, n_threads=8)["labels"])
+    assert st["n_edges"] == st0["n_edges"]
+    if name != "small_alphabet":  # (hundreds of empty and one-token rows there: may or may not exceed the limit)
+        assert (st["n_retry_slices"] > 0) == (name == "perms400")
+    if st["n_retry_slices"] == 0:
+        assert st["n_candidates"] == st["n_edges"]  # every table match is a real edge (up to 64-bit hash collisions)
+    ptr, idx = _lib.neighbours_csr(indptr, indices, 1)
+    assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
+
+
+def test_variant_join_queue_overflow_falls_back(monkeypatch):
+    """rows in no common order: the join cannot certify its matches itself and queues them for k_verify; a queue
+    that is too small makes bfk_ctx_sync redo the step on the all-pairs path (which has the sliced recovery)"""
+    indptr, indices = _join_cases()["medium"]
+    want, st0 = _lib.cluster_csr(indptr, indices, 1)
+    assert st0["n_retry_slices"] == 0
+    monkeypatch.setenv("BFK_CAND_CAP_SHARD", "1")
+    got, st = _lib.cluster_csr(indptr, indices, 1)
+    assert st["n_retry_slices"] > 0
+    assert np.array_equal(got, want) and st["n_edges"] == st0["n_edges"]
+
+
+def test_variant_join_on_a_resident_context_alternates_its_tables():
+    """steps on one context: the join clears the table set of the NEXT step; rebinding a smaller and a larger CSR
+    in between must not leave stale entries"""
+    cases = _join_cases()
+    ctx = _lib.Context(0)
+    for name in ("medium", "long_rows", "profiles30k", "medium", "perms100"):
+        indptr, indices = cases[name]
+        n = len(indptr) - 1
+        want = orc.cluster_csr(indptr, indices, 1, n_threads=8)["labels"]
+        ctx.upload_csr(indptr, indices)
+        d_out = ctx.alloc(4 * n)
+        for _ in range(3):
+            ctx.cluster(1, d_out)
+            st = ctx.sync()
+            assert st["n_retry_slices"] == 0
+            assert np.array_equal(ctx.download_i32(d_out, n), want)
+        ctx.cluster(2, d_out)  # the all-pairs path in between
+        ctx.sync()
+        ctx.cluster(1, d_out)
+        ctx.sync()
+        assert np.array_equal(ctx.download_i32(d_out, n), want)
+    ctx.close()
 
 
 def test_allreduce_min_merge_reaches_the_fix_point():

@@ -1,0 +1,11 @@
+#!/bin/bash
+# timing attribution of the variant join: bench phases with parts of the kernels switched off (BFK_JOIN_DEBUG)
+cd "$(dirname "$0")/.."
+for dbg in 0 32 1 3 7 8 24; do
+  BFK_JOIN_DEBUG=$dbg python bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > gpurun_out/ja_$dbg.json 2>/dev/null
+  python - <<PY
+import json
+b=json.loads(open("gpurun_out/ja_$dbg.json").read()); p=b["phases_ms"]
+print("dbg=%-3s step %.4f  jhash %.4f join %.4f verify %.4f flatten %.4f" % ("$dbg", b["ms_per_step"], p["ms_prep"], p["ms_prefilter"], p["ms_verify"], p["ms_flatten"]))
+PY
+done
