@@ -79,6 +79,7 @@ struct Plan {
     Counters *ctr;
     unsigned long long *dbg_t;
     int join_grid;  // most blocks of k_join (it strides over the blocks of rows)
+    int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;
 };

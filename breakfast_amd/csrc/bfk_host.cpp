@@ -196,6 +196,9 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
+    // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
+    // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
+    int join_empty_shard = -1, join_empty_shards = 0;
     // last run
     bool ran = false;
     int last_d = 0, last_w1 = 0, last_shards = 1;
@@ -411,6 +414,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->need_zero = true;  // bins are laid out by kcap
     c->join_clear = true;
     c->join_off = false;
+    c->join_empty_shard = -1;
     return ctx_size_workspace(c, 0);
 }
 
@@ -595,6 +599,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.bits_next = (uint32_t *)(cur ? bits0 : bits1);
         pl.ja.rowhash = (uint2 *)(bits1 + c->join_bits / 8);
         pl.join_grid = 1 << 20;
+        pl.join_skip_verify = (c->join_empty_shard == shard && c->join_empty_shards == n_shards && !c->edge_capture &&
+                               2 * c->kcap <= VERIFY_MAX_TOKENS && !getenv("BFK_CAND_CAP_SHARD")) ? 1 : 0;
         // k_verify only sees what k_join could not certify itself (rows in no common order, rows over 64 tokens)
         if (!getenv("BFK_VERIFY_GRID")) pl.verify_grid = 256;
         pl.ja.dups = (int2 *)((char *)pl.ja.rowhash + (c->n + 16) * 8);
@@ -633,7 +639,8 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
 // the counters read back from the device (n_edges already holds the edges of the long-pair kernel)
 static int ctx_pair_stats(bfk_ctx *c, Counters *h) {
     std::vector<int> v((size_t)2 * c->plan.verify_grid);
-    HIP_TRY(hipMemcpy(v.data(), c->d_blk_stats, v.size() * 4, hipMemcpyDeviceToHost));
+    if (c->plan.join && c->plan.join_skip_verify) v.clear();  // k_verify did not run: its counts are another step's
+    if (!v.empty()) HIP_TRY(hipMemcpy(v.data(), c->d_blk_stats, v.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long e = 0, k = 0;
     for (size_t i = 0; i < v.size(); i += 2) {
         e += (unsigned)v[i];
@@ -744,6 +751,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             // or its candidates did not fit the queue: the step is redone on the all-pairs path, which has its own
             // recovery; a give-up also turns the join off for this CSR
             if (h.join_fail) c->join_off = true;
+            c->join_empty_shard = -1;
             c->need_zero = true;
             c->join_clear = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
@@ -751,6 +759,16 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
             c->last_tiles = (int64_t)h.n_work;
             retry_slices = 1;
+        }
+        if (c->plan.join && !h.overflow && !h.join_fail) {
+            unsigned long long queued = 0;
+            for (unsigned v : h.ncand) queued += v;
+            if (queued == 0) {
+                c->join_empty_shard = c->plan.shard;
+                c->join_empty_shards = c->plan.n_shards;
+            } else {
+                c->join_empty_shard = -1;
+            }
         }
         if (!h.overflow)
             if (int rc = ctx_pair_stats(c, &h)) return rc;

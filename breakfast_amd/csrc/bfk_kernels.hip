@@ -1355,8 +1355,8 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
 //   settle() takes the matches (A, B, p) — B minus its token at position p hashes like A — and checks them right
 //     here: profiles list their mutations in one order, so A is almost always B with position p deleted, i.e.
 //     A[j] == B[j + (j >= p)] for all j, a 64-lane compare of two coalesced loads (four matches in flight); a
-//     certified pair is hooked into the union-find at once, one edge per lane.  Whatever fails that test (other
-//     token order, rows over 64 tokens, a hash collision) goes to the candidate queue and k_verify's exact count.
+//     certified pair is hooked into the union-find at once, one edge per lane.  Whatever fails that test (another
+//     token order, a hash collision) goes to the candidate queue and k_verify's exact count.
 __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
                                                 int nnz, int rpw, JoinArgs ja, PairArgs pa, int shard0, int nshards,
                                                 int2 *edges, int edge_cap) {
@@ -1446,7 +1446,6 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             const int ka = ea - ba, kb = eb - bb;
             // B minus one token has k_b - 1 tokens: anything else is a hash collision
             const bool live = have && kb == ka + 1;
-            const bool simple = live && ka <= 64;
             bool cert = false, dup = false;
             for (int m0 = 0; m0 < nm; m0 += 4) {  // four matches in flight
                 uint32_t av[4], bv[4];
@@ -1473,11 +1472,27 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                     }
                 }
             }
-            if (live && !simple) {  // rows over 64 tokens: the first-occurrence test token by token, the check by k_verify
-                dup = false;
-                for (int j = 0; j < p && !dup; j++) dup = indices[bb + j] == tok;
+            // rows over 64 tokens (rare): the same two tests, one match at a time, 64 positions per step
+            for (unsigned long long lm = __builtin_amdgcn_ballot_w64(live && ka > 64); lm != 0ull; lm &= lm - 1ull) {
+                const int m = (int)__builtin_ctzll(lm);
+                const int ba_m = __builtin_amdgcn_readlane(ba, m), bb_m = __builtin_amdgcn_readlane(bb, m);
+                const int ka_m = __builtin_amdgcn_readlane(ka, m), p_m = __builtin_amdgcn_readlane(p, m);
+                const uint32_t tok_m = (uint32_t)__builtin_amdgcn_readlane((int)tok, m);
+                bool bad = false, again = false;
+                for (int j0 = 0; j0 < ka_m; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool in = j < ka_m;
+                    const uint32_t xa = in ? indices[ba_m + j] : 0u, xb = in ? indices[bb_m + j + (j >= p_m ? 1 : 0)] : 0u;
+                    bad |= in && xa != xb;
+                    again |= in && j < p_m && xb == tok_m;
+                }
+                const bool ok = __builtin_amdgcn_ballot_w64(bad) == 0ull, ag = __builtin_amdgcn_ballot_w64(again) != 0ull;
+                if (lane == m) {
+                    cert = ok;
+                    dup = ag;
+                }
             }
-            cert = cert && simple && !dup;
+            cert = cert && live && !dup;
             if (cert && !(ja.dbg & 32)) {
                 uf_union(pa.parent, A, B);
                 if (edges) record_edge(pa, edges, edge_cap, A, B);
@@ -1637,9 +1652,11 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
 // (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
-__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr) {
+__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && ctr) ctr->n_dup = 0;  // the dup list of the variant join: consumed, empty for the next step
+    // k_verify was not launched because this CSR queued nothing the last time: if it did now, the step is redone
+    if (expect_empty_queue && i < CAND_SHARDS && ctr->ncand[i] != 0u) ctr->join_fail = 1;
     if (i >= n) return;
     int cur = parent[i], next;
     while (cur > (next = parent[cur])) cur = next;
@@ -1820,7 +1837,8 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 }
 
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
-    hipLaunchKernelGGL(k_flatten, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels, pl.ctr);
+    hipLaunchKernelGGL(k_flatten, dim3((std::max(pl.n, CAND_SHARDS) + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels, pl.ctr,
+                       pl.join && pl.join_skip_verify ? 1 : 0);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return 0;
@@ -1841,7 +1859,11 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
                            pl.ja, pa, pl.shard, pl.n_shards, pl.edges, pl.edge_cap);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
-        if (int e = launch_verify(pl, pa, st, ev)) return e;
+        if (pl.join_skip_verify) {  // nothing was queued the last time (k_flatten checks that this still holds)
+            if (ev) (void)hipEventRecord(ev[3], st);
+        } else if (int e = launch_verify(pl, pa, st, ev)) {
+            return e;
+        }
         return launch_flatten(pl, st, ev);
     }
     KeyCfg key;
@@ -1908,7 +1930,7 @@ int launch_lists(int *parent, int n, const long long *off, const int *flat, long
                            n_lists, n, ctr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr);
+    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1919,7 +1941,7 @@ int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labe
     dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr);
+    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0);
     LAUNCH_CHECK();
     if (changed) {
         hipLaunchKernelGGL(k_changed, g, b, 0, st, (const int *)labels, gathered, n, changed);

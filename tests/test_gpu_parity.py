@@ -604,8 +604,9 @@ def test_variant_join_on_a_resident_context_alternates_its_tables():
         ctx.cluster(2, d_out)  # the all-pairs path in between
         ctx.sync()
         ctx.cluster(1, d_out)
-        ctx.sync()
+        st2 = ctx.sync()
         assert np.array_equal(ctx.download_i32(d_out, n), want)
+        assert st2["n_edges"] == st["n_edges"] and st2["n_candidates"] == st["n_candidates"]
     ctx.close()
 
 
