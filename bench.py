@@ -204,13 +204,16 @@ def main():
         # measured HBM bytes per launch of the pair kernel: bench.py cannot collect PMC counters itself, so the
         # figure comes from the committed rocprofv3 passes of this same command (tools/profile_gpu.sh), FETCH_SIZE
         # doubled per the gfx950 note of the microarchitecture guide (an upper bound for 4-byte-per-lane reads)
+        # max-dist 1 up to 800k rows runs the variant join (k_jhash + k_join) instead of the all-pairs kernels
+        join = d == 1 and st["n_work_items"] == 0 and n_u > 0
+        dom = "k_join" if join else "k_prefilter"
         traffic, traffic_src = None, None
         if world == 1 and n_rows == 100000 and d == 1 and not a.indels:
             import glob
             for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                                    "*_pmc_per_launch.json")), reverse=True):
                 pm = json.load(open(f))
-                hit = [v for kk, v in pm.items() if "k_prefilter" in kk and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+                hit = [v for kk, v in pm.items() if dom in kk and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
                 if hit:
                     traffic = (2.0 * hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0
                     traffic_src = f"{os.path.basename(f)}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
@@ -233,13 +236,14 @@ def main():
                             f"{', indels kept' if a.indels else ''}), N_u={n_u} unique, k_mean={nnz / n_u:.1f}, "
                             f"max-dist {d}",
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
-                "sharding": f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)" +
+                "sharding": (f"blocks of rows (their lookups) round-robin over {world} rank(s)" if join else
+                             f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"k_prefilter<W={w}>",
+                "kernel": "k_join" if join else f"k_prefilter<W={w}>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -248,13 +252,27 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": b_alg / world,
                 "kernel_ms": st["ms_prefilter"],
-                "note": "SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
-                        "band + 8 B per pruned pair.  The kernel never streams those operands: the (k,f,g) sort key "
-                        "prunes ~92% of the band before any comparison and the rest is a 4-byte signature compare "
-                        "out of registers/LDS, so frac >> 1 measures algorithmic reuse, not HBM over-subscription; "
-                        "measured HBM bytes per launch are in profiles/ (FETCH_SIZE/WRITE_SIZE passes)",
+                "note": ("SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
+                         "band + 8 B per pruned pair.  The variant join never forms those pairs: one hash-table "
+                         "lookup per token occurrence decides all of them (O(nnz) instead of O(N^2)), so frac >> 1 "
+                         "measures the algorithmic shortcut, not HBM over-subscription; what the kernel must move "
+                         "and what it does move are in `join` below and in profiles/ (FETCH_SIZE/WRITE_SIZE passes)"
+                         if join else
+                         "SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
+                         "band + 8 B per pruned pair.  The kernel never streams those operands: the (k,f,g) sort key "
+                         "prunes ~92% of the band before any comparison and the rest is a 4-byte signature compare "
+                         "out of registers/LDS, so frac >> 1 measures algorithmic reuse, not HBM over-subscription; "
+                         "measured HBM bytes per launch are in profiles/ (FETCH_SIZE/WRITE_SIZE passes)"),
                 "pairs_in_reference_band": merged_pairs,
-                "valu": {"lane_ops_per_s": valu, "peak": VALU_PEAK_LANEOPS,
+                # the join kernel's own floor: every token, extent and row hash once (compulsory bytes) against the
+                # HBM peak; it is bound by its instruction stream (one wave-instruction sequence per row, 40 of 64 lanes
+                # busy; measured by switching its phases off: BFK_JOIN_DEBUG), not by bytes
+                **({"join": {"lookups": st["pairs_filtered"], "lookups_per_s": st["pairs_filtered"] / t_pf if t_pf > 0 else None,
+                             "compulsory_bytes": 4 * nnz + 12 * n_u,
+                             "compulsory_GBps": (4 * nnz + 12 * n_u) / world / t_pf / 1e9 if t_pf > 0 else None,
+                             "frac_of_hbm_peak": (4 * nnz + 12 * n_u) / world / t_pf / 1e9 / HBM_PEAK_GBS if t_pf > 0 else None}}
+                   if join else {}),
+                "valu": None if join else {"lane_ops_per_s": valu, "peak": VALU_PEAK_LANEOPS,
                          "frac": valu / VALU_PEAK_LANEOPS if valu else None,
                          "ops_per_pair": ops_per_pair, "pair_slots": st["pairs_filtered"],
                          "pair_slots_per_s": slots_rate, "measured_issue_ceiling_slots_per_s": slots_ceiling,

@@ -17,6 +17,9 @@
 //                lock-free union-find hooks of the verified edges (one edge per lane);
 //                k_verify_long for pairs > 192 tokens
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
+//   max_dist == 1 (up to 800k rows) replaces k_sig .. k_verify by the VARIANT JOIN: k_jhash (additive multiset hash
+//                of every row -> hash table + bitmap), k_join (one lookup per token occurrence: H(B) - h(t); matches
+//                certified by a 64-lane compare and hooked at once; the rest to k_verify) — O(nnz), no pairs formed
 //   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
 //
 // What it replaces in the reference: the band loop + get_neighbours_batch + sklearn _sparse_manhattan +

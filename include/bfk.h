@@ -47,16 +47,16 @@ typedef struct bfk_stats {
     int64_t nnz;             /* stored entries (multiset sizes summed) */
     int64_t pairs_resolved;  /* unordered pairs whose <=max_dist status this shard decided: N(N-1)/2 for 1 shard */
     int64_t pairs_in_band;   /* unordered pairs with |k_i-k_j| <= max_dist (need a set comparison), all shards */
-    int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded) */
+    int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded); variant join: table lookups */
     int64_t n_candidates;    /* pairs that passed both signature levels and were checked exactly */
     int64_t n_edges;         /* candidates with exact distance <= max_dist */
     int64_t n_retry_slices;  /* >0: the candidate queue overflowed and the run was redone in this many slices */
     int32_t max_row_len;     /* largest multiset size k */
     int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
-    int32_t n_work_items;    /* tiles (<= 64 sorted rows of one sort-key cell) of the pair kernel, all shards */
+    int32_t n_work_items;    /* tiles (<= 64 sorted rows of one sort-key cell) of the pair kernel, all shards; 0 = variant join */
     int32_t profiled;        /* number of steps the ms fields below are averaged over (0 = profiling off) */
-    float ms_prep;           /* row keys + signatures + cell histogram/ranks, scan, scatter */
-    float ms_prefilter;      /* all-pairs signature kernel (the dominant kernel) */
+    float ms_prep;           /* row keys + signatures + cell histogram/ranks, scan, scatter; variant join: k_jhash */
+    float ms_prefilter;      /* all-pairs signature kernel (the dominant kernel); variant join: k_join */
     float ms_verify;         /* exact check of the candidates + union-find hooks */
     float ms_flatten;        /* label flatten */
     float ms_total;          /* first launch to last launch completion */
