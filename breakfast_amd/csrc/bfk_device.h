@@ -19,6 +19,7 @@ constexpr int VERIFY_MAX_TOKENS = 192;  // pairs with more tokens (both rows) go
 constexpr int LONG_TABLE = 4096;        // hash-table slots in LDS per block of k_verify_long (32 KiB)
 constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long (each owns a slice of the global scratch table)
 constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-join table {tag : row}
+constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wave of k_join
 constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
@@ -45,6 +46,7 @@ struct JoinArgs {
     unsigned long long *tab, *tab_next;  // mask + 1 slots
     uint32_t *bits, *bits_next;          // bmask + 1 bits, index = low bits of H.x
     uint2 *rowhash;
+    int *batch_row;  // per JOIN_TPW tokens: the row that holds the first of them
     int2 *dups;  // pairs of rows with one H, found while inserting
     int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
     uint32_t mask, bmask;
@@ -78,7 +80,6 @@ struct Plan {
     int *labels;
     Counters *ctr;
     unsigned long long *dbg_t;
-    int join_grid;  // most blocks of k_join (it strides over the blocks of rows)
     int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;

@@ -455,7 +455,7 @@ static int sig_words_for(int d) {
 
 // The variant join serves max_dist == 1 (BFK_JOIN=0 forces the all-pairs kernels, e.g. to measure them).
 static bool join_wanted(const bfk_ctx *c, int max_dist) {
-    if (max_dist != 1 || c->join_off || c->n > ((int64_t)1 << 27)) return false;
+    if (max_dist != 1 || c->join_off || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25)) return false;
     if (const char *e = getenv("BFK_JOIN")) return atoi(e) != 0;
     // measured (ms per step, join vs all-pairs): 100k rows 0.061 / 0.074, 300k 0.153 / 0.172, 600k 0.325 / 0.360,
     // 1M 0.537 / 0.505 — both grow about linearly there, the join's cost is the instruction stream per row
@@ -466,8 +466,9 @@ static int ctx_size_join(bfk_ctx *c) {
     int64_t slots = 1024, bits = 4096;
     while (slots < 4 * c->n) slots <<= 1;  // load <= 1/4
     while (bits < 32 * c->n) bits <<= 1;   // ~3% of the bits set
-    const int64_t blocks = c->n / 16 + 2;  // k_join blocks (>= 16 rows each)
-    const int64_t bytes = 2 * slots * 8 + 2 * bits / 8 + (c->n + 16) * 8 + (4 * c->n + 65536) * 8 + blocks * 8;
+    const int64_t blocks = c->nnz / (16 * JOIN_TPW) + 2;  // k_join blocks
+    const int64_t batches = c->nnz / JOIN_TPW + 2;
+    const int64_t bytes = 2 * slots * 8 + 2 * bits / 8 + (c->n + 16) * 8 + (4 * c->n + 65536) * 8 + blocks * 8 + batches * 4;
     if (bytes > c->join_bytes || !c->d_join) {
         if (c->d_join) (void)hipFree(c->d_join);
         c->d_join = nullptr;
@@ -598,7 +599,6 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.bits = (uint32_t *)(cur ? bits1 : bits0);
         pl.ja.bits_next = (uint32_t *)(cur ? bits0 : bits1);
         pl.ja.rowhash = (uint2 *)(bits1 + c->join_bits / 8);
-        pl.join_grid = 1 << 20;
         pl.join_skip_verify = (c->join_empty_shard == shard && c->join_empty_shards == n_shards && !c->edge_capture &&
                                2 * c->kcap <= VERIFY_MAX_TOKENS && !getenv("BFK_CAND_CAP_SHARD")) ? 1 : 0;
         // k_verify only sees what k_join could not certify itself (rows in no common order, rows over 64 tokens)
@@ -606,6 +606,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.dups = (int2 *)((char *)pl.ja.rowhash + (c->n + 16) * 8);
         pl.ja.dup_cap = (int)std::min<int64_t>(4 * c->n + 65536, INT32_MAX);
         pl.ja.stats = (int *)((char *)pl.ja.dups + (4 * c->n + 65536) * 8);
+        pl.ja.batch_row = pl.ja.stats + 2 * (c->nnz / (16 * JOIN_TPW) + 2);
         pl.ja.mask = (uint32_t)(c->join_slots - 1);
         pl.ja.bmask = (uint32_t)(c->join_bits - 1);
         pl.ja.dbg = getenv("BFK_JOIN_DEBUG") ? atoi(getenv("BFK_JOIN_DEBUG")) : 0;
@@ -647,8 +648,7 @@ static int ctx_pair_stats(bfk_ctx *c, Counters *h) {
         k += (unsigned)v[i + 1];
     }
     if (c->plan.join) {  // pairs k_join certified and hooked itself
-        const int rpw = (int)std::max<int64_t>(1, std::min<int64_t>(16, (c->n + 8191) / 8192));
-        const int64_t blocks = std::min<int64_t>((c->n + rpw * 16 - 1) / (rpw * 16), c->plan.join_grid);
+        const int64_t blocks = std::max<int64_t>(1, (c->nnz + 16 * JOIN_TPW - 1) / (16 * JOIN_TPW));
         std::vector<int> j((size_t)2 * blocks);
         HIP_TRY(hipMemcpy(j.data(), c->plan.ja.stats, j.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < j.size(); i += 2) {

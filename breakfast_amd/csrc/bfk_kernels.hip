@@ -1330,6 +1330,10 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
         const int i = r0 + lane;
         ja.rowhash[i] = make_uint2(my1, my2);
         parent[i] = i;
+        {   // k_join's waves own JOIN_TPW tokens each: the row that holds a wave's first token
+            const int b = indptr[i], e = min(indptr[i + 1], nnz);
+            for (int q = (b + JOIN_TPW - 1) / JOIN_TPW; q * JOIN_TPW < e; q++) ja.batch_row[q] = i;
+        }
         atomicOr(&ja.bits[(my1 & ja.bmask) >> 5], 1u << (my1 & 31u));
         const unsigned long long ent = ((unsigned long long)my2 << 32) | (unsigned long long)(uint32_t)i;
         uint32_t s = my1 & ja.mask;
@@ -1350,27 +1354,36 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
     }
 }
 
-// k_join: the lookups, the check of the matches and the unions.  Per wave:
-//   phase A requests the first 64 tokens and the bitmap words of all its rows;
-//   phase B turns bitmap hits into entries of the wave's LDS queue {key1, key2, row, position} (a token that occurs
-//     twice in a row is looked up once: the pair would be found twice);
+// k_join: the lookups, the check of the matches and the unions.  TOKEN-parallel: a wave owns JOIN_TPW = 512
+// consecutive entries of `indices` (8 windows of 64), whatever rows they belong to — all 64 lanes work, there is no
+// per-row instruction stream and no special case for long rows (a wave per row kept 40 of 64 lanes busy and spent
+// ~170 wave-instructions per row: 38 us at 100k rows).  Per wave:
+//   (A) the 8 windows' tokens are requested at once, together with the extents and the hashes of the 64 rows from
+//       the row that holds the wave's first token (k_jhash left that row in batch_row[]); a lane finds its row by
+//       counting the row boundaries at or below its token (a short wave-uniform loop: ~1.6 boundaries per window),
+//       takes the row's H from the hash register of that row's lane (ds_bpermute) and requests the bitmap word of
+//       H - h(token).  A scattered load costs one request per distinct line: lanes with nothing to ask all ask
+//       for word 0 through an UNCONDITIONAL load of a SELECTED address (a load under a lane mask made the compiler
+//       wait for each load in turn).  Batches whose rows do not fit the 64 loaded extents (runs of tiny or empty
+//       rows) find their rows by binary search (slow_window);
+//   (B) bitmap hits -> the wave's LDS queue {key.x, key.y, row B, position p};
 //   drain() probes the table for a whole queue at once, one lookup per lane, two slots per step;
 //   settle() takes the matches (A, B, p) — B minus its token at position p hashes like A — and checks them right
 //     here: profiles list their mutations in one order, so A is almost always B with position p deleted, i.e.
 //     A[j] == B[j + (j >= p)] for all j, a 64-lane compare of two coalesced loads (four matches in flight); a
-//     certified pair is hooked into the union-find at once, one edge per lane.  Whatever fails that test (another
-//     token order, a hash collision) goes to the candidate queue and k_verify's exact count.
+//     certified pair is hooked into the union-find at once, one edge per lane.  A token that occurs several times
+//     in B is looked up at every occurrence: the pair counts at the first one only.  Whatever fails the test
+//     (another token order, a hash collision) goes to the candidate queue and k_verify's exact count.
 __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
-                                                int nnz, int rpw, JoinArgs ja, PairArgs pa, int shard0, int nshards,
-                                                int2 *edges, int edge_cap) {
+                                                   int nnz, JoinArgs ja, PairArgs pa, int shard0, int nshards, int2 *edges,
+                                                   int edge_cap) {
     constexpr int QCAP = 128, MCAP = 64;
     __shared__ uint32_t q_k1[16][QCAP], q_k2[16][QCAP];
-    __shared__ int q_b[16][QCAP];             // row of the wave (4 bits) | token position << 4
-    __shared__ int m_a[16][MCAP], m_b[16][MCAP];  // matches: row A, q_b of the lookup
+    __shared__ int q_b[16][QCAP], q_p[16][QCAP];                 // row B, position of the looked-up token in B
+    __shared__ int m_a[16][MCAP], m_b[16][MCAP], m_p[16][MCAP];  // matches: row A, row B, position
     __shared__ unsigned s_edges, s_cands;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rows_per_block = rpw * 16;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cshard = (blockIdx.x * 16 + wave) & (CAND_SHARDS - 1);
     if (threadIdx.x == 0) s_edges = s_cands = 0;
@@ -1396,7 +1409,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
         }
     };
 
-    {   // rows k_jhash found to share one H: the block of the later row owns the pair (the same on every rank)
+    {   // rows k_jhash found to share one H: the rank (later row) % nshards owns the pair (the same on every rank)
         const int ndup = (int)min(pa.ctr->n_dup, (unsigned)ja.dup_cap);
         const int per = (int)gridDim.x * 1024;
         for (int i0 = (int)blockIdx.x * 1024 + wave * 64; i0 < ndup; i0 += per) {  // wave-uniform trip count
@@ -1407,7 +1420,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                 const int2 pr = ja.dups[i];
                 A = min(pr.x, pr.y);
                 B = max(pr.x, pr.y);
-                mine = (B / rows_per_block) % nshards == shard0;
+                mine = B % nshards == shard0;
                 if (mine) {
                     ba = indptr[A];
                     ea = indptr[A + 1];
@@ -1418,20 +1431,14 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             enqueue(mine, A, B, ba, bb, ea - ba, eb - bb);
         }
     }
-    // the grid strides over blocks of rows_per_block rows; multi-GPU: those are dealt round-robin; without any token
-    // there is nothing to look up
-    uint32_t *qk1 = q_k1[wave], *qk2 = q_k2[wave];
-    int *qb = q_b[wave], *ma = m_a[wave], *mb = m_b[wave];
+    // multi-GPU: the blocks (16 x 512 tokens, i.e. their lookups) are dealt round-robin
+    const int gw = blockIdx.x * 16 + wave;
+    const int T0 = gw * JOIN_TPW;  // (the host keeps nnz + JOIN_TPW below 2^31)
     unsigned my_edges = 0, my_cands = 0;
-    const int nvb = nnz > 0 ? (n + rows_per_block - 1) / rows_per_block : 0;
-#pragma unroll 1
-    for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-        if (vb % nshards != shard0) continue;
-        const int r0 = vb * rows_per_block + wave * rpw;
-        const int nr = max(0, min(rpw, n - r0));
-        if (nr <= 0) continue;
+    if ((int)(blockIdx.x % (unsigned)nshards) == shard0 && T0 < nnz) {
+        uint32_t *qk1 = q_k1[wave], *qk2 = q_k2[wave];
+        int *qb = q_b[wave], *qp = q_p[wave], *ma = m_a[wave], *mb = m_b[wave], *mp = m_p[wave];
         int nq = 0, nm = 0;  // wave-uniform
-        const int ext = indptr[min(r0 + min(lane, rpw), n)];
 
         auto settle = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1439,16 +1446,13 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (ja.dbg & 1) nm = 0;
             const bool have = lane < nm;
-            const int A = have ? ma[lane] : 0;
-            const int tb = have ? mb[lane] : 0;
-            const int t = tb & 15, p = tb >> 4;
-            const int B = r0 + t;
-            const int bb = __shfl(ext, t), eb = __shfl(ext, t + 1);
+            const int A = have ? ma[lane] : 0, B = have ? mb[lane] : 0, p = have ? mp[lane] : 0;
             const int ba = have ? indptr[A] : 0, ea = have ? indptr[A + 1] : 0;
-            const uint32_t tok = have ? indices[min(bb + p, nnz - 1)] : 0u;  // the token whose deletion was looked up
+            const int bb = have ? indptr[B] : 0, eb = have ? indptr[B + 1] : 0;
             const int ka = ea - ba, kb = eb - bb;
             // B minus one token has k_b - 1 tokens: anything else is a hash collision
             const bool live = have && kb == ka + 1;
+            const uint32_t tok = live ? indices[bb + p] : 0u;  // the token whose deletion was looked up
             bool cert = false, dup = false;
             for (int m0 = 0; m0 < nm; m0 += 4) {  // four matches in flight
                 uint32_t av[4], bv[4];
@@ -1466,8 +1470,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                     const int ka_m = __builtin_amdgcn_readlane(ka, m), p_m = __builtin_amdgcn_readlane(p, m);
                     const uint32_t tok_m = (uint32_t)__builtin_amdgcn_readlane((int)tok, m);
                     const bool ok = __builtin_amdgcn_ballot_w64(lane < ka_m && av[u] != bv[u]) == 0ull;
-                    // a token that occurs more than once in B is looked up at every occurrence: the pair counts at
-                    // the first one only (lanes below p hold B[lane])
+                    // the pair counts at the first occurrence of the token in B only (lanes below p hold B[lane])
                     const bool again = __builtin_amdgcn_ballot_w64(lane < p_m && bv[u] == tok_m) != 0ull;
                     if (lane == m) {
                         cert = ok;
@@ -1517,17 +1520,17 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                 const int i = q0 + lane;
                 bool active = i < nq;
                 const uint32_t k2 = active ? qk2[i] : 0u;
-                const int bt = active ? qb[i] : 0;
+                const int qB = active ? qb[i] : 0, qP = active ? qp[i] : 0;
                 uint32_t s = (active ? qk1[i] : 0u) & ja.mask;
                 int probes = 0;
                 while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
                     unsigned long long e0 = JOIN_EMPTY, e1 = JOIN_EMPTY;
-                    if (active) {  // two slots per step: at load 1/8 nearly every chain ends inside them
+                    if (active) {  // two slots per step: at load 1/4 nearly every chain ends inside them
                         e0 = ja.tab[s];
                         e1 = ja.tab[(s + 1) & ja.mask];
                     }
-                    const bool m0 = active && e0 != JOIN_EMPTY && (uint32_t)(e0 >> 32) == k2;
-                    const bool m1 = active && e0 != JOIN_EMPTY && e1 != JOIN_EMPTY && (uint32_t)(e1 >> 32) == k2;
+                    const bool h0 = active && e0 != JOIN_EMPTY && (uint32_t)(e0 >> 32) == k2;
+                    const bool h1 = active && e0 != JOIN_EMPTY && e1 != JOIN_EMPTY && (uint32_t)(e1 >> 32) == k2;
                     if (active) {
                         if (e0 == JOIN_EMPTY || e1 == JOIN_EMPTY) active = false;
                         s = (s + 2) & ja.mask;
@@ -1539,14 +1542,15 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                     }
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const bool mt = h ? m1 : m0;
+                        const bool mt = h ? h1 : h0;
                         const unsigned long long mm = __builtin_amdgcn_ballot_w64(mt);
                         if (mm == 0ull) continue;
                         if (nm + __popcll(mm) > MCAP) settle();
                         if (mt) {
                             const int pos = nm + __popcll(mm & lt);
                             ma[pos] = (int)(uint32_t)(h ? e1 : e0);
-                            mb[pos] = bt;
+                            mb[pos] = qB;
+                            mp[pos] = qP;
                         }
                         nm += __popcll(mm);
                     }
@@ -1556,60 +1560,65 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             nq = 0;
         };
 
-        // hits of one 64-token chunk of row t -> queue (hs = first hash stage of the lane's token)
-        auto push_hits = [&](int t, int j0, bool valid, uint32_t hs, uint32_t k1, uint32_t w, uint32_t S2) {
-            unsigned long long hm = __builtin_amdgcn_ballot_w64(valid && ((w >> (k1 & 31u)) & 1u));
+        // bitmap hits of one window -> queue
+        auto push_hits = [&](bool hit, uint32_t k1, uint32_t k2, int B, int p) {
+            unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
             if (ja.dbg & 4) hm = 0ull;
             if ((hm >> lane) & 1ull) {
                 const int pos = nq + __popcll(hm & lt);
                 qk1[pos] = k1;
-                qk2[pos] = S2 - jh2_of(hs);
-                qb[pos] = t | ((j0 + lane) << 4);
+                qk2[pos] = k2;
+                qb[pos] = B;
+                qp[pos] = p;
             }
             nq += __popcll(hm);
         };
 
-        uint2 hv = make_uint2(0u, 0u);
-        if (lane < nr) hv = ja.rowhash[r0 + lane];
-        unsigned slow = 0;  // rows left to the generic loop below: longer than 64 tokens, or the queue was nearly full
+        const int r0 = ja.batch_row[gw];                      // the row that holds token T0
+        const int extm = indptr[min(r0 + lane, n)];            // lane 0: start of row r0; lane l: end of row r0 + l - 1
+        const uint2 rh = ja.rowhash[min(r0 + lane, n - 1)];    // lane l: H of row r0 + l
+        const int Tend = min(T0 + JOIN_TPW, nnz);
+        unsigned pend = 0;  // windows left to slow_window: the rows did not fit the 64 extents, or the queue was nearly full
+        const bool covered = __builtin_amdgcn_readlane(extm, 63) >= Tend;
+        int base = 0;  // boundaries (extm[1..]) already at or below the window start
 #pragma unroll 1
-        for (int t0 = 0; t0 < nr; t0 += 8) {  // eight rows in flight (sixteen do not fit 64 VGPRs = two blocks per CU)
-            uint32_t xs[8], wv[8];  // xs: the token, then its first hash stage (tokens are not needed again)
+        for (int ub = 0; ub < 8; ub += 4) {  // four windows in flight (eight do not fit 64 VGPRs = two blocks per CU)
+            uint32_t xs[4], wv[4], k1s[4];  // xs: the token, then its first hash stage
+            int rp[4];                      // row offset from r0 (6 bits) | position in the row << 6
+            if (T0 + 64 * ub >= Tend) break;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int bt = __builtin_amdgcn_readlane(ext, t0 + u);
-                xs[u] = indices[min(max(bt, 0) + lane, nnz - 1)];
-            }
+            for (int u = 0; u < 4; u++) xs[u] = indices[min(T0 + 64 * (ub + u) + lane, nnz - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t S1 = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, t0 + u);
-                const int k = __builtin_amdgcn_readlane(ext, t0 + u + 1) - __builtin_amdgcn_readlane(ext, t0 + u);
+            for (int u = 0; u < 4; u++) {
+                const int j0 = T0 + 64 * (ub + u), j = j0 + lane;
+                int ro = base, st = __builtin_amdgcn_readlane(extm, base);
+                while (base < 63) {  // wave-uniform
+                    const int e = __builtin_amdgcn_readlane(extm, base + 1);
+                    if (e >= j0 + 64) break;
+                    ro += j >= e ? 1 : 0;
+                    st = j >= e ? e : st;
+                    base++;
+                }
+                const uint32_t S1 = (uint32_t)__shfl((int)rh.x, ro);
                 xs[u] = jh_stage(xs[u]);
-                const uint32_t k1 = S1 - jh1_of(xs[u]);
-                // a scattered load costs one cache-line request per distinct line: lanes past the row all ask for
-                // word 0 (an UNCONDITIONAL load of a selected address — a load under a lane mask made the compiler
-                // wait for each load before issuing the next)
-                wv[u] = ja.bits[lane < k ? ((k1 & ja.bmask) >> 5) : 0u];
+                k1s[u] = S1 - jh1_of(xs[u]);
+                rp[u] = ro | ((j - st) << 6);
+                wv[u] = ja.bits[(covered && j < Tend && !(ja.dbg & 128)) ? ((k1s[u] & ja.bmask) >> 5) : 0u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int t = t0 + u;
-                if (t >= nr) continue;  // wave-uniform
-                const int b = __builtin_amdgcn_readlane(ext, t), e = __builtin_amdgcn_readlane(ext, t + 1);
-                const int k = e - b;  // (k_jhash has flagged malformed extents)
-                if (k <= 0) continue;
-                if (k > 64 || nq > QCAP - 64) {
-                    slow |= 1u << t;
+            for (int u = 0; u < 4; u++) {
+                const int j0 = T0 + 64 * (ub + u), j = j0 + lane;
+                if (j0 >= Tend) continue;  // wave-uniform
+                if (!covered || nq > QCAP - 64) {
+                    pend |= 1u << (ub + u);
                     continue;
                 }
-                const uint32_t S1 = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, t);
-                const uint32_t S2 = (uint32_t)__builtin_amdgcn_readlane((int)hv.y, t);
-                push_hits(t, 0, lane < k, xs[u], S1 - jh1_of(xs[u]), wv[u], S2);
+                const int ro = rp[u] & 63;
+                const uint32_t S2 = (uint32_t)__shfl((int)rh.y, ro);
+                push_hits(j < Tend && ((wv[u] >> (k1s[u] & 31u)) & 1u), k1s[u], S2 - jh2_of(xs[u]), r0 + ro, rp[u] >> 6);
             }
         }
-        // the one drain site: after the fast loop, whenever a chunk of a slow row could overfill the queue, at the end
-        int st = -1, sb = 0, sk = 0, sj = 0;
-        uint32_t sS1 = 0, sS2 = 0;
+        // the one drain site: after the fast windows, whenever a slow window could overfill the queue, at the end
         bool first = true, fin = false;
         while (true) {
             if (first || fin || nq > QCAP - 64) {
@@ -1617,26 +1626,26 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                 first = false;
                 if (fin) break;
             }
-            if (st < 0 || sj >= sk) {  // next slow row
-                if (slow == 0u) {
-                    fin = true;
-                    continue;
-                }
-                st = (int)__builtin_ctz(slow);
-                slow &= slow - 1u;
-                sb = __shfl(ext, st);
-                sk = __shfl(ext, st + 1) - sb;
-                sS1 = (uint32_t)__shfl((int)hv.x, st);
-                sS2 = (uint32_t)__shfl((int)hv.y, st);
-                sj = 0;
+            if (pend == 0u) {
+                fin = true;
                 continue;
             }
-            const bool valid = lane < sk - sj;
-            const uint32_t hs = jh_stage(valid ? indices[sb + sj + lane] : 0u);
-            const uint32_t k1 = sS1 - jh1_of(hs);
+            // slow_window: every lane finds the row of its token by binary search over indptr
+            const int u = (int)__builtin_ctz(pend);
+            pend &= pend - 1u;
+            const int j = T0 + 64 * u + lane;
+            const bool valid = j < Tend;
+            int lo = 0, hi = n;  // last row r with indptr[r] <= j (it holds token j: indptr[r + 1] > j)
+            while (hi - lo > 1) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (indptr[mid] <= (valid ? j : 0)) lo = mid; else hi = mid;
+            }
+            const int B = lo;
+            const uint2 hB = ja.rowhash[B];
+            const uint32_t hs = jh_stage(indices[valid ? j : 0]);
+            const uint32_t k1 = hB.x - jh1_of(hs);
             const uint32_t w = ja.bits[valid ? ((k1 & ja.bmask) >> 5) : 0u];
-            push_hits(st, sj, valid, hs, k1, w, sS2);
-            sj += 64;
+            push_hits(valid && ((w >> (k1 & 31u)) & 1u), k1, hB.y - jh2_of(hs), B, j - indptr[B]);
         }
         settle();
     }
@@ -1858,8 +1867,9 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
                            pl.parent, pl.ctr);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
-        hipLaunchKernelGGL(k_join, dim3(std::min(blocks, pl.join_grid)), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, rpw,
-                           pl.ja, pa, pl.shard, pl.n_shards, pl.edges, pl.edge_cap);
+        const int jblocks = std::max(1, (int)(((long long)pl.nnz + 16 * JOIN_TPW - 1) / (16 * JOIN_TPW)));
+        hipLaunchKernelGGL(k_join, dim3(jblocks), dim3(1024), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.ja, pa, pl.shard,
+                           pl.n_shards, pl.edges, pl.edge_cap);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         if (pl.join_skip_verify) {  // nothing was queued the last time (k_flatten checks that this still holds)

@@ -547,10 +547,19 @@ def _join_cases():
         cases[name] = (indptr, np.concatenate(rows).astype(np.int32))
     uf = list(dict.fromkeys(generate_profiles(30000, p_del=0.05, p_ins=0.02)))
     cases["profiles30k"] = _lib.build_csr(uf, " ")[:2]
+    # rows of 0..4 tokens: 512 consecutive tokens span far more than 64 rows, so k_join finds the row of a token by
+    # binary search (slow_window) instead of from the 64 extents a wave loads
+    rows = [rng.choice(4000, size=int(rng.integers(1, 5)), replace=False).astype(np.int32) for _ in range(6000)]
+    for i in range(0, 6000, 150):
+        rows[i] = np.zeros(0, np.int32)
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    cases["tiny_rows"] = (indptr, np.concatenate(rows).astype(np.int32))
     return cases
 
 
-@pytest.mark.parametrize("name", ["small_alphabet", "medium", "long_rows", "perms100", "perms400", "profiles30k"])
+@pytest.mark.parametrize("name", ["small_alphabet", "medium", "long_rows", "perms100", "perms400", "profiles30k",
+                                  "tiny_rows"])
 def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
     """max_dist 1 is served by the hash join (H(B) - h(t) lookups): labels, edge count and neighbour
     lists must equal those of the all-pairs kernels and of the oracle — repeated tokens (a pair must be found once),
@@ -590,7 +599,7 @@ def test_variant_join_on_a_resident_context_alternates_its_tables():
     in between must not leave stale entries"""
     cases = _join_cases()
     ctx = _lib.Context(0)
-    for name in ("medium", "long_rows", "profiles30k", "medium", "perms100"):
+    for name in ("medium", "long_rows", "profiles30k", "tiny_rows", "medium", "perms100"):
         indptr, indices = cases[name]
         n = len(indptr) - 1
         want = orc.cluster_csr(indptr, indices, 1, n_threads=8)["labels"]

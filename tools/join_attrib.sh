@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing attribution of the variant join: bench phases with parts of the kernels switched off (BFK_JOIN_DEBUG)
 cd "$(dirname "$0")/.."
-for dbg in 0 32 1 3 7 8 24; do
+for dbg in ${DBGS:-0 32 1 3 7 8 24}; do
   BFK_JOIN_DEBUG=$dbg python bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > gpurun_out/ja_$dbg.json 2>/dev/null
   python - <<PY
 import json
