@@ -51,8 +51,8 @@ struct JoinArgs {
     int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
     uint32_t mask, bmask;
     int dup_cap;
-    int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no bitmap test,
-              // 8 no table insert, 16 no clearing, 32 no unions
+    int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no queueing of
+              // bitmap hits, 8 no table insert, 16 no clearing, 32 no unions, 128 no scattered bitmap loads
 };
 
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).
