@@ -455,7 +455,9 @@ static int sig_words_for(int d) {
 
 // The variant join serves max_dist == 1 (BFK_JOIN=0 forces the all-pairs kernels, e.g. to measure them).
 static bool join_wanted(const bfk_ctx *c, int max_dist) {
-    if (max_dist != 1 || c->join_off || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25)) return false;
+    if (max_dist != 1 || c->join_off || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25) ||
+        c->nnz > (int64_t)INT32_MAX - 4 * JOIN_TPW)  // 32-bit token offsets, position packed above 6 bits
+        return false;
     if (const char *e = getenv("BFK_JOIN")) return atoi(e) != 0;
     // measured (ms per step, join vs all-pairs): 100k rows 0.061 / 0.074, 300k 0.153 / 0.172, 600k 0.325 / 0.360,
     // 1M 0.537 / 0.505 — both grow about linearly there, the join's cost is the instruction stream per row
