@@ -83,12 +83,32 @@ def cpu_baseline(indptr, indices, d, n_u, target_s=15.0):
     t0 = time.perf_counter()
     res = orc.cluster_csr(indptr, indices, d, select_ind=sel, n_threads=cores)
     t = time.perf_counter() - t0
-    return {
+    out = {
         "value": s * (n_u - 1) / 2 / t, "unit": "pairs/s", "cores": cores, "kind": "port",
         "sample": f"{s} of {n_u} query rows x all columns (select_ind shape), {res['n_merges']} row merges "
                   f"in {t:.1f} s, OpenMP over query rows like sklearn's prange",
         "seconds": round(t, 2),
     }
+    # beside it, when the box has them: the third-party kernel the reference itself calls (scikit-learn's
+    # pairwise_distances_chunked / _sparse_manhattan on the length bands, oracle/sk_port.py), same sample shape,
+    # time spent inside the sklearn calls only; its OpenMP threads = all host cores
+    try:
+        from oracle import sk_port
+
+        if sk_port.available():
+            sel0 = np.sort(rng.choice(n_u, size=min(n_u, 200), replace=False)).astype(np.int64)
+            _, t0s = sk_port.neighbours(indptr, indices, d, select_ind=sel0)
+            s2 = int(min(n_u, max(200, 200 * 8.0 / max(t0s, 1e-3))))
+            sel2 = np.sort(rng.choice(n_u, size=s2, replace=False)).astype(np.int64)
+            _, ts = sk_port.neighbours(indptr, indices, d, select_ind=sel2)
+            out["sklearn"] = {"value": s2 * (n_u - 1) / 2 / ts, "unit": "pairs/s", "cores": cores,
+                              "sample": f"{s2} of {n_u} query rows x their length bands, "
+                                        f"{sk_port.merges(indptr, d, sel2)} row merges, {ts:.1f} s inside "
+                                        f"pairwise_distances_chunked(metric='manhattan')",
+                              "seconds": round(ts, 2), "versions": sk_port.versions()}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        out["sklearn"] = {"error": repr(e)}
+    return out
 
 
 def main():

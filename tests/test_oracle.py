@@ -63,6 +63,42 @@ def test_get_neighbours_batch_per_band(name):
     assert seen == edges
 
 
+@pytest.mark.parametrize("n,d,p_del,p_ins", [(1500, 1, 0.0, 0.0), (1500, 2, 0.0, 0.0), (800, 5, 0.05, 0.01)])
+def test_c_restatement_against_the_sklearn_kernel_the_reference_calls(n, d, p_del, p_ins):
+    """oracle/sk_port.py makes the reference's own third-party call (pairwise_distances_chunked, manhattan, on the
+    length band) — the C restatement must find the same neighbours row by row, do the same number of row merges,
+    and the components must be the components of that graph (seeded inputs beyond the committed fixtures)"""
+    from oracle import sk_port
+
+    if not sk_port.available():
+        pytest.skip("scikit-learn / scipy not importable")
+    from breakfast_amd.synth import generate_profiles
+
+    rows = list(dict.fromkeys(generate_profiles(n, p_del=p_del, p_ins=p_ins, seed=99 + d)))
+    indptr, indices, nv = orc.sparse_feature_matrix(rows, " ")
+    nf = np.diff(indptr)
+    want, _ = sk_port.neighbours(indptr, indices, d, n_vocab=nv)
+    got = [set() for _ in rows]
+    for q in dict.fromkeys(nf.tolist()):
+        qrows = np.flatnonzero(np.abs(nf - q) <= d)
+        for i, l in zip(qrows, orc.get_neighbours_batch(indptr, indices, nf, q, d)):
+            got[i] |= set(l.tolist())
+    assert all(sorted(g) == w.tolist() for g, w in zip(got, want))
+    res = orc.cluster_csr(indptr, indices, d)
+    assert res["n_merges"] == sk_port.merges(indptr, d)
+    # components of the sklearn graph by a plain label propagation
+    lab = np.arange(len(rows))
+    changed = True
+    while changed:
+        changed = False
+        for i, w in enumerate(want):
+            m = lab[w].min()
+            if (lab[w] != m).any():
+                lab[w] = m
+                changed = True
+    assert np.array_equal(res["labels"], lab)
+
+
 def test_select_ind_path():
     g = load_stage("syn200_d1")
     nf = g["n_features"]
