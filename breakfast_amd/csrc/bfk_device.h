@@ -52,7 +52,7 @@ struct JoinArgs {
     uint32_t mask, bmask;
     int dup_cap;
     int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no queueing of
-              // bitmap hits, 8 no table insert, 16 no clearing, 32 no unions, 128 no scattered bitmap loads
+              // bitmap hits, 8 no table insert, 16 no clearing, 32 no unions, 128 no scattered bitmap loads, 256 no bitmap atomicOr
 };
 
 // Everything one enqueue of the pipeline needs (device pointers live in the ctx workspace).

@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
             const int b = indptr[i], e = min(indptr[i + 1], nnz);
             for (int q = (b + JOIN_TPW - 1) / JOIN_TPW; q * JOIN_TPW < e; q++) ja.batch_row[q] = i;
         }
-        atomicOr(&ja.bits[(my1 & ja.bmask) >> 5], 1u << (my1 & 31u));
+        if (!(ja.dbg & 256)) atomicOr(&ja.bits[(my1 & ja.bmask) >> 5], 1u << (my1 & 31u));
         const unsigned long long ent = ((unsigned long long)my2 << 32) | (unsigned long long)(uint32_t)i;
         uint32_t s = my1 & ja.mask;
         for (int probes = 0; !(ja.dbg & 8); probes++) {
