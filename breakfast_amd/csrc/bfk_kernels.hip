@@ -106,6 +106,22 @@ __device__ __forceinline__ bool uf_union(int *parent, int a, int b) {
     return false;
 }
 
+// Union by splicing (Rem's algorithm), one returning atomic per step and no loads: parent[hi] = min(parent[hi], lo)
+// keeps every invariant above (the value stored is <= hi and of hi's final component); if hi was a root, or already
+// pointed at lo, the edge is in; otherwise hi's former parent `old` and lo still have to be united — both are below
+// hi, so the walk ends.  Where nearly every edge meets two fresh or shallow nodes (max_dist <= 2) this is one
+// memory round trip per edge instead of two loads, the finds and the hook; in dense graphs (max_dist >= 3), where
+// most edges are redundant, uf_union's two loads end them sooner (see make_pair_args).
+__device__ __forceinline__ void uf_link(int *parent, int a, int b) {
+    while (a != b) {
+        const int hi = max(a, b), lo = min(a, b);
+        const int old = atomicMin(parent + hi, lo);
+        if (old == hi || old == lo) break;
+        a = old;
+        b = lo;
+    }
+}
+
 // slot hash of the verify tables
 __device__ __forceinline__ uint32_t hash3(uint32_t x) {
     uint32_t h = x * 0xC2B2AE35u;
@@ -495,6 +511,7 @@ struct PairArgs {
     int n, nnz;
     int union_batch;  // edges a 16-lane group of k_verify collects before it hooks them (power of two <= 16)
     int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
+    int use_link;  // k_verify hooks its edges with uf_link (splicing) instead of uf_union (find + hook)
     Counters *ctr;
 };
 
@@ -1133,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                 nkept++;
                 if ((nkept & ubm) == 0) {  // the batch is full: hook these edges now
                     if (my_a >= 0) {  // lanes beyond the batch size hold no edge
-                        uf_union(pa.parent, my_a, my_b);
+                        if (pa.use_link) uf_link(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
                         if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
                     }
                     my_a = my_b = -1;
@@ -1147,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     }
     // one edge per lane: the dependent find / CAS chains of all edges of the wave overlap
     if (my_a >= 0) {
-        uf_union(pa.parent, my_a, my_b);
+        if (pa.use_link) uf_link(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
         if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
     }
     if (l16 == 0 && nkept) atomicAdd(&blk_edges, (unsigned)nkept);
@@ -1500,7 +1517,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             }
             cert = cert && live && !dup;
             if (cert && !(ja.dbg & 32)) {
-                uf_union(pa.parent, A, B);
+                uf_link(pa.parent, A, B);
                 if (edges) record_edge(pa, edges, edge_cap, A, B);
             }
             const int nc = __popcll(__builtin_amdgcn_ballot_w64(cert));
@@ -1746,6 +1763,11 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.union_batch = (pl.d == 2 || pl.d == 3) ? 8 : 16;
     if (const char *e = getenv("BFK_UNION_BATCH")) pa.union_batch = atoi(e) >= 16 ? 16 : (atoi(e) >= 8 ? 8 : (atoi(e) >= 4 ? 4 : 2));
     pa.dbg = pl.dbg;
+    // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
+    // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
+    // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
+    pa.use_link = pl.d <= 2 ? 1 : 0;
+    if (const char *e = getenv("BFK_UF_LINK")) pa.use_link = atoi(e) != 0;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
     pa.candk = pl.candk;
