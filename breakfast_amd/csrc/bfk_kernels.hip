@@ -1045,9 +1045,9 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     int2 kk_n = pa.candk[base + min(j0 + jstep, capm1)];
     const int cnt = (int)min(cnt_raw, (unsigned)pa.cand_cap_shard);
     // lane i of the group keeps the group's i-th edge of the current batch; a batch is hooked when it is full and
-    // at the end.  Batches of 8 at d = 2, 3, where a group sees ~10 edges: the hooks then interleave with the
+    // at the end.  Batches of 8 at d = 3, where a group sees ~10 edges: the hooks then interleave with the
     // checks of other waves instead of arriving in one burst at the end of the kernel (100k rows, d = 3: 0.35 vs
-    // 0.52 ms for the kernel with batches of 8 vs 16; d = 2: 0.135 vs 0.137; 1M rows, d = 5: 16 is better)
+    // 0.52 ms for the kernel with batches of 8 vs 16; 1M rows, d = 5: 16 is better; d <= 2 hooks by splicing: 16)
     int my_a = -1, my_b = -1;
     int nkept = 0;
     const int ubm = pa.union_batch - 1;
@@ -1760,7 +1760,7 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.srec = pl.srec;
     pa.n = pl.n;
     pa.nnz = pl.nnz;
-    pa.union_batch = (pl.d == 2 || pl.d == 3) ? 8 : 16;
+    pa.union_batch = pl.d == 3 ? 8 : 16;  // (d = 2 hooks by splicing: 16 is better there, 0.169 vs 0.172 ms at 100k rows)
     if (const char *e = getenv("BFK_UNION_BATCH")) pa.union_batch = atoi(e) >= 16 ? 16 : (atoi(e) >= 8 ? 8 : (atoi(e) >= 4 ? 4 : 2));
     pa.dbg = pl.dbg;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
