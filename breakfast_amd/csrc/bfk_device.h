@@ -60,6 +60,7 @@ struct Plan {
     int n, nnz, kcap, d, w1;
     int rows_per_lane, fb, gb, hb;
     int shard, n_shards;
+    int verify_phases, verify_phase2_union;  // > 1: two-phase verify (first 1/phases of every shard, compress, the rest)
     int verify_grid, wave_table_d;  // k_verify: per-wave hash table up to this max_dist, per-group tables beyond
     int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)

@@ -247,11 +247,11 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
     }
     c->stream = c->own_stream;
     if (hipMalloc((void **)&c->d_small, 64) != hipSuccess ||
-        hipMalloc((void **)&c->d_blk_stats, (size_t)VERIFY_GRID_MAX * 2 * sizeof(int)) != hipSuccess) {
+        hipMalloc((void **)&c->d_blk_stats, (size_t)VERIFY_GRID_MAX * 4 * sizeof(int)) != hipSuccess) {
         delete c;
         return fail(BFK_ENOMEM, "hipMalloc failed");
     }
-    (void)hipMemset(c->d_blk_stats, 0, (size_t)VERIFY_GRID_MAX * 2 * sizeof(int));
+    (void)hipMemset(c->d_blk_stats, 0, (size_t)VERIFY_GRID_MAX * 4 * sizeof(int));
     *ctx_out = c;
     return BFK_OK;
 }
@@ -526,6 +526,14 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     pl.verify_grid = max_dist <= pl.wave_table_d ? 1536 : 2048;
     if (const char *e = getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, std::max(32, atoi(e) / 32 * 32));
     pl.blk_stats = c->d_blk_stats;
+    // two-phase verify (first 1/8 of every queue shard by splicing, compress the forest, the rest by find + hook): pays
+    // where the hooks of a dense graph fight over few roots — measured (verify kernel, one / two phases): 100k rows
+    // d = 3: 374 / 273 us, d = 4: 590 / 470 us; no gain at d = 5 (849 / 849: the exact counts dominate), a loss at
+    // 1M rows (d = 3: 1.49 / 1.85 ms, d = 5: 5.1 / 5.7 ms) and nothing to win at d <= 2 (sparse forests, splicing)
+    pl.verify_phases = ((max_dist == 3 || max_dist == 4) && c->n < 400000) ? 8 : 1;
+    pl.verify_phase2_union = 0;
+    if (const char *e = getenv("BFK_VERIFY_PHASES")) pl.verify_phases = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("BFK_VERIFY_PHASE2")) pl.verify_phase2_union = std::max(0, std::min(2, atoi(e)));
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
     pl.pf_blocks = c->n_cus * 256;  // upper bound of the pair kernel's grid (it strides over the tile entries)
     pl.pf_waves = (c->rows_per_lane == 1 && c->n < 400000) ? 4 : 2;
@@ -641,7 +649,7 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
 // k_verify leaves its per-block edge / candidate counts in plain stores (no same-word atomics): add them to
 // the counters read back from the device (n_edges already holds the edges of the long-pair kernel)
 static int ctx_pair_stats(bfk_ctx *c, Counters *h) {
-    std::vector<int> v((size_t)2 * c->plan.verify_grid);
+    std::vector<int> v((size_t)2 * c->plan.verify_grid * (c->plan.verify_phases > 1 ? 2 : 1));
     if (c->plan.join && c->plan.join_skip_verify) v.clear();  // k_verify did not run: its counts are another step's
     if (!v.empty()) HIP_TRY(hipMemcpy(v.data(), c->d_blk_stats, v.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long e = 0, k = 0;

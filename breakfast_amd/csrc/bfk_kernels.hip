@@ -122,6 +122,13 @@ __device__ __forceinline__ void uf_link(int *parent, int a, int b) {
     }
 }
 
+// after a compression pass (k_compress) nearly every node points at its root: equal first hops = same tree already,
+// one round trip of loads for a redundant edge; otherwise splice from the parents
+__device__ __forceinline__ void uf_link_checked(int *parent, int a, int b) {
+    const int pa = ld_agent(parent + a), pb = ld_agent(parent + b);
+    if (pa != pb) uf_link(parent, pa, pb);
+}
+
 // slot hash of the verify tables
 __device__ __forceinline__ uint32_t hash3(uint32_t x) {
     uint32_t h = x * 0xC2B2AE35u;
@@ -511,7 +518,9 @@ struct PairArgs {
     int n, nnz;
     int union_batch;  // edges a 16-lane group of k_verify collects before it hooks them (power of two <= 16)
     int dbg;  // BFK_PF_DEBUG experiments: 1 = no flush, 2 = no rescan (results wrong; timing only)
-    int use_link;  // k_verify hooks its edges with uf_link (splicing) instead of uf_union (find + hook)
+    int use_link;  // k_verify hooks its edges with 0 uf_union (find + hook), 1 uf_link (splicing), 2 first hops, then splicing
+    int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
+    int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
     Counters *ctr;
 };
 
@@ -1051,8 +1060,18 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     int my_a = -1, my_b = -1;
     int nkept = 0;
     const int ubm = pa.union_batch - 1;
-    if (j0 == 0 && l16 == 0 && cnt) atomicAdd(&blk_cands, (unsigned)cnt);
-    if (j0 < cnt) {
+    if (j0 == 0 && l16 == 0 && cnt && pa.part_lo == 0) atomicAdd(&blk_cands, (unsigned)cnt);
+    // the part of the shard this launch works on (the whole shard unless the kernel runs in two phases)
+    const int e_lo = (int)((long long)cnt * pa.part_lo / pa.part_den), e_hi = (int)((long long)cnt * pa.part_hi / pa.part_den);
+    int e_first = j0;
+    if (e_lo > j0) {
+        e_first = j0 + (e_lo - j0 + jstep - 1) / jstep * jstep;
+        rec = pa.cand[base + min(e_first, capm1)];
+        kk = pa.candk[base + min(e_first, capm1)];
+        rec_n = pa.cand[base + min(e_first + jstep, capm1)];
+        kk_n = pa.candk[base + min(e_first + jstep, capm1)];
+    }
+    if (e_first < e_hi) {
         // A group has only ~2 candidates (32k groups are resident: 8 waves per SIMD), so latency is hidden by
         // occupancy, not by a deep pipeline per group: only the next queue record is fetched ahead.
         const int last = cnt - 1;
@@ -1070,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                 bs[st] = (uint32_t)(j + sft) < (uint32_t)kk.y ? Bs[st * 16] : 0u;
             }
         };
-        for (int e = j0; e < cnt; e += jstep) {
+        for (int e = e_first; e < e_hi; e += jstep) {
             const int e2 = min(e + 2 * jstep, last);
             const int4 rec_nn = pa.cand[base + e2];
             const int2 kk_nn = pa.candk[base + e2];
@@ -1150,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
                 nkept++;
                 if ((nkept & ubm) == 0) {  // the batch is full: hook these edges now
                     if (my_a >= 0) {  // lanes beyond the batch size hold no edge
-                        if (pa.use_link) uf_link(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
+                        if (pa.use_link == 1) uf_link(pa.parent, my_a, my_b); else if (pa.use_link == 2) uf_link_checked(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
                         if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
                     }
                     my_a = my_b = -1;
@@ -1164,14 +1183,14 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     }
     // one edge per lane: the dependent find / CAS chains of all edges of the wave overlap
     if (my_a >= 0) {
-        if (pa.use_link) uf_link(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
+        if (pa.use_link == 1) uf_link(pa.parent, my_a, my_b); else if (pa.use_link == 2) uf_link_checked(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
         if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
     }
     if (l16 == 0 && nkept) atomicAdd(&blk_edges, (unsigned)nkept);
     __syncthreads();
     if (threadIdx.x == 0) {  // plain stores, summed by the host (no same-word global atomics)
-        blk_stats[2 * blockIdx.x] = (int)blk_edges;
-        blk_stats[2 * blockIdx.x + 1] = (int)blk_cands;
+        blk_stats[pa.stats_off + 2 * blockIdx.x] = (int)blk_edges;
+        blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = (int)blk_cands;
     }
 }
 
@@ -1680,6 +1699,16 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 // ------------------------------------------------------------------------------------------------
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
+// k_compress: parent[i] = root(i) in place, between the two phases of a two-phase verify (only roots are written:
+// a concurrent reader sees an ancestor either way)
+__global__ void k_compress(int *parent, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cur = parent[i], next;
+    while (cur > (next = parent[cur])) cur = next;
+    parent[i] = cur;
+}
+
 // (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
 __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1763,6 +1792,9 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.union_batch = pl.d == 3 ? 8 : 16;  // (d = 2 hooks by splicing: 16 is better there, 0.169 vs 0.172 ms at 100k rows)
     if (const char *e = getenv("BFK_UNION_BATCH")) pa.union_batch = atoi(e) >= 16 ? 16 : (atoi(e) >= 8 ? 8 : (atoi(e) >= 4 ? 4 : 2));
     pa.dbg = pl.dbg;
+    pa.part_lo = 0;
+    pa.part_hi = pa.part_den = 1;
+    pa.stats_off = 0;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
     // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
     // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
@@ -1778,9 +1810,10 @@ static PairArgs make_pair_args(const Plan &pl) {
 }
 
 // exact check + union of everything in the candidate queue
-static int launch_verify(const Plan &pl, const PairArgs &pa, hipStream_t st, hipEvent_t *ev) {
-    {   // 16-token steps covering the longest row a pair of k_verify can have
-        const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
+static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, hipEvent_t *ev) {
+    // 16-token steps covering the longest row a pair of k_verify can have
+    const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
+    auto one = [&](const PairArgs &pa) {
 #define VF_CASE(S)                                                                                                        \
     if (pl.d <= pl.wave_table_d)                                                                                          \
         hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
@@ -1794,6 +1827,28 @@ static int launch_verify(const Plan &pl, const PairArgs &pa, hipStream_t st, hip
         else if (steps <= 8) { VF_CASE(8); }
         else { VF_CASE(12); }
 #undef VF_CASE
+    };
+    const PairArgs &pa = pa_in;
+    if (pl.verify_phases > 1) {
+        // Two phases (the idea of Afforest): a first part of every queue shard is hooked by splicing, the forest is
+        // compressed, and the rest — in a dense graph mostly edges inside components that exist by then — ends after
+        // one round trip of loads (equal roots)
+        PairArgs a = pa_in, b = pa_in;
+        a.part_lo = 0;
+        a.part_hi = 1;
+        a.part_den = pl.verify_phases;
+        a.use_link = 1;
+        b.part_lo = 1;
+        b.part_hi = b.part_den = pl.verify_phases;
+        b.use_link = pl.verify_phase2_union;
+        b.stats_off = 2 * pl.verify_grid;
+        one(a);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_compress, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n);
+        LAUNCH_CHECK();
+        one(b);
+    } else {
+        one(pa);
     }
     LAUNCH_CHECK();
     if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table

@@ -479,14 +479,15 @@ def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
                                  {"BFK_KEY_H": "16", "BFK_PF_ROWS": "2"}, {"BFK_UNION_BATCH": "2"},
                                  {"BFK_UNION_BATCH": "4"}, {"BFK_UNION_BATCH": "16"}, {"BFK_WAVE_TABLE_D": "3"},
                                  {"BFK_WAVE_TABLE_D": "0"}, {"BFK_SIG_WORDS": "1"}, {"BFK_SIG_WORDS": "2"},
-                                 {"BFK_UF_LINK": "0"}, {"BFK_UF_LINK": "1"},
+                                 {"BFK_UF_LINK": "0"}, {"BFK_UF_LINK": "1"}, {"BFK_VERIFY_PHASES": "8"},
+                                 {"BFK_VERIFY_PHASES": "3", "BFK_VERIFY_PHASE2": "2"}, {"BFK_VERIFY_PHASES": "1"},
                                  {"BFK_SIG_WORDS": "4", "BFK_PF_ROWS": "2"}])
 @pytest.mark.parametrize("d", [1, 2, 3, 4])
 def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monkeypatch):
     """128- and 256-row tiles (chosen above 2M / 8M rows), 2 and 4 waves per tile, extreme verify grids, the
     third sort key (chosen above 600k rows; d = 4 needs more candidate ranges than lanes and falls back to the
-    two-key ranges over four-key cells), union batch sizes, hash-table placements and both union algorithms of the verify
-    kernel: the configurations the default sizes of the test inputs never pick"""
+    two-key ranges over four-key cells), union batch sizes, hash-table placements, both union algorithms and the one- and
+    two-phase form of the verify kernel: the configurations the default sizes of the test inputs never pick"""
     rows = generate_profiles(6000, p_del=0.05, p_ins=0.02)
     uf = list(dict.fromkeys(rows))
     indptr, indices, _ = _lib.build_csr(uf, " ")
