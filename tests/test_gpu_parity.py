@@ -585,6 +585,49 @@ def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
     assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_variant_join_fuzz_vs_oracle(seed):
+    """many small inputs of every shape the join special-cases: rows of 0 .. 700 tokens (single tokens, windows that
+    hold dozens of rows, rows spanning several 512-token batches), repeated tokens, equal multisets in other orders,
+    edits at the first / last position, few and many rows — labels and edge counts against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    by_join = 0  # inputs the join finished itself (no give-up: few rows that are one multiset)
+    for it in range(25):
+        n_base = int(rng.integers(1, 30))
+        alphabet = int(rng.choice([3, 10, 100, 5000]))
+        kmax = int(rng.choice([1, 4, 20, 70, 200, 700]))
+        base = [rng.integers(0, alphabet, size=int(rng.integers(0, kmax + 1))) for _ in range(n_base)]
+        rows = []
+        for _ in range(int(rng.integers(1, 400))):
+            r = list(base[int(rng.integers(0, n_base))])
+            for _ in range(int(rng.integers(0, 3))):
+                op = rng.random()
+                pos = int(rng.choice([0, len(r), int(rng.integers(0, len(r) + 1))]))
+                if op < 0.4 and r:
+                    r.pop(min(pos, len(r) - 1))
+                elif op < 0.8:
+                    r.insert(pos, int(rng.integers(0, alphabet)))
+                elif r:
+                    r.insert(pos, r[int(rng.integers(0, len(r)))])
+            if rng.random() < 0.1:
+                rng.shuffle(r)
+            rows.append(np.array(r, dtype=np.int32))
+        indptr = np.zeros(len(rows) + 1, np.int32)
+        indptr[1:] = np.cumsum([len(r) for r in rows])
+        indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+        want = orc.cluster_csr(indptr, indices, 1, n_threads=4, want_neigh=False)["labels"]
+        got, st = _lib.cluster_csr(indptr, indices, 1)
+        assert np.array_equal(got, want), (seed, it)
+        by_join += st["n_retry_slices"] == 0
+        dense = np.zeros((len(rows), alphabet), np.int32)
+        for i, r in enumerate(rows):
+            np.add.at(dense[i], r, 1)
+        if len(rows) <= 200 and alphabet <= 100:  # exact edge count by brute force on the count matrix
+            dist = np.abs(dense[:, None, :] - dense[None, :, :]).sum(axis=2)
+            assert st["n_edges"] == int(np.triu(dist <= 1, 1).sum()), (seed, it)
+    assert by_join >= 15, by_join
+
+
 def test_variant_join_queue_overflow_falls_back(monkeypatch):
     """rows in no common order: the join cannot certify its matches itself and queues them for k_verify; a queue
     that is too small makes bfk_ctx_sync redo the step on the all-pairs path (which has the sliced recovery)"""
