@@ -628,6 +628,32 @@ def test_variant_join_fuzz_vs_oracle(seed):
     assert by_join >= 15, by_join
 
 
+@pytest.mark.parametrize("name,n_shards", [("perms100", 3), ("tiny_rows", 4), ("long_rows", 2)])
+def test_variant_join_sharded_equals_one_shard(name, n_shards):
+    """the join's multi-GPU split on one GPU: blocks of tokens (their lookups) round-robin, a pair of equal multisets to
+    the shard its later row picks — every edge exactly once over the shards, merged labels = the 1-shard labels"""
+    indptr, indices = _join_cases()[name]
+    n = len(indptr) - 1
+    want, st1 = _lib.cluster_csr(indptr, indices, 1)
+    assert st1["n_retry_slices"] == 0
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_gath = ctx.alloc(4 * n * n_shards)
+    d_out = ctx.alloc(4 * n)
+    edges = 0
+    for s_ in range(n_shards):
+        ctx.cluster(1, d_gath + 4 * n * s_, s_, n_shards)
+        st = ctx.sync()
+        assert st["n_retry_slices"] == 0
+        edges += st["n_edges"]
+    ctx.merge_labels(d_gath, n_shards, d_out)
+    ctx.sync()
+    got = ctx.download_i32(d_out, n)
+    ctx.close()
+    assert np.array_equal(got, want)
+    assert edges == st1["n_edges"]
+
+
 def test_variant_join_queue_overflow_falls_back(monkeypatch):
     """rows in no common order: the join cannot certify its matches itself and queues them for k_verify; a queue
     that is too small makes bfk_ctx_sync redo the step on the all-pairs path (which has the sliced recovery)"""
