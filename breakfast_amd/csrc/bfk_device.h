@@ -93,6 +93,6 @@ int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_lists(int *parent, int n, const long long *off, const int *flat, long long total, int n_lists, int *labels,
                  Counters *ctr, hipStream_t st);
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
-                 hipStream_t st);
+                 int skip, int splice, hipStream_t st);
 
 }  // namespace bfk

@@ -640,8 +640,13 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
     if (c->n == 0) return BFK_OK;
     if (!d_gathered || !d_labels_out || n_parts <= 0) return fail(BFK_EARG, "bad merge arguments");
     if (d_changed) HIP_TRY(hipMemsetAsync(d_changed, 0, 4, c->stream));
+    // the part gathered from this very forest adds nothing (all-gather form: part = shard index); sparse forests
+    // (max_dist <= 2) are merged by splicing like the verify kernel hooks them
+    const int skip = (n_parts == c->plan.n_shards && n_parts > 1 && !getenv("BFK_MERGE_ALL")) ? c->plan.shard : -1;
+    int splice = c->last_d <= 2 ? 1 : 0;
+    if (const char *e = getenv("BFK_UF_LINK")) splice = atoi(e) != 0;
     if (int e = launch_merge(c->d_parent, (int)c->n, (const int *)d_gathered, n_parts, (int *)d_labels_out,
-                             (int *)d_changed, (Counters *)c->d_head, c->stream))
+                             (int *)d_changed, (Counters *)c->d_head, skip, splice, c->stream))
         return fail(BFK_EHIP, std::string("merge launch: ") + hipGetErrorString((hipError_t)e));
     return BFK_OK;
 }

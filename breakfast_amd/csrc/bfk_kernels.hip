@@ -1721,16 +1721,19 @@ __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict
     labels[i] = cur;
 }
 
-__global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, int n_parts, Counters *ctr) {
+// (skip = the part that came from this forest itself, or -1; splice: uf_link instead of uf_union, see make_pair_args)
+__global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, int n_parts, Counters *ctr, int skip, int splice) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int g = 0; g < n_parts; g++) {
+        if (g == skip) continue;
         int l = gathered[(size_t)g * n + i];
         if (l < 0 || l >= n) {
             atomicOr(&ctr->err, ERR_LABEL);
             continue;
         }
-        if (l != i) uf_union(parent, i, l);
+        if (l == i) continue;
+        if (splice) uf_link(parent, i, l); else uf_union(parent, i, l);
     }
 }
 
@@ -2026,10 +2029,10 @@ int launch_lists(int *parent, int n, const long long *off, const int *flat, long
 }
 
 int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labels, int *changed, Counters *ctr,
-                 hipStream_t st) {
+                 int skip, int splice, hipStream_t st) {
     if (n <= 0) return 0;
     dim3 g((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr);
+    hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr, skip, splice);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0);
     LAUNCH_CHECK();

@@ -126,7 +126,9 @@ int bfk_ctx_cluster(bfk_ctx *ctx, int32_t max_dist, int32_t shard, int32_t n_sha
 
 /* enqueue the multi-GPU merge: d_gathered = int32[n_parts][n_rows] label arrays (all_gather output, or
  * 1 part holding an elementwise-min all-reduce); every (i, gathered[g][i]) is united into this ctx's
- * forest and d_labels_out is re-flattened.  d_changed (device int32, may be NULL) is set to 1 if any
+ * forest and d_labels_out is re-flattened.  With n_parts == n_shards of the last bfk_ctx_cluster, part g must be
+ * the labels of shard g (all_gather order): the part of this ctx's own shard is skipped, it adds nothing.
+ * d_changed (device int32, may be NULL) is set to 1 if any
  * label differs from d_gathered part 0 (fix-point test for the all-reduce(min) form).                */
 int bfk_ctx_merge_labels(bfk_ctx *ctx, const void *d_gathered, int32_t n_parts, void *d_labels_out, void *d_changed);
 
