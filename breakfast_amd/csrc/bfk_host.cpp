@@ -455,7 +455,7 @@ static int sig_words_for(int d) {
 
 // The variant join serves max_dist == 1 (BFK_JOIN=0 forces the all-pairs kernels, e.g. to measure them).
 static bool join_wanted(const bfk_ctx *c, int max_dist) {
-    if (max_dist != 1 || c->join_off || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25) ||
+    if (max_dist != 1 || c->join_off || c->nnz <= 0 || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25) ||
         c->nnz > (int64_t)INT32_MAX - 4 * JOIN_TPW)  // 32-bit token offsets, position packed above 6 bits
         return false;
     if (const char *e = getenv("BFK_JOIN")) return atoi(e) != 0;
