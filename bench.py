@@ -256,7 +256,7 @@ def main():
                             f"{', indels kept' if a.indels else ''}), N_u={n_u} unique, k_mean={nnz / n_u:.1f}, "
                             f"max-dist {d}",
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
-                "sharding": (f"blocks of rows (their lookups) round-robin over {world} rank(s)" if join else
+                "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM",
