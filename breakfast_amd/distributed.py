@@ -4,7 +4,8 @@ Every rank holds the full CSR (<= 180 MB at 1M rows) and runs the prep kernels o
 the sorted order are dealt round-robin over the ranks (owner = index of the cell's first tile mod world —
 cells, not tiles: the order of the rows inside a cell comes from atomics and differs from rank to rank, whole
 cells are the same sets everywhere), so each rank evaluates ~1/world of the pair tiles and hooks the edges it
-finds into a LOCAL union-find forest over all N rows.  The only
+finds into a LOCAL union-find forest over all N rows.  (max_dist 1, the variant join: every rank builds the whole
+hash table and the blocks of 8192 tokens — their table lookups — are dealt round-robin.)  The only
 exchange step is the label merge, over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests):
 
