@@ -44,7 +44,7 @@ struct Counters {
 // variant join (max_dist == 1): table / bitmap of this step, the set to clear for the next step, row hashes
 struct JoinArgs {
     unsigned long long *tab, *tab_next;  // mask + 1 slots
-    unsigned long long *bits, *bits_next;  // bmask + 1 bits in 64-bit words (blocked Bloom filter, two bits per row)
+    uint32_t *bits, *bits_next;          // bmask + 1 bits in 32-bit words (blocked Bloom filter, two bits per row)
     uint2 *rowhash;
     int *batch_row;  // per JOIN_TPW tokens: the row that holds the first of them
     int2 *dups;  // pairs of rows with one H, found while inserting

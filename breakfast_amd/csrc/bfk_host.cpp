@@ -606,8 +606,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.join = 1;
         pl.ja.tab = (unsigned long long *)(cur ? tab1 : tab0);
         pl.ja.tab_next = (unsigned long long *)(cur ? tab0 : tab1);
-        pl.ja.bits = (unsigned long long *)(cur ? bits1 : bits0);
-        pl.ja.bits_next = (unsigned long long *)(cur ? bits0 : bits1);
+        pl.ja.bits = (uint32_t *)(cur ? bits1 : bits0);
+        pl.ja.bits_next = (uint32_t *)(cur ? bits0 : bits1);
         pl.ja.rowhash = (uint2 *)(bits1 + c->join_bits / 8);
         pl.join_skip_verify = (c->join_empty_shard == shard && c->join_empty_shards == n_shards && !c->edge_capture &&
                                2 * c->kcap <= VERIFY_MAX_TOKENS && !getenv("BFK_CAND_CAP_SHARD")) ? 1 : 0;
