@@ -1419,9 +1419,9 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                                                    int nnz, JoinArgs ja, PairArgs pa, int shard0, int nshards, int2 *edges,
                                                    int edge_cap) {
     constexpr int QCAP = 128, MCAP = 64;
-    __shared__ uint32_t q_k1[16][QCAP], q_k2[16][QCAP];
-    __shared__ int q_b[16][QCAP], q_p[16][QCAP];                 // row B, position of the looked-up token in B
-    __shared__ int m_a[16][MCAP], m_b[16][MCAP], m_p[16][MCAP];  // matches: row A, row B, position
+    // one 16-byte record per entry (one ds_write_b128 / ds_read_b128 and one address instead of four)
+    __shared__ int4 q_rec[16][QCAP];  // queued lookups: {key.x, key.y, row B, position of the looked-up token in B}
+    __shared__ int4 m_rec[16][MCAP];  // matches: {row A, row B, position, -}
     __shared__ unsigned s_edges, s_cands;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1477,8 +1477,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
     const int T0 = gw * JOIN_TPW;  // (the host keeps nnz + JOIN_TPW below 2^31)
     unsigned my_edges = 0, my_cands = 0;
     if ((int)(blockIdx.x % (unsigned)nshards) == shard0 && T0 < nnz) {
-        uint32_t *qk1 = q_k1[wave], *qk2 = q_k2[wave];
-        int *qb = q_b[wave], *qp = q_p[wave], *ma = m_a[wave], *mb = m_b[wave], *mp = m_p[wave];
+        int4 *qr = q_rec[wave], *mr = m_rec[wave];
         int nq = 0, nm = 0;  // wave-uniform
 
         auto settle = [&]() {
@@ -1487,7 +1486,8 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (ja.dbg & 1) nm = 0;
             const bool have = lane < nm;
-            const int A = have ? ma[lane] : 0, B = have ? mb[lane] : 0, p = have ? mp[lane] : 0;
+            const int4 mrec = have ? mr[lane] : make_int4(0, 0, 0, 0);
+            const int A = mrec.x, B = mrec.y, p = mrec.z;
             const int ba = have ? indptr[A] : 0, ea = have ? indptr[A + 1] : 0;
             const int bb = have ? indptr[B] : 0, eb = have ? indptr[B + 1] : 0;
             const int ka = ea - ba, kb = eb - bb;
@@ -1560,9 +1560,10 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             for (int q0 = 0; q0 < nq; q0 += 64) {
                 const int i = q0 + lane;
                 bool active = i < nq;
-                const uint32_t k2 = active ? qk2[i] : 0u;
-                const int qB = active ? qb[i] : 0, qP = active ? qp[i] : 0;
-                uint32_t s = (active ? qk1[i] : 0u) & ja.mask;
+                const int4 qrec = active ? qr[i] : make_int4(0, 0, 0, 0);
+                const uint32_t k2 = (uint32_t)qrec.y;
+                const int qB = qrec.z, qP = qrec.w;
+                uint32_t s = (uint32_t)qrec.x & ja.mask;
                 int probes = 0;
                 while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
                     unsigned long long e0 = JOIN_EMPTY, e1 = JOIN_EMPTY;
@@ -1589,9 +1590,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                         if (nm + __popcll(mm) > MCAP) settle();
                         if (mt) {
                             const int pos = nm + __popcll(mm & lt);
-                            ma[pos] = (int)(uint32_t)(h ? e1 : e0);
-                            mb[pos] = qB;
-                            mp[pos] = qP;
+                            mr[pos] = make_int4((int)(uint32_t)(h ? e1 : e0), qB, qP, 0);
                         }
                         nm += __popcll(mm);
                     }
@@ -1607,10 +1606,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             if (ja.dbg & 4) hm = 0ull;
             if ((hm >> lane) & 1ull) {
                 const int pos = nq + __popcll(hm & lt);
-                qk1[pos] = k1;
-                qk2[pos] = k2;
-                qb[pos] = B;
-                qp[pos] = p;
+                qr[pos] = make_int4((int)k1, (int)k2, B, p);
             }
             nq += __popcll(hm);
         };
