@@ -1333,8 +1333,10 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
     const int nr = max(0, min(rpw, n - r0));
     if (nr <= 0) return;
     uint32_t my1 = 0, my2 = 0;  // lane t: H of row r0 + t
-    if (nnz > 0) {
-        const int ext = indptr[min(r0 + min(lane, rpw), n)];
+    unsigned long long first_old = JOIN_EMPTY;  // what the first CAS of this lane's row returned
+    bool tried = false;
+    const int ext = indptr[min(r0 + min(lane, rpw), n)];  // lane l: start of row r0 + l (the host sends nnz = 0 elsewhere)
+    {
         uint32_t xs[MAXRPW];
 #pragma unroll
         for (int t = 0; t < MAXRPW; t++) {
@@ -1344,6 +1346,13 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
 #pragma unroll
         for (int t = 0; t < MAXRPW; t++) {
             if (t >= nr) continue;  // wave-uniform
+            if (t == 8 && lane < 8 && !(ja.dbg & 8)) {
+                // rows 0..7 are hashed: their first insert attempt goes out now, the hashing of rows 8.. hides its
+                // round trip (all the inserts at the end were 3.6 us of exposed tail)
+                first_old = atomicCAS(&ja.tab[my1 & ja.mask], JOIN_EMPTY,
+                                      ((unsigned long long)my2 << 32) | (unsigned long long)(uint32_t)(r0 + lane));
+                tried = true;
+            }
             const int b = __builtin_amdgcn_readlane(ext, t), e = __builtin_amdgcn_readlane(ext, t + 1);
             int k = e - b;
             if (k < 0 || k > kcap) {
@@ -1367,19 +1376,19 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
             }
         }
     }
+    const int my_b = ext, my_e = min(__shfl_down(ext, 1), nnz);  // this lane's row
     if (lane < nr) {
         const int i = r0 + lane;
         ja.rowhash[i] = make_uint2(my1, my2);
         parent[i] = i;
-        {   // k_join's waves own JOIN_TPW tokens each: the row that holds a wave's first token
-            const int b = indptr[i], e = min(indptr[i + 1], nnz);
-            for (int q = (b + JOIN_TPW - 1) / JOIN_TPW; q * JOIN_TPW < e; q++) ja.batch_row[q] = i;
-        }
+        // k_join's waves own JOIN_TPW tokens each: the row that holds a wave's first token (extents from the
+        // registers: a load here would sit in front of the insert below, one more round trip at the kernel's tail)
+        for (int q = (my_b + JOIN_TPW - 1) / JOIN_TPW; q * JOIN_TPW < my_e; q++) ja.batch_row[q] = i;
         if (!(ja.dbg & 256)) atomicOr(&ja.bits[(my1 & ja.bmask) >> 5], join_bloom_mask(my1));
         const unsigned long long ent = ((unsigned long long)my2 << 32) | (unsigned long long)(uint32_t)i;
         uint32_t s = my1 & ja.mask;
         for (int probes = 0; !(ja.dbg & 8); probes++) {
-            const unsigned long long old = atomicCAS(&ja.tab[s], JOIN_EMPTY, ent);
+            const unsigned long long old = (probes == 0 && tried) ? first_old : atomicCAS(&ja.tab[s], JOIN_EMPTY, ent);
             if (old == JOIN_EMPTY) break;
             if ((uint32_t)(old >> 32) == my2) {  // an earlier row with this H: (up to a hash collision) the same multiset
                 const unsigned q = atomicAdd(&ctr->n_dup, 1u);
