@@ -585,7 +585,7 @@ def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
     assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "6"))))
 def test_variant_join_fuzz_vs_oracle(seed):
     """many small inputs of every shape the join special-cases: rows of 0 .. 700 tokens (single tokens, windows that
     hold dozens of rows, rows spanning several 512-token batches), repeated tokens, equal multisets in other orders,
