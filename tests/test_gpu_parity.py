@@ -628,6 +628,46 @@ def test_variant_join_fuzz_vs_oracle(seed):
     assert by_join >= 15, by_join
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
+def test_all_pairs_fuzz_vs_oracle(seed):
+    """the general path on many small inputs at max-dist 2 .. 5 (splicing and find + hook unions, one- and two-phase
+    verify, both certificates and the counting table): labels against the oracle, edge counts against brute force"""
+    rng = np.random.default_rng(5000 + seed)
+    for it in range(20):
+        d = int(rng.integers(2, 6))
+        n_base = int(rng.integers(1, 20))
+        alphabet = int(rng.choice([4, 12, 100, 3000]))
+        kmax = int(rng.choice([3, 12, 40, 90, 250]))
+        base = [np.sort(rng.integers(0, alphabet, size=int(rng.integers(0, kmax + 1)))) for _ in range(n_base)]
+        rows = []
+        for _ in range(int(rng.integers(1, 500))):
+            r = list(base[int(rng.integers(0, n_base))])
+            for _ in range(int(rng.integers(0, d + 2))):
+                op = rng.random()
+                pos = int(rng.choice([0, len(r), int(rng.integers(0, len(r) + 1))]))
+                if op < 0.45 and r:
+                    r.pop(min(pos, len(r) - 1))
+                elif op < 0.9:
+                    r.insert(pos, int(rng.integers(0, alphabet)))
+                elif r:
+                    r.insert(pos, r[int(rng.integers(0, len(r)))])
+            if rng.random() < 0.05:
+                rng.shuffle(r)
+            rows.append(np.array(r, dtype=np.int32))
+        indptr = np.zeros(len(rows) + 1, np.int32)
+        indptr[1:] = np.cumsum([len(r) for r in rows])
+        indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+        want = orc.cluster_csr(indptr, indices, d, n_threads=4)["labels"]
+        got, st = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want), (seed, it, d)
+        if len(rows) <= 250 and alphabet <= 100:
+            dense = np.zeros((len(rows), alphabet), np.int32)
+            for i, r in enumerate(rows):
+                np.add.at(dense[i], r, 1)
+            dist = np.abs(dense[:, None, :] - dense[None, :, :]).sum(axis=2)
+            assert st["n_edges"] == int(np.triu(dist <= d, 1).sum()), (seed, it, d)
+
+
 @pytest.mark.parametrize("name,n_shards", [("perms100", 3), ("tiny_rows", 4), ("long_rows", 2)])
 def test_variant_join_sharded_equals_one_shard(name, n_shards):
     """the join's multi-GPU split on one GPU: blocks of tokens (their lookups) round-robin, a pair of equal multisets to
