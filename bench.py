@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--indels", action="store_true", help="config 5 generator: p_del=0.05 p_ins=0.01, indels kept")
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="experiment (not the contract's default): P independent contexts on P streams take the steps "
+                         "round-robin, so that the label exchange of one step overlaps the kernels of the next")
     a = ap.parse_args()
 
     import torch
@@ -160,9 +163,32 @@ def main():
     k = np.diff(indptr)
     d = a.max_dist
 
-    eng = GpuEngine(local_rank)
-    sc = ShardedClusterer(eng, rank, world, a.merge)
-    sc.bind(indptr, indices)
+    # one context on torch's current stream; with --pipeline P, P of them, each on a stream of its own
+    pipe = max(1, a.pipeline)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(pipe - 1)]
+    engs, scs = [], []
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            e_ = GpuEngine(local_rank)
+            c_ = ShardedClusterer(e_, rank, world, a.merge)
+            c_.bind(indptr, indices)
+        engs.append(e_)
+        scs.append(c_)
+    eng, sc = engs[0], scs[0]
+
+    def run_steps(count):
+        for i in range(count):
+            if pipe == 1:
+                sc.step(d)
+            else:
+                with torch.cuda.stream(streams[i % pipe]):
+                    scs[i % pipe].step(d)
+
+    def sync_all():
+        sts = [e_.sync() for e_ in engs]
+        worst = dict(sts[0])
+        worst["n_retry_slices"] = max(x["n_retry_slices"] for x in sts)
+        return worst
 
     def barrier():
         torch.cuda.synchronize()
@@ -173,9 +199,8 @@ def main():
     # warm-up; a candidate-queue overflow (dense inputs) is repaired inside sync() and grows the queue, so repeat
     # until a step runs clean: the timed steps must be complete single-pass steps
     for attempt in range(6):
-        for _ in range(max(a.warmup, 1)):
-            sc.step(d)
-        st0 = eng.sync()
+        run_steps(max(a.warmup, pipe))
+        st0 = sync_all()
         again = int(st0["n_retry_slices"] != 0)
         if world > 1:  # every rank must run the same number of steps (each step holds a collective)
             tt = torch.tensor([again], dtype=torch.int32, device="cuda")
@@ -185,8 +210,7 @@ def main():
             break
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sc.step(d)
+    run_steps(a.steps)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -194,7 +218,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    st_timed = eng.sync()  # checks the device-side overflow / error flags of the last timed step
+    st_timed = sync_all()  # checks the device-side overflow / error flags of the last timed step(s)
     if st_timed["n_retry_slices"] != 0:
         raise SystemExit("bench invalid: a timed step overflowed the candidate queue")
     labels = sc.labels[0][:n_u].cpu().numpy()
@@ -260,6 +284,7 @@ def main():
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM",
+                **({"pipeline": f"{pipe} contexts on {pipe} streams, steps round-robin (opt-in experiment)"} if pipe > 1 else {}),
             },
             "roofline": {
                 "bound": "hbm",
