@@ -1,27 +1,46 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json metric on MI355X: genome-pair distance evaluations/s of the clustering hot path.
-
-A step = one pass of the hot path over one batch: CSR of the unique synthetic profiles RESIDENT IN HBM
--> row canonicalisation + signatures -> all-pairs prefilter within the length band -> exact verify ->
-union-find -> canonical labels in HBM (+ for N>1 ranks: RCCL label merge).  value = pairs resolved
-(N_u(N_u-1)/2, every unordered pair's <= max_dist status decided) / step time.
+"""bench.py — BASELINE.json's metric on MI355X: genome-pair dists/sec + clusters.tsv wall-clock, 100k seqs, max-dist 1.
 
   python bench.py [--gpus N --steps K --warmup W] [--rows R --max-dist D --indels --merge allgather|allreduce]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-N=1 workload: BASELINE.json configs[2] = 100k synthetic SARS-CoV-2 profiles (~40 SNPs), max-dist 1 (the
-configuration the metric is quoted on).  N>1: weak scaling in PAIRS — rows = round(100k*sqrt(N)) so each
-rank evaluates the same number of pair tiles as the 1-GPU run (work items are dealt round-robin).
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes of
+`python -m torch.distributed.run`, before this process has touched the GPU), relays rank 0's JSON line and exits
+with the children's status; under a launcher (WORLD_SIZE set) it is one rank.
+
+What the ONE JSON line holds (every number is measured in this run unless it says otherwise):
+
+  value / ms_per_step    a step = one pass of the hot path over the batch, CSR of the unique profiles RESIDENT IN
+                         HBM -> canonical labels in HBM (+ RCCL label merge for N > 1); EXACTLY --steps steps timed
+                         between barrier + synchronize; value = N_u(N_u-1)/2 pairs resolved per step / time.
+  sustained              the same steps for >= 0.3 s (so that an outside sampler sees the GPU busy)
+  ms_per_step_cold       first step after a bind (k_verify launched, nothing memoised), median of 5 re-binds
+  t_cluster_host_ms      metric (1) as SURVEY 8(d) defines it: list of N_u strings in host memory -> labels in host
+                         memory through the C-ABI (bfk_build_csr + H2D + kernels + D2H): first call and steady state,
+                         and value_host_inclusive = pairs / steady time (PCIe-inclusive; never `value`)
+  clusters_tsv_wall_s    metric (2): a fresh subprocess of the CLI, input file -> clusters.tsv, sha256 of the output
+                         checked against tests/golden/sha256.json (the digest of the reference's own output)
+  all_pairs              the same step with the all-pairs kernels forced (k_sig .. k_prefilter .. k_verify): the
+                         design north_star describes; the default at max-dist 1 is the variant join
+  roofline               dominant kernel of the default step: bytes the executed algorithm must move (compulsory
+                         reads + writes of that kernel) / its mean duration (HIP events on the launch stream) vs the
+                         8 TB/s HBM peak.  `reference_equivalent` keeps SURVEY 8(d)'s untiled operand-stream figure
+                         (what the reference's CPU kernel touches) for comparison only — it is never `achieved`.
+  cpu_baseline           the scikit-learn kernel the reference calls, timed on this host's cores on a bounded sample
+                         (oracle/sk_port.py); the C oracle leg beside it.  bench-only use of oracle/.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -30,13 +49,14 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD32 x 2.4 GHz
 
 
-def algorithmic_bytes(k: np.ndarray, d: int, nnz: int):
+def reference_equivalent_bytes(k: np.ndarray, d: int, nnz: int):
     """SURVEY.md 8(d) 'one figure': B_alg = sum over merged (in-band) unordered pairs 4(k_i+k_j)
-    + 8 B per length-pruned pair + 4*nnz + 8*N_u.  Exact from the length histogram."""
+    + 8 B per length-pruned pair + 4*nnz + 8*N_u — what an untiled all-pairs merge (the reference's CPU kernel)
+    touches.  Exact from the length histogram.  Reported for comparison; NOT what these kernels move."""
     n = len(k)
     cnt = np.bincount(k).astype(np.float64)
     ks = np.arange(len(cnt), dtype=np.float64)
@@ -65,11 +85,13 @@ def host_cores():
     return n
 
 
-def cpu_baseline(indptr, indices, d, n_u, target_s=15.0):
-    """The oracle (CPU restatement of the reference: band loop + two-pointer merges + graph) timed on the
-    host cores on a bounded sample: S query rows x all columns (the reference's select_ind shape,
-    breakfast.py:241-245), scaled to pairs/s as S*(N_u-1)/2 / t — the share of the full job's unordered
-    pairs those S query rows account for.  bench-only use of oracle/ (never the measured product)."""
+def cpu_baseline(indptr, indices, d, n_u, target_s=10.0):
+    """CPU legs on the host cores, each on a bounded sample of S query rows (the reference's select_ind shape,
+    breakfast.py:241-245), scaled to pairs/s as S*(N_u-1)/2 / t — the share of the job's unordered pairs those S
+    query rows account for.  Top level: the scikit-learn kernel the reference itself calls
+    (pairwise_distances_chunked / _sparse_manhattan on the length bands, oracle/sk_port.py; time inside the sklearn
+    calls).  `c_oracle`: the C restatement (oracle/bfk_oracle.c), OpenMP over query rows.  bench-only use of
+    oracle/ (never the measured product)."""
     from oracle import ref_port as orc
 
     cores = host_cores()
@@ -83,48 +105,149 @@ def cpu_baseline(indptr, indices, d, n_u, target_s=15.0):
     t0 = time.perf_counter()
     res = orc.cluster_csr(indptr, indices, d, select_ind=sel, n_threads=cores)
     t = time.perf_counter() - t0
-    out = {
+    port = {
         "value": s * (n_u - 1) / 2 / t, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "kernel": "oracle/bfk_oracle.c (C restatement of the reference path)",
         "sample": f"{s} of {n_u} query rows x all columns (select_ind shape), {res['n_merges']} row merges "
-                  f"in {t:.1f} s, OpenMP over query rows like sklearn's prange",
+                  f"in {t:.1f} s, OpenMP over query rows like sklearn's prange; extrapolated to the full job",
         "seconds": round(t, 2),
     }
-    # beside it, when the box has them: the third-party kernel the reference itself calls (scikit-learn's
-    # pairwise_distances_chunked / _sparse_manhattan on the length bands, oracle/sk_port.py), same sample shape,
-    # time spent inside the sklearn calls only; its OpenMP threads = all host cores
     try:
         from oracle import sk_port
 
         if sk_port.available():
             sel0 = np.sort(rng.choice(n_u, size=min(n_u, 200), replace=False)).astype(np.int64)
             _, t0s = sk_port.neighbours(indptr, indices, d, select_ind=sel0)
-            s2 = int(min(n_u, max(200, 200 * 8.0 / max(t0s, 1e-3))))
+            s2 = int(min(n_u, max(200, 200 * target_s / max(t0s, 1e-3))))
             sel2 = np.sort(rng.choice(n_u, size=s2, replace=False)).astype(np.int64)
             _, ts = sk_port.neighbours(indptr, indices, d, select_ind=sel2)
-            out["sklearn"] = {"value": s2 * (n_u - 1) / 2 / ts, "unit": "pairs/s", "cores": cores,
-                              "sample": f"{s2} of {n_u} query rows x their length bands, "
-                                        f"{sk_port.merges(indptr, d, sel2)} row merges, {ts:.1f} s inside "
-                                        f"pairwise_distances_chunked(metric='manhattan')",
-                              "seconds": round(ts, 2), "versions": sk_port.versions()}
+            return {"value": s2 * (n_u - 1) / 2 / ts, "unit": "pairs/s", "cores": cores, "kind": "port",
+                    "kernel": "scikit-learn pairwise_distances_chunked(metric='manhattan') -> _sparse_manhattan: the "
+                              "third-party kernel the reference calls (breakfast.py:259-267), driven band by band by "
+                              "oracle/sk_port.py; " + sk_port.versions(),
+                    "sample": f"{s2} of {n_u} query rows x their length bands, {sk_port.merges(indptr, d, sel2)} row "
+                              f"merges, {ts:.1f} s inside the sklearn calls; extrapolated to the full job",
+                    "seconds": round(ts, 2), "c_oracle": port}
     except Exception as e:  # the baseline is a report, never a reason to lose the bench line
-        out["sklearn"] = {"error": repr(e)}
-    return out
+        port["sklearn_error"] = repr(e)
+    return port
+
+
+def kernel_source_digest():
+    """sha256 over the device + host sources a libbfk.so is built from: a PMC file is only quoted as `traffic` when
+    it was taken on exactly these sources (tools/profile_gpu.sh stamps it)."""
+    h = hashlib.sha256()
+    for f in ("bfk_kernels.hip", "bfk_host.cpp", "bfk_device.h"):
+        h.update((ROOT / "breakfast_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel: str, workload_key: str):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this very build and
+    workload (profiles/*_pmc_per_launch.json, separate --pmc passes).  bench.py cannot collect PMC counters on
+    itself; a file taken on other sources is not quoted (returns None)."""
+    import glob
+
+    want = kernel_source_digest()
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_per_launch.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        meta = pm.get("_meta", {})
+        if meta.get("source_digest") != want or meta.get("workload") != workload_key:
+            continue
+        hit = [v for kk, v in pm.items() if kk.startswith(kernel) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        if hit:
+            # FETCH_SIZE / WRITE_SIZE are KiB.  The guide's x2 note on FETCH_SIZE holds for 16-B-per-lane streaming
+            # reads; both readings are given, `traffic` uses the uncorrected counter (lower bound) and says so.
+            return {"bytes": (hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0,
+                    "fetch_bytes": hit[0]["FETCH_SIZE"] * 1024.0, "write_bytes": hit[0]["WRITE_SIZE"] * 1024.0,
+                    "fetch_bytes_x2": 2 * hit[0]["FETCH_SIZE"] * 1024.0,
+                    "source": f"{os.path.basename(f)} (commit {meta.get('commit', '?')}, sources {want}): FETCH_SIZE + "
+                              f"WRITE_SIZE per launch, separate --pmc passes; counts Infinity-Cache hits too"}
+    return None
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """Parent of an N-rank run: never touches the GPU; starts the ranks, relays rank 0's line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cli_wall(n_rows: int, d: int, indels: bool):
+    """metric (2): input file -> clusters.tsv through the CLI in a FRESH process (imports, library load, context,
+    module load all inside), twice (the second run has the input in the page cache and the code object cache warm)."""
+    from breakfast_amd import synth
+
+    tmp = Path(tempfile.mkdtemp(prefix="bfk_bench_"))
+    inp = tmp / "in.tsv"
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    synth.generate_tsv(inp, n_rows, **kw)
+    args = ["--input-file", str(inp), "--max-dist", str(d)] + (["--no-skip-del", "--no-skip-ins"] if indels else [])
+    runs = []
+    digest = None
+    for i in range(3):
+        out = tmp / f"out{i}"
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "breakfast_amd", *args, "--outdir", str(out)], cwd=str(ROOT),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr.decode(errors="replace")[-400:]}
+        runs.append(round(dt, 4))
+        digest = hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest()
+    res = {"seconds": min(runs), "runs_s": runs, "what": "python -m breakfast_amd --input-file <tsv> --outdir <dir>, fresh "
+           "process each (interpreter start, imports, libbfk + HIP runtime load, context, kernels, writer); min of 3",
+           "rows": n_rows, "clusters_sha256": digest}
+    gold = json.loads((ROOT / "tests" / "golden" / "sha256.json").read_text())
+    key = f"syn{n_rows}_d{d}"
+    if not indels and key in gold:
+        res["sha256_matches_reference"] = digest == gold[key]["clusters_sha256"]
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rows", type=int, default=0, help="input sequences (default 100000*sqrt(gpus))")
     ap.add_argument("--max-dist", type=int, default=1)
     ap.add_argument("--indels", action="store_true", help="config 5 generator: p_del=0.05 p_ins=0.01, indels kept")
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="only the timed steps + roofline (no host / CLI / CPU legs)")
+    ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join"], help="candidate generator of the main leg")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="experiment (not the contract's default): P independent contexts on P streams take the steps "
                          "round-robin, so that the label exchange of one step overlaps the kernels of the next")
     a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus))  # nothing above has touched the GPU
+    world = max(world, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    a.gpus = world
+
+    n_rows = a.rows or int(round(100000 * math.sqrt(world)))
+    d = a.max_dist
+    full = world == 1 and not a.quick and a.pipeline == 1
+
+    # metric (2) first: a fresh CLI process, before this process initialises the GPU
+    cli = cli_wall(n_rows, d, a.indels) if (full and rank == 0) else None
 
     import torch
     import torch.distributed as dist
@@ -133,13 +256,6 @@ def main():
     from breakfast_amd.distributed import GpuEngine, ShardedClusterer
     from breakfast_amd.synth import generate_profiles
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # rehearsal of the N > 1 path on a one-GPU box: BFK_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and the
@@ -148,20 +264,51 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if one_device else "nccl"
         if one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n_rows = a.rows or int(round(100000 * math.sqrt(world)))
     kw = dict(p_del=0.05, p_ins=0.01) if a.indels else {}
     rows = list(dict.fromkeys(generate_profiles(n_rows, **kw)))  # collapse_duplicates: unique profiles
+    n_u = len(rows)
+
+    # ---- metric (1), host-inclusive: strings in host memory -> labels in host memory through the one-shot C-ABI
+    host = None
+    if full:
+        raw = [r.encode() for r in rows]
+        off = np.zeros(n_u + 1, dtype=np.int64)
+        np.cumsum(np.fromiter((len(r) for r in raw), dtype=np.int64, count=n_u), out=off[1:])
+        buf = b"".join(raw)
+
+        def one_shot():
+            t0 = time.perf_counter()
+            ip, ix, nv = _lib.build_csr_bytes(buf, off, " ")
+            t1 = time.perf_counter()
+            lab, st_ = _lib.cluster_csr(ip, ix, d)
+            t2 = time.perf_counter()
+            return (t1 - t0) * 1e3, (t2 - t1) * 1e3, lab
+
+        b0, c0, lab_first = one_shot()
+        reps = [one_shot()[:2] for _ in range(7)]
+        bs, cs = sorted(x[0] for x in reps), sorted(x[1] for x in reps)
+        steady = bs[len(bs) // 2] + cs[len(cs) // 2]
+        host = {"first_call": round(b0 + c0, 3), "steady": round(steady, 3),
+                "steady_build_csr": round(bs[len(bs) // 2], 3), "steady_cluster_csr": round(cs[len(cs) // 2], 3),
+                "first_build_csr": round(b0, 3), "first_cluster_csr": round(c0, 3),
+                "what": "N_u profile strings as one byte buffer + offsets (the C-ABI's input) -> bfk_build_csr (tokeniser + "
+                        "first-appearance vocabulary, host) -> bfk_cluster_csr (H2D of the CSR, kernels, D2H of the labels); "
+                        "first_call includes context creation, code-object load and allocations; steady = median of 7 "
+                        "further calls", "text_bytes": len(buf)}
+        del raw
+
     indptr, indices, n_vocab = _lib.build_csr(rows, " ")
-    n_u, nnz = len(rows), int(indptr[-1])
+    nnz = int(indptr[-1])
     k = np.diff(indptr)
-    d = a.max_dist
 
     # one context on torch's current stream; with --pipeline P, P of them, each on a stream of its own
     pipe = max(1, a.pipeline)
@@ -170,6 +317,7 @@ def main():
     for s_ in streams:
         with torch.cuda.stream(s_):
             e_ = GpuEngine(local_rank)
+            e_.ctx.set_candidate_path(a.path)
             c_ = ShardedClusterer(e_, rank, world, a.merge)
             c_.bind(indptr, indices)
         engs.append(e_)
@@ -196,80 +344,168 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up; a candidate-queue overflow (dense inputs) is repaired inside sync() and grows the queue, so repeat
-    # until a step runs clean: the timed steps must be complete single-pass steps
-    for attempt in range(6):
-        run_steps(max(a.warmup, pipe))
-        st0 = sync_all()
-        again = int(st0["n_retry_slices"] != 0)
-        if world > 1:  # every rank must run the same number of steps (each step holds a collective)
-            tt = torch.tensor([again], dtype=torch.int32, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            again = int(tt.item())
-        if not again:
-            break
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st_timed = sync_all()  # checks the device-side overflow / error flags of the last timed step(s)
-    if st_timed["n_retry_slices"] != 0:
-        raise SystemExit("bench invalid: a timed step overflowed the candidate queue")
-    labels = sc.labels[0][:n_u].cpu().numpy()
+    def warm(count):
+        # a candidate-queue overflow (dense inputs) is repaired inside sync() and grows the queue, so repeat until a
+        # step runs clean: the timed steps must be complete single-pass steps
+        for _ in range(6):
+            run_steps(max(count, pipe))
+            st0 = sync_all()
+            again = int(st0["n_retry_slices"] != 0)
+            if world > 1:  # every rank must run the same number of steps (each step holds a collective)
+                tt = torch.tensor([again], dtype=torch.int32, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                again = int(tt.item())
+            if not again:
+                return
 
-    # dominant-kernel duration: HIP events on the launch stream, recorded inside libbfk around each phase
-    # of each step (ring of 64 event sets), over a second pass of the same steps
-    eng.ctx.set_profiling(True)
-    prof_steps = min(a.steps, 64)
-    for _ in range(prof_steps):
-        sc.step(d)
-    st = eng.sync()
-    eng.ctx.set_profiling(False)
+    def timed(count):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(count)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        st_ = sync_all()  # checks the device-side overflow / error flags of the last timed step(s)
+        if st_["n_retry_slices"] != 0:
+            raise SystemExit("bench invalid: a timed step overflowed the candidate queue")
+        return elapsed, st_
+
+    def profiled(count=64):
+        # per-phase durations: HIP events on the launch stream, recorded inside libbfk around each phase of each
+        # step (ring of 64 event sets), over a separate pass of the same steps
+        eng.ctx.set_profiling(True)
+        for _ in range(min(count, 64)):
+            sc.step(d)
+        st_ = eng.sync()
+        eng.ctx.set_profiling(False)
+        return st_
+
+    # ---- the contract's timed region: W warm-up steps, EXACTLY K steps
+    warm(a.warmup)
+    elapsed, st_timed = timed(a.steps)
+    labels = sc.labels[0][:n_u].cpu().numpy()
+    ms_step = elapsed / a.steps * 1e3
+
+    # ---- the same steps for >= 0.3 s
+    sustained = None
+    if world == 1:
+        n_sus = int(min(200000, max(a.steps, math.ceil(0.35 / max(ms_step * 1e-3, 1e-6)))))
+        e2, _ = timed(n_sus)
+        sustained = {"steps": n_sus, "seconds": round(e2, 4), "ms_per_step": e2 / n_sus * 1e3}
+    st = profiled()
+    edges_per_rank = None
+    if world > 1:
+        ne = torch.tensor([st["n_edges"]], dtype=torch.int64, device="cuda")
+        allne = [torch.zeros_like(ne) for _ in range(world)]
+        dist.all_gather(allne, ne)
+        edges_per_rank = [int(x.item()) for x in allne]
+
+    # ---- first step after a bind: k_verify launched, nothing memoised about this CSR
+    cold = None
+    if world == 1 and pipe == 1:
+        ts = []
+        for _ in range(5):
+            sc.bind(indptr, indices)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sc.step(d)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            eng.sync()
+        cold = sorted(ts)[len(ts) // 2]
+        warm(5)
+
+    # ---- the all-pairs kernels on the same workload (north_star's design), when the main leg ran the join
+    join = d == 1 and st["n_work_items"] == 0 and n_u > 0
+    allpairs = None
+    if full and join:
+        eng.ctx.set_candidate_path("allpairs")
+        warm(a.warmup)
+        n_ap = int(min(50000, max(200, math.ceil(0.2 / max(ms_step * 1.5e-3, 1e-6)))))
+        e3, _ = timed(n_ap)
+        lab_ap = sc.labels[0][:n_u].cpu().numpy()
+        st_ap = profiled()
+        w = st_ap["sig_words"]
+        t_pf = st_ap["ms_prefilter"] * 1e-3
+        cyc_per_slot = w * (2.6 + 4.3) + 4.3  # measured issue cost per pair slot (tools/ubench/valu_rate.hip)
+        ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
+        allpairs = {
+            "ms_per_step": e3 / n_ap * 1e3, "steps": n_ap, "value": n_u * (n_u - 1) / 2 * n_ap / e3,
+            "labels_equal_default_path": bool(np.array_equal(lab_ap, labels)),
+            "phases_ms": {kk: st_ap[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
+            "counters": {kk: st_ap[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges", "n_work_items")},
+            "roofline": {"bound": "valu", "kernel": f"k_prefilter<W={w}>", "pair_slots": st_ap["pairs_filtered"],
+                         "pair_slots_per_s": st_ap["pairs_filtered"] / t_pf if t_pf > 0 else None,
+                         "measured_issue_ceiling_slots_per_s": ceiling,
+                         "frac": st_ap["pairs_filtered"] / t_pf / ceiling if t_pf > 0 else None,
+                         "kernel_ms": st_ap["ms_prefilter"],
+                         "hbm": {"compulsory_bytes": 8 * n_u * w + 16 * n_u,
+                                 "note": "sorted signatures + row records once; the tile loop re-reads them from L2"}},
+        }
+        eng.ctx.set_candidate_path(a.path)
+        warm(5)
 
     if rank == 0:
-        b_alg, merged_pairs, resolved = algorithmic_bytes(k, d, nnz)
-        t_pf = st["ms_prefilter"] * 1e-3
-        # this rank's share of the pair tiles (work items are dealt round-robin)
-        achieved = b_alg / world / t_pf / 1e9 if t_pf > 0 else None
+        b_ref, merged_pairs, resolved = reference_equivalent_bytes(k, d, nnz)
+        t_dom = st["ms_prefilter"] * 1e-3
         w = st["sig_words"]
-        ops_per_pair = 2 * w + 1
-        valu = st["pairs_filtered"] * ops_per_pair / t_pf if t_pf > 0 else None
-        # measured issue cost on gfx950 (tools/ubench/valu_rate.hip, cycles per wave-instruction per SIMD @2.4 GHz):
-        # v_xor (VGPR operands) 2.6, v_bcnt 4.3, v_min 4.3 per slot
-        cyc_per_slot = w * (2.6 + 4.3) + 4.3
-        slots_ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
-        slots_rate = st["pairs_filtered"] / t_pf if t_pf > 0 else None
-        # measured HBM bytes per launch of the pair kernel: bench.py cannot collect PMC counters itself, so the
-        # figure comes from the committed rocprofv3 passes of this same command (tools/profile_gpu.sh), FETCH_SIZE
-        # doubled per the gfx950 note of the microarchitecture guide (an upper bound for 4-byte-per-lane reads)
-        # max-dist 1 up to 800k rows runs the variant join (k_jhash + k_join) instead of the all-pairs kernels
-        join = d == 1 and st["n_work_items"] == 0 and n_u > 0
-        dom = "k_join" if join else "k_prefilter"
-        traffic, traffic_src = None, None
-        if world == 1 and n_rows == 100000 and d == 1 and not a.indels:
-            import glob
-            for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                   "*_pmc_per_launch.json")), reverse=True):
-                pm = json.load(open(f))
-                hit = [v for kk, v in pm.items() if dom in kk and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-                if hit:
-                    traffic = (2.0 * hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0
-                    traffic_src = f"{os.path.basename(f)}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
-                    break
+        if join:
+            dom = "k_join"
+            # what k_join must move: every token once (4 nnz), row extents (4 N), row hashes (8 N); its table / bitmap
+            # lookups and the rows of the few matches are algorithm-internal traffic, not compulsory
+            comp = (4 * nnz + 12 * n_u) / world
+            comp_what = "4*nnz tokens + 4*N_u extents + 8*N_u row hashes, read once"
+            step_bytes = (8 * nnz + 44 * n_u) / world
+        else:
+            dom = f"k_prefilter<W={w}>"
+            comp = (4 * w * n_u + 16 * n_u) / world
+            comp_what = "sorted first-level signatures (4*W*N_u) + row records (16*N_u), read once"
+            step_bytes = (4 * nnz + (84 + 16 * w) * n_u) / world
+        achieved = comp / t_dom / 1e9 if t_dom > 0 else None
+        wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'allpairs'}"
+        tr = measured_traffic("k_join" if join else "k_prefilter", wl_key) if world == 1 else None
+        roof = {
+            "bound": "hbm", "kernel": dom,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS if achieved else None,
+            "traffic": tr["bytes"] if tr else None,
+            "traffic_detail": tr,
+            "algorithmic_bytes_per_launch": comp, "algorithmic_bytes_what": comp_what,
+            "kernel_ms": st["ms_prefilter"],
+            "kernel_ms_source": "HIP events on the launch stream around the kernel, mean of 64 steps (includes the "
+                                "launch gap, ~3 us more than rocprofv3's kernel time: profiles/)",
+            "whole_step": {"bytes": step_bytes, "GBps": step_bytes / (ms_step * 1e-3) / 1e9,
+                           "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "compulsory bytes of every kernel of the step / ms_per_step"},
+            "reference_equivalent": {
+                "bytes": b_ref / world, "pairs_in_reference_band": merged_pairs,
+                "equivalent_GBps": b_ref / world / (ms_step * 1e-3) / 1e9,
+                "note": "SURVEY 8(d) untiled operand-stream bytes, 4(k_i+k_j) per pair of the reference's length band + "
+                        "8 B per pruned pair: what an untiled all-pairs merge touches.  These kernels never stream those "
+                        "operands, so this is an algorithmic-speedup figure, not a bandwidth claim"},
+        }
+        if not join:
+            t_pf = t_dom
+            cyc_per_slot = w * (2.6 + 4.3) + 4.3
+            ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
+            roof["valu"] = {"pair_slots": st["pairs_filtered"], "pair_slots_per_s": st["pairs_filtered"] / t_pf if t_pf > 0 else None,
+                            "measured_issue_ceiling_slots_per_s": ceiling,
+                            "frac_of_measured_ceiling": st["pairs_filtered"] / t_pf / ceiling if t_pf > 0 else None,
+                            "note": "the pair kernel is VALU-issue-bound (xor + popcount + min per 32-bit signature "
+                                    "word per pair slot), its working set lives in L2; this is the binding roofline"}
+        else:
+            roof["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
         out = {
-            "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step)",
+            "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step) + clusters.tsv wall-clock",
             "value": resolved * a.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -279,59 +515,42 @@ def main():
                 "workload": f"{n_rows} synthetic SARS-CoV-2 profiles (SURVEY App. A, seed 20240601"
                             f"{', indels kept' if a.indels else ''}), N_u={n_u} unique, k_mean={nnz / n_u:.1f}, "
                             f"max-dist {d}",
+                "workload_key": wl_key, "kernel_source_digest": kernel_source_digest(),
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
+                "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else "all-pairs kernels (k_sig .. k_prefilter .. k_verify)"),
                 "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
-                "input": "CSR resident in HBM",
+                "input": "CSR resident in HBM (host-inclusive figures: t_cluster_host_ms)",
+                "steady_state_memo": ("k_verify is not launched in the timed steps: the previous synced step on this CSR queued "
+                                      "nothing for it (the queued set is a function of the CSR only; k_flatten re-checks). The "
+                                      "first step after a bind launches it: ms_per_step_cold" if join else None),
+                **({"collective_backend": backend, "world_size": world, "n_edges_per_rank": edges_per_rank} if world > 1 else {}),
                 **({"pipeline": f"{pipe} contexts on {pipe} streams, steps round-robin (opt-in experiment)"} if pipe > 1 else {}),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_join" if join else f"k_prefilter<W={w}>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": b_alg / world,
-                "kernel_ms": st["ms_prefilter"],
-                "note": ("SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
-                         "band + 8 B per pruned pair.  The variant join never forms those pairs: one hash-table "
-                         "lookup per token occurrence decides all of them (O(nnz) instead of O(N^2)), so frac >> 1 "
-                         "measures the algorithmic shortcut, not HBM over-subscription; what the kernel must move "
-                         "and what it does move are in `join` below and in profiles/ (FETCH_SIZE/WRITE_SIZE passes)"
-                         if join else
-                         "SURVEY 8(d) untiled operand-stream bytes: 4(k_i+k_j) per pair of the reference's length "
-                         "band + 8 B per pruned pair.  The kernel never streams those operands: the (k,f,g) sort key "
-                         "prunes ~92% of the band before any comparison and the rest is a 4-byte signature compare "
-                         "out of registers/LDS, so frac >> 1 measures algorithmic reuse, not HBM over-subscription; "
-                         "measured HBM bytes per launch are in profiles/ (FETCH_SIZE/WRITE_SIZE passes)"),
-                "pairs_in_reference_band": merged_pairs,
-                # the join kernel's own floor: every token, extent and row hash once (compulsory bytes) against the
-                # HBM peak; it is bound by its instruction stream (one wave-instruction sequence per row, 40 of 64 lanes
-                # busy; measured by switching its phases off: BFK_JOIN_DEBUG), not by bytes
-                **({"join": {"lookups": st["pairs_filtered"], "lookups_per_s": st["pairs_filtered"] / t_pf if t_pf > 0 else None,
-                             "compulsory_bytes": 4 * nnz + 12 * n_u,
-                             "compulsory_GBps": (4 * nnz + 12 * n_u) / world / t_pf / 1e9 if t_pf > 0 else None,
-                             "frac_of_hbm_peak": (4 * nnz + 12 * n_u) / world / t_pf / 1e9 / HBM_PEAK_GBS if t_pf > 0 else None}}
-                   if join else {}),
-                "valu": None if join else {"lane_ops_per_s": valu, "peak": VALU_PEAK_LANEOPS,
-                         "frac": valu / VALU_PEAK_LANEOPS if valu else None,
-                         "ops_per_pair": ops_per_pair, "pair_slots": st["pairs_filtered"],
-                         "pair_slots_per_s": slots_rate, "measured_issue_ceiling_slots_per_s": slots_ceiling,
-                         "frac_of_measured_ceiling": slots_rate / slots_ceiling if slots_rate else None},
-            },
+            "roofline": roof,
             "phases_ms": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
             "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges",
                                                "n_retry_slices", "n_work_items", "max_row_len")},
             "result": {"components": int(len(np.unique(labels))), "labels_crc": int(np.bitwise_xor.reduce(
                 (labels.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(13)))},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if sustained:
+            out["sustained"] = sustained
+        if cold is not None:
+            out["ms_per_step_cold"] = cold
+        if host:
+            host["labels_equal_resident_path"] = bool(np.array_equal(lab_first, labels))
+            out["t_cluster_host_ms"] = host
+            out["value_host_inclusive"] = resolved / (host["steady"] * 1e-3)
+        if cli:
+            out["clusters_tsv_wall_s"] = cli.get("seconds")
+            out["clusters_tsv"] = cli
+        if allpairs:
+            out["all_pairs"] = allpairs
+        if full and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(indptr, indices, d, n_u)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -65,6 +65,7 @@ EXPORTS = {
     "bfk_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bfk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bfk_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bfk_ctx_set_candidate_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "bfk_ctx_upload_csr": (C.c_int, [C.c_void_p, c_i32p, c_i32p, C.c_int64]),
     "bfk_ctx_bind_csr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "bfk_ctx_cluster": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -143,6 +144,22 @@ def build_csr(features, sep: str):
     if rc == -1 and len(sepb) == 0:
         raise ValueError("empty separator")
     _check(rc)
+    indices = np.ctypeslib.as_array(out, shape=(max(nnz.value, 1),))[: nnz.value].copy()
+    lib.bfk_free(out)
+    return indptr, indices, int(nv.value)
+
+
+def build_csr_bytes(buf: bytes, row_off, sep: str):
+    """bfk_build_csr on the C-ABI's own input: one byte buffer + int64 offsets[N+1] (no Python strings touched)."""
+    lib = load()
+    off = np.ascontiguousarray(row_off, dtype=np.int64)
+    n = len(off) - 1
+    sepb = sep.encode()
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    out = c_i32p()
+    nnz = C.c_int64()
+    nv = C.c_int32()
+    _check(lib.bfk_build_csr(buf, _p64(off), n, sepb, len(sepb), _p32(indptr), C.byref(out), C.byref(nnz), C.byref(nv)))
     indices = np.ctypeslib.as_array(out, shape=(max(nnz.value, 1),))[: nnz.value].copy()
     lib.bfk_free(out)
     return indptr, indices, int(nv.value)
@@ -345,6 +362,9 @@ class Context:
 
     def set_profiling(self, on=True):
         _check(self.lib.bfk_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def set_candidate_path(self, mode: str = "auto"):
+        _check(self.lib.bfk_ctx_set_candidate_path(self.h, {"auto": 0, "allpairs": 1, "join": 2}[mode]))
 
     def upload_csr(self, indptr, indices):
         indptr = np.ascontiguousarray(indptr, dtype=np.int32)

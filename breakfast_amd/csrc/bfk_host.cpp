@@ -196,6 +196,7 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
+    int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
     int join_empty_shard = -1, join_empty_shards = 0;
@@ -290,6 +291,19 @@ extern "C" int bfk_ctx_set_profiling(bfk_ctx *c, int32_t enable) {
     }
     c->profiling = enable != 0;
     c->n_prof_calls = 0;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
+    if (!c) return fail(BFK_EARG, "null ctx");
+    if (mode < 0 || mode > 2) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join");
+    if (mode != c->path_mode) {  // the other path's per-step invariants (clean histogram / cleared table sets) are void
+        c->need_zero = true;
+        c->join_clear = true;
+        c->join_empty_shard = -1;
+        c->last_tiles = 0;
+    }
+    c->path_mode = mode;
     return BFK_OK;
 }
 
@@ -458,6 +472,7 @@ static bool join_wanted(const bfk_ctx *c, int max_dist) {
     if (max_dist != 1 || c->join_off || c->nnz <= 0 || c->n > ((int64_t)1 << 27) || c->kcap >= (1 << 25) ||
         c->nnz > (int64_t)INT32_MAX - 4 * JOIN_TPW)  // 32-bit token offsets, position packed above 6 bits
         return false;
+    if (c->path_mode) return c->path_mode == 2;
     if (const char *e = getenv("BFK_JOIN")) return atoi(e) != 0;
     // measured (ms per step, join vs all-pairs): 100k rows 0.061 / 0.074, 300k 0.153 / 0.172, 600k 0.325 / 0.360,
     // 1M 0.537 / 0.505 — both grow about linearly there, the join's cost is the instruction stream per row

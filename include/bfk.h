@@ -113,6 +113,11 @@ int bfk_ctx_destroy(bfk_ctx *ctx);
 int bfk_ctx_set_stream(bfk_ctx *ctx, void *hip_stream);   /* NULL = the ctx's own stream */
 int bfk_ctx_set_profiling(bfk_ctx *ctx, int32_t enable);  /* record HIP events between phases */
 
+/* which candidate generator bfk_ctx_cluster uses: 0 = automatic (the default: variant join at max_dist 1 up to
+ * 800k rows, all-pairs kernels otherwise), 1 = always the all-pairs kernels, 2 = the variant join wherever it applies
+ * (max_dist 1).  Same labels either way; bench.py times both.                                              */
+int bfk_ctx_set_candidate_path(bfk_ctx *ctx, int32_t mode);
+
 /* copy a host CSR into ctx-owned device buffers (synchronous) */
 int bfk_ctx_upload_csr(bfk_ctx *ctx, const int32_t *indptr, const int32_t *indices, int64_t n_rows);
 /* borrow a CSR that already lives in device memory (int32 indptr[n_rows+1], int32 indices[nnz]);
