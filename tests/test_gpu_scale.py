@@ -1,0 +1,276 @@
+"""GPU parity at BASELINE.json's full sizes — configs[3] (1M profiles, max-dist 1, the 8-GPU sharding run on one
+GPU) and configs[4] (1M profiles, max-dist 5, indels kept) — through size-independent properties plus sampled rows
+against the oracle's select_ind path (get_neighbours_batch, src/breakfast/breakfast.py:223-276: query rows x all
+columns); the size switches of the host code (variant join up to 800k rows, third sort key from 600k) crossed with
+NO environment knob; one 50k-row comparison against the full oracle; and the one-process-per-GPU driver
+(GpuEngine + ShardedClusterer.step) on the HIP path.  Integer work: bit-exact."""
+
+import os
+
+import numpy as np
+import pytest
+
+from breakfast_amd import _lib
+from breakfast_amd.synth import generate_profiles
+from oracle import ref_port as orc
+
+pytestmark = pytest.mark.gpu
+CORES = min(16, os.cpu_count() or 8)
+
+
+@pytest.fixture(scope="module")
+def million():
+    """the 1M-row generator output (the smaller sizes below are its prefixes: the generator is sequential)"""
+    return generate_profiles(1_000_000)
+
+
+@pytest.fixture(scope="module")
+def million_indels():
+    return generate_profiles(1_000_000, p_del=0.05, p_ins=0.01)
+
+
+def _csr(rows):
+    uf = list(dict.fromkeys(rows))  # collapse_duplicates
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    return uf, indptr, indices
+
+
+def _check_fix_point(labels):
+    n = len(labels)
+    assert np.all(labels <= np.arange(n)) and np.array_equal(labels[labels], labels)
+
+
+def _check_sampled_rows(indptr, indices, d, labels, n_sample, seed):
+    """neighbour lists of sampled rows == the oracle's select_ind lists; and every neighbour shares the row's label"""
+    n = len(indptr) - 1
+    rng = np.random.default_rng(seed)
+    sel = np.sort(rng.choice(n, size=n_sample, replace=False)).astype(np.int64)
+    ptr, idx = _lib.neighbours_csr(indptr, indices, d, sel)
+    nf = np.diff(indptr).astype(np.int64)
+    n_nb = 0
+    for s, i in enumerate(sel.tolist()):
+        want = set()
+        for q in range(max(0, int(nf[i]) - d), int(nf[i]) + d + 1):
+            for l in orc.get_neighbours_batch(indptr, indices, nf, q, d, select_ind=np.array([i], np.int64), n_threads=CORES):
+                want |= set(l.tolist())
+        got = idx[ptr[s]: ptr[s + 1]]
+        assert set(got.tolist()) == want, f"row {i}"
+        assert np.all(labels[got] == labels[i])
+        n_nb += len(got) - 1
+    return n_nb
+
+
+def _check_permutation_invariance(uf, d, labels, seed):
+    n = len(uf)
+    perm = np.random.default_rng(seed).permutation(n)
+    ip2, ix2, _ = _lib.build_csr([uf[i] for i in perm], " ")
+    lp, _ = _lib.cluster_csr(ip2, ix2, d)
+    back = np.empty(n, np.int64)
+    back[perm] = np.arange(n)                      # original row -> permuted row
+    canon = np.full(n, n, np.int64)
+    np.minimum.at(canon, lp[back], np.arange(n))   # min original index per component of the permuted run
+    assert np.array_equal(canon[lp[back]], labels)
+
+
+def _sharded_labels(indptr, indices, d, n_shards):
+    """the N-GPU path on one GPU: every shard into its own local forest, label arrays merged like after an
+    all_gather"""
+    n = len(indptr) - 1
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_gath = ctx.alloc(4 * n * n_shards)
+    d_out = ctx.alloc(4 * n)
+    edges = 0
+    for s in range(n_shards):
+        for attempt in range(4):  # a dense shard may overflow the first queue: recovered inside sync, which grows it
+            ctx.cluster(d, d_gath + 4 * n * s, s, n_shards)
+            st = ctx.sync()
+            if st["n_retry_slices"] == 0 or attempt == 3:
+                break
+        edges += st["n_edges"]
+    ctx.merge_labels(d_gath, n_shards, d_out)
+    ctx.sync()
+    got = ctx.download_i32(d_out, n).copy()
+    ctx.close()
+    return got, edges
+
+
+def test_config3_one_million_rows_max_dist_1(million):
+    uf, indptr, indices = _csr(million)
+    assert len(uf) > 990_000
+    l1, st1 = _lib.cluster_csr(indptr, indices, 1)
+    assert st1["n_work_items"] > 0          # beyond 800k rows max-dist 1 runs the all-pairs kernels (third sort key)
+    assert st1["n_retry_slices"] == 0
+    assert st1["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
+    _check_fix_point(l1)
+    l2, _ = _lib.cluster_csr(indptr, indices, 2)
+    _check_fix_point(l2)
+    assert np.array_equal(l2[l1], l2)       # the partition at d refines the partition at d + 1
+    assert _check_sampled_rows(indptr, indices, 1, l1, 48, seed=11) > 0
+    _check_permutation_invariance(uf, 1, l1, seed=12)
+    got8, edges8 = _sharded_labels(indptr, indices, 1, 8)  # configs[3]: row-sharded over 8 ranks, label merge
+    assert np.array_equal(got8, l1)
+    assert edges8 == st1["n_edges"]         # every edge found by exactly one shard
+    # the forced variant join (it is the default up to 800k rows) agrees at this size too
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("join")
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * len(uf))
+    ctx.cluster(1, d_out)
+    stj = ctx.sync()
+    assert stj["n_work_items"] == 0 and stj["n_edges"] == st1["n_edges"]
+    assert np.array_equal(ctx.download_i32(d_out, len(uf)), l1)
+    ctx.close()
+
+
+def test_config4_one_million_rows_max_dist_5_indels(million_indels):
+    uf, indptr, indices = _csr(million_indels)
+    d = 5
+    l5, st5 = _lib.cluster_csr(indptr, indices, d)
+    if st5["n_retry_slices"]:               # the first queue is sized for sparse graphs; sync grows it: run again clean
+        l5b, st5 = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(l5b, l5)
+    _check_fix_point(l5)
+    l4, _ = _lib.cluster_csr(indptr, indices, 4)
+    assert np.array_equal(l5[l4], l5)
+    assert st5["n_edges"] > 5 * len(uf)     # the dense graph the configuration is about
+    assert _check_sampled_rows(indptr, indices, d, l5, 40, seed=21) > 40
+    _check_permutation_invariance(uf, d, l5, seed=22)
+    got8, edges8 = _sharded_labels(indptr, indices, d, 8)
+    assert np.array_equal(got8, l5)
+    assert edges8 == st5["n_edges"]
+
+
+@pytest.mark.parametrize("n_rows,join,third_key", [(590_000, True, False), (610_000, True, True), (790_000, True, True),
+                                                   (815_000, False, True)])
+def test_size_switches_without_knobs(million, n_rows, join, third_key):
+    """either side of the 600k third-key switch (the all-pairs kernels, max-dist 2) and of the 800k join switch
+    (max-dist 1); the paths must agree with each other and with sampled oracle rows"""
+    uf, indptr, indices = _csr(million[:n_rows])
+    n = len(uf)
+    assert (n >= 600_000) == third_key and (n <= 800_000) == join
+    l1, st = _lib.cluster_csr(indptr, indices, 1)
+    assert (st["n_work_items"] == 0) == join
+    _check_fix_point(l1)
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("allpairs" if join else "join")   # the other generator, same labels and edges
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * n)
+    ctx.cluster(1, d_out)
+    st_o = ctx.sync()
+    assert np.array_equal(ctx.download_i32(d_out, n), l1) and st_o["n_edges"] == st["n_edges"]
+    ctx.close()
+    l2, st2 = _lib.cluster_csr(indptr, indices, 2)           # all-pairs with / without the third key
+    assert np.array_equal(l2[l1], l2)
+    _check_sampled_rows(indptr, indices, 2, l2, 12, seed=n_rows)
+    _check_sampled_rows(indptr, indices, 1, l1, 12, seed=n_rows + 1)
+
+
+@pytest.mark.parametrize("d,indels", [(1, False), (2, True)])
+def test_50k_rows_against_the_full_oracle(d, indels):
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    uf, indptr, indices = _csr(generate_profiles(50000, **kw))
+    got, st = _lib.cluster_csr(indptr, indices, d)
+    want = orc.cluster_csr(indptr, indices, d, n_threads=CORES)["labels"]
+    assert st["n_retry_slices"] == 0
+    assert np.array_equal(got, want)
+
+
+# ---- the one-process-per-GPU driver on the HIP path ---------------------------------------------------------------
+def _driver_case():
+    uf, indptr, indices = _csr(generate_profiles(30000, p_del=0.03, p_ins=0.01))
+    return indptr, indices
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_gpu_engine_world_1_matches_one_shot(d):
+    import torch
+
+    from breakfast_amd.distributed import GpuEngine, ShardedClusterer
+
+    indptr, indices = _driver_case()
+    want, st1 = _lib.cluster_csr(indptr, indices, d)
+    eng = GpuEngine(0)
+    sc = ShardedClusterer(eng, 0, 1)
+    sc.bind(indptr, indices)
+    for _ in range(3):  # steady-state steps (the join memoises the empty verify queue after the first sync)
+        got = sc.step(d)
+        st = eng.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(got[: len(want)].cpu().numpy(), want)
+        assert st["n_edges"] == st1["n_edges"]
+
+
+def _nccl_worker(rank, world, port, d, merge, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from breakfast_amd.distributed import GpuEngine, ShardedClusterer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        indptr, indices = _driver_case()
+        eng = GpuEngine(rank)
+        sc = ShardedClusterer(eng, rank, world, merge)
+        sc.bind(indptr, indices)
+        for _ in range(2):
+            got = sc.step(d)
+            st = eng.sync()
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"labels_{rank}.npy"), got[: len(indptr) - 1].cpu().numpy())
+        np.save(os.path.join(out_dir, f"edges_{rank}.npy"), np.array([st["n_edges"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,merge", [(1, "allgather"), (2, "allgather"), (2, "allreduce")])
+def test_gpu_engine_world_2_over_rccl(d, merge, tmp_path):
+    """two ranks, two GPUs, RCCL label exchange: every rank ends with the 1-GPU labels (needs >= 2 devices)"""
+    if _lib.load().bfk_device_count() < 2:
+        pytest.skip("needs two gfx950 devices (the driver's 8-GPU node); one-device rehearsal: test below")
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    indptr, indices = _driver_case()
+    want, st1 = _lib.cluster_csr(indptr, indices, d)
+    mp.spawn(_nccl_worker, args=(2, port, d, merge, str(tmp_path)), nprocs=2, join=True)
+    edges = 0
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"labels_{r}.npy"), want)
+        edges += int(np.load(tmp_path / f"edges_{r}.npy")[0])
+    assert edges == st1["n_edges"]
+
+
+@pytest.mark.parametrize("d,world", [(1, 2), (2, 3)])
+def test_gpu_engine_sharded_steps_on_one_device(d, world):
+    """GpuEngine.cluster_shard + GpuEngine.merge for every rank of a `world`-rank run, executed one after the other on
+    this one GPU with the all_gather done by hand: the exchange protocol of ShardedClusterer.step on the HIP engine"""
+    import torch
+
+    from breakfast_amd.distributed import GpuEngine
+
+    indptr, indices = _driver_case()
+    n = len(indptr) - 1
+    want, st1 = _lib.cluster_csr(indptr, indices, d)
+    engs = [GpuEngine(0) for _ in range(world)]
+    local, edges = [], 0
+    for r, e in enumerate(engs):
+        e.bind(indptr, indices)
+        lab = e.new_labels(1)
+        e.cluster_shard(d, r, world, lab)
+        edges += e.sync()["n_edges"]
+        local.append(lab)
+    gathered = torch.cat(local, dim=0).contiguous()  # what all_gather_into_tensor leaves on every rank
+    for e in engs:
+        out = e.new_labels(1)
+        e.merge(gathered, world, out)
+        e.sync()
+        assert np.array_equal(out[0, :n].cpu().numpy(), want)
+    assert edges == st1["n_edges"]
