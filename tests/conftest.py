@@ -4,6 +4,9 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+# torch bundles its own HIP / HSA runtime and loads it by path: if libbfk.so has already pulled the system runtime into
+# the process, torch.cuda then finds "no HIP GPUs" (two runtimes, one device).  Loaded first, torch's copy serves both.
+import torch  # noqa: F401
 
 ROOT = Path(__file__).resolve().parent.parent
 GOLD = ROOT / "tests" / "golden"

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libbfk: see conftest.py)
 
 from breakfast_amd import _lib
 from breakfast_amd.synth import generate_profiles
@@ -41,20 +42,26 @@ def _check_fix_point(labels):
 
 
 def _check_sampled_rows(indptr, indices, d, labels, n_sample, seed):
-    """neighbour lists of sampled rows == the oracle's select_ind lists; and every neighbour shares the row's label"""
+    """neighbour lists of sampled rows == the oracle's select_ind lists (one get_neighbours_batch call per query length
+    q, like cluster_features' loop: the lists come back for the selected rows of the band of q, in row order); and
+    every neighbour shares the row's label"""
     n = len(indptr) - 1
     rng = np.random.default_rng(seed)
     sel = np.sort(rng.choice(n, size=n_sample, replace=False)).astype(np.int64)
     ptr, idx = _lib.neighbours_csr(indptr, indices, d, sel)
     nf = np.diff(indptr).astype(np.int64)
+    want = {int(i): set() for i in sel}
+    for q in sorted({int(q) for i in sel for q in range(max(0, int(nf[i]) - d), int(nf[i]) + d + 1)}):
+        rows_q = [int(i) for i in sel if abs(int(nf[i]) - q) <= d]
+        lists = orc.get_neighbours_batch(indptr, indices, nf, q, d, select_ind=sel, n_threads=CORES)
+        assert len(lists) == len(rows_q)
+        for i, l in zip(rows_q, lists):
+            assert i in l
+            want[i] |= set(l.tolist())
     n_nb = 0
     for s, i in enumerate(sel.tolist()):
-        want = set()
-        for q in range(max(0, int(nf[i]) - d), int(nf[i]) + d + 1):
-            for l in orc.get_neighbours_batch(indptr, indices, nf, q, d, select_ind=np.array([i], np.int64), n_threads=CORES):
-                want |= set(l.tolist())
         got = idx[ptr[s]: ptr[s + 1]]
-        assert set(got.tolist()) == want, f"row {i}"
+        assert set(got.tolist()) == want[i], f"row {i}"
         assert np.all(labels[got] == labels[i])
         n_nb += len(got) - 1
     return n_nb
