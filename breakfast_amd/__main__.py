@@ -1,4 +1,26 @@
-from .console import main
+import sys
+
+
+def _early_preload():
+    """Before click is even imported: if this is a plain clustering run, start loading the HIP library on a native thread
+    (fastpath.run would do it a few tens of milliseconds later; a second start is a no-op)."""
+    argv = sys.argv[1:]
+    if "--input-file" not in argv or "--input-cache" in argv or "--output-cache" in argv or "--help" in argv:
+        return
+    try:
+        i = argv.index("--max-dist") if "--max-dist" in argv else -1
+        if i >= 0 and argv[i + 1] == "0":
+            return
+        from . import _front
+
+        _front.preload(argv[argv.index("--input-file") + 1])
+    except Exception:  # never a reason to fail: the run proceeds without the head start
+        pass
+
+
+_early_preload()
+
+from .console import main  # noqa: E402
 
 if __name__ == "__main__":
     main()

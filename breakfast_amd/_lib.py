@@ -90,6 +90,10 @@ EXPORTS = {
     "bfk_table_feature": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_id": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_write": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i64p]),
+    "bfk_table_cluster_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, c_i64p]),
+    "bfk_warmup": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
+    "bfk_preload_start": (C.c_int, [C.c_char_p, C.c_int, C.c_int64, C.c_int64]),
+    "bfk_preload_wait": (C.c_int, []),
 }
 
 
@@ -165,7 +169,7 @@ def build_csr_bytes(buf: bytes, row_off, sep: str):
     return indptr, indices, int(nv.value)
 
 
-def cluster_csr(indptr, indices, max_dist: int):
+def cluster_csr(indptr, indices, max_dist: int, n_gpus: int = 1):
     """bfk_cluster_csr -> (labels int32[N] = min row index of the component, stats dict)"""
     lib = load()
     indptr = np.ascontiguousarray(indptr, dtype=np.int32)
@@ -173,7 +177,7 @@ def cluster_csr(indptr, indices, max_dist: int):
     n = len(indptr) - 1
     labels = np.empty(max(n, 1), dtype=np.int32)
     st = Stats()
-    _check(lib.bfk_cluster_csr(_p32(indptr), _p32(indices), n, int(max_dist), 1, _p32(labels), C.byref(st)))
+    _check(lib.bfk_cluster_csr(_p32(indptr), _p32(indices), n, int(max_dist), int(n_gpus), _p32(labels), C.byref(st)))
     return labels[:n], st.as_dict()
 
 

@@ -113,10 +113,10 @@ def collapse_duplicates(meta):
     return meta_nodups
 
 
-def cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache):
+def cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache, n_gpus=1):
     if max_dist == 0:
         return cluster_identical_features(meta_nodups, min_cluster_size)
-    return cluster_features(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache)
+    return cluster_features(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache, n_gpus=n_gpus)
 
 
 def _feature_csr(features, feature_sep):
@@ -173,7 +173,7 @@ def _assign_cluster_ids(meta, labels, min_cluster_size):
     return meta
 
 
-def cluster_features(meta, feature_sep, max_dist, min_cluster_size, input_cache, output_cache):
+def cluster_features(meta, feature_sep, max_dist, min_cluster_size, input_cache, output_cache, n_gpus=1):
     indptr, indices, _ = _feature_csr(meta["feature"], feature_sep)
     if len(indices) == 0:
         # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
@@ -185,7 +185,7 @@ def cluster_features(meta, feature_sep, max_dist, min_cluster_size, input_cache,
     else:
         print("Imported cached results are not available. "
               "Distance matrix of complete dataset will be calculated.")
-        labels, _ = _lib.cluster_csr(indptr, indices, max_dist)
+        labels, _ = _lib.cluster_csr(indptr, indices, max_dist, n_gpus)
     print("Create graph and recover connected components")
     print("Save clusters")
     return _assign_cluster_ids(meta, labels, min_cluster_size)

@@ -35,9 +35,11 @@ _DNA = ("covsonar_dna", "nextclade_dna")
 @click.option("--skip-ins/--no-skip-ins", default=True, help="Skip insertions")
 @click.option("--jobs", type=click.IntRange(1), default=1, envvar="OMP_NUM_THREADS",
               help="Number of jobs (threads); kept for compatibility, the GPU path ignores it")
+@click.option("--gpus", type=click.IntRange(1), default=1, envvar="BFK_GPUS",
+              help="GPUs to shard the distance work over (one process, one context per device; not in the reference)")
 @click.version_option(version=__version__)
 def main(input_file, outdir, input_cache, output_cache, id_col, clust_col, var_type, sep, sep2, max_dist,
-         min_cluster_size, trim_start, trim_end, reference_length, skip_del, skip_ins, jobs):
+         min_cluster_size, trim_start, trim_end, reference_length, skip_del, skip_ins, jobs, gpus):
     if var_type not in _DNA:
         # trimming / indel skipping only make sense for DNA profiles: explicit requests are errors,
         # the DNA-oriented defaults are switched off
@@ -74,7 +76,7 @@ def main(input_file, outdir, input_cache, output_cache, id_col, clust_col, var_t
         from . import fastpath
 
         if fastpath.run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
-                        reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache):
+                        reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache, gpus):
             return
     from . import breakfast  # pandas-based mirror of the reference's functions
 
@@ -82,5 +84,5 @@ def main(input_file, outdir, input_cache, output_cache, id_col, clust_col, var_t
     meta["feature"] = breakfast.filter_features(meta["feature"], sep2, var_type, skip_ins, skip_del, trim_start,
                                                 trim_end, reference_length)
     meta_nodups = breakfast.collapse_duplicates(meta)
-    meta_clustered = breakfast.cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache)
+    meta_clustered = breakfast.cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_cache, n_gpus=gpus)
     breakfast.write_output(meta_clustered, meta, outdir)

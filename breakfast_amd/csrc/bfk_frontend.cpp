@@ -10,13 +10,18 @@
 #include "../../include/bfk.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
-int bfk_fail(int code, const std::string &msg);  // bfk_host.cpp: sets the thread-local message
+int bfk_fail(int code, const std::string &msg);  // bfk_base.cpp: sets the thread-local message
+int bfk_front_cluster(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist, int32_t n_gpus,
+                      int32_t *labels_out);  // bfk_base.cpp: bfk_cluster_csr of the preloaded libbfk.so
 
 namespace {
 
@@ -162,7 +167,201 @@ struct TokSlot {
     uint8_t used;
 };
 
+// ---- host threads ----------------------------------------------------------------------------------
+// The text stages are row-parallel: contiguous row chunks, one std::thread each (BFK_THREADS overrides the count;
+// default = the CPUs this process may use, at most 16).  Results that depend on the input ORDER (first-appearance
+// vocabulary ids, the order of the "invalid feature" lines, first-appearance unique rows) are merged chunk by chunk
+// in row order, so the output is identical for every thread count (tests/test_frontend.py runs 1, 3 and 8).
+int host_threads() {
+    if (const char *e = getenv("BFK_THREADS")) return std::max(1, std::min(64, atoi(e)));
+    unsigned n = std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n ? n : 64, (unsigned)CPU_COUNT(&set));
+#endif
+    return (int)std::max(1u, std::min(16u, n));
+}
+
+void parallel_chunks(int n_chunks, const std::function<void(int)> &fn) {
+    if (n_chunks <= 1) {
+        if (n_chunks == 1) fn(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)n_chunks - 1);
+    for (int c = 1; c < n_chunks; c++) th.emplace_back(fn, c);
+    fn(0);
+    for (auto &t : th) t.join();
+}
+
+// ---- phase A of the tokeniser: one contiguous row chunk ---------------------------------------------
+// Rows are byte ranges of `base`; tokens are split on `sep` (non-overlapping, left to right, like str.split), empty
+// tokens never enter a row (:208-209).  With a classifier every distinct token is judged once (memoised in the
+// chunk's table); kept tokens get CHUNK-LOCAL ids in order of first kept appearance.
+struct TokChunk {
+    int64_t r0 = 0, r1 = 0;
+    std::vector<int32_t> ids;       // local (later global) ids of the kept tokens of all rows of the chunk
+    std::vector<int64_t> row_end;   // per row: end offset into ids
+    std::vector<Span> vocab;        // local id -> token bytes
+    std::vector<uint64_t> vhash;    // ... and their hashes (reused by the merge)
+    std::vector<Span> invalid;      // token occurrences that matched no pattern, in order
+    std::vector<int32_t> to_global;
+};
+
+void tokenize_chunk(const char *base, const std::function<Span(int64_t)> &row_span, const char *sep, int64_t sep_len,
+                    const Classifier *cls, TokChunk &ck) {
+    const char s0 = sep[0];
+    size_t tcap = 1u << 12, tcount = 0;
+    std::vector<TokSlot> tab(tcap, TokSlot{nullptr, 0, -1, 0, 0});
+    std::vector<uint64_t> hs(tcap, 0);
+    ck.row_end.reserve((size_t)(ck.r1 - ck.r0));
+    for (int64_t r = ck.r0; r < ck.r1; r++) {
+        const Span sp = row_span(r);
+        const char *s = base + sp.off;
+        const int64_t len = sp.len;
+        int64_t pos = 0;
+        while (pos <= len) {
+            int64_t nx = -1;  // next separator at or after pos
+            if (sep_len == 1) {
+                const void *f = pos < len ? memchr(s + pos, s0, (size_t)(len - pos)) : nullptr;
+                if (f) nx = (const char *)f - s;
+            } else {
+                for (int64_t i = pos; i + sep_len <= len; i++)
+                    if (s[i] == s0 && memcmp(s + i, sep, (size_t)sep_len) == 0) {
+                        nx = i;
+                        break;
+                    }
+            }
+            const int64_t tl = (nx < 0 ? len : nx) - pos;
+            const char *tk = s + pos;
+            if (tl == 0) {
+                // empty token: never in the CSR; with filtering its verdict still counts (it is "invalid" for most
+                // types and printed as such)
+                if (cls && (*cls)(tk, 0) == INVALID) ck.invalid.push_back(Span{tk - base, 0});
+            } else {
+                const uint64_t h = bytes_hash(tk, (size_t)tl);
+                size_t i = h & (tcap - 1);
+                while (tab[i].used && !(hs[i] == h && tab[i].len == (uint32_t)tl && memcmp(tab[i].p, tk, (size_t)tl) == 0)) i = (i + 1) & (tcap - 1);
+                if (!tab[i].used) {
+                    tab[i] = TokSlot{tk, (uint32_t)tl, -1, (int8_t)(cls ? (*cls)(tk, tl) : KEEP), 1};
+                    hs[i] = h;
+                    tcount++;
+                }
+                TokSlot &sl = tab[i];
+                if (sl.verdict == KEEP) {
+                    if (sl.id < 0) {
+                        sl.id = (int32_t)ck.vocab.size();
+                        ck.vocab.push_back(Span{tk - base, (int32_t)tl});
+                        ck.vhash.push_back(h);
+                    }
+                    ck.ids.push_back(sl.id);
+                } else if (sl.verdict == INVALID) {
+                    ck.invalid.push_back(Span{tk - base, (int32_t)tl});
+                }
+                if (tcount * 2 > tcap) {
+                    std::vector<TokSlot> nt(tcap * 2, TokSlot{nullptr, 0, -1, 0, 0});
+                    std::vector<uint64_t> nh(tcap * 2, 0);
+                    for (size_t o = 0; o < tcap; o++)
+                        if (tab[o].used) {
+                            size_t j = hs[o] & (tcap * 2 - 1);
+                            while (nt[j].used) j = (j + 1) & (tcap * 2 - 1);
+                            nt[j] = tab[o];
+                            nh[j] = hs[o];
+                        }
+                    tab.swap(nt);
+                    hs.swap(nh);
+                    tcap *= 2;
+                }
+            }
+            if (nx < 0) break;
+            pos = nx + sep_len;
+        }
+        ck.row_end.push_back((int64_t)ck.ids.size());
+    }
+}
+
+// ---- phases B + C: the chunks' vocabularies merged in row order (first-appearance ids of the whole input), then every
+// chunk's ids rewritten in place.  Returns the global vocabulary (token bytes per id).
+void merge_vocab(const char *base, std::vector<TokChunk> &cks, std::vector<Span> &vocab_out) {
+    size_t total = 0;
+    for (const TokChunk &c : cks) total += c.vocab.size();
+    size_t cap = 1u << 10;
+    while (cap < total * 2 + 16) cap <<= 1;
+    std::vector<int32_t> slot(cap, -1);
+    std::vector<uint64_t> sh(cap, 0);
+    vocab_out.clear();
+    for (TokChunk &c : cks) {
+        c.to_global.resize(c.vocab.size());
+        for (size_t l = 0; l < c.vocab.size(); l++) {
+            const Span v = c.vocab[l];
+            const uint64_t h = c.vhash[l];
+            size_t i = h & (cap - 1);
+            while (slot[i] >= 0) {
+                const Span o = vocab_out[(size_t)slot[i]];
+                if (sh[i] == h && o.len == v.len && memcmp(base + o.off, base + v.off, (size_t)v.len) == 0) break;
+                i = (i + 1) & (cap - 1);
+            }
+            if (slot[i] < 0) {
+                slot[i] = (int32_t)vocab_out.size();
+                sh[i] = h;
+                vocab_out.push_back(v);
+            }
+            c.to_global[l] = slot[i];
+        }
+    }
+    parallel_chunks((int)cks.size(), [&](int q) {
+        TokChunk &c = cks[(size_t)q];
+        for (int32_t &x : c.ids) x = c.to_global[(size_t)x];
+    });
+}
+
+std::vector<TokChunk> make_chunks(int64_t n_rows, int64_t total_bytes) {
+    int t = host_threads();
+    // a thread is worth starting for ~256 KiB of text
+    t = (int)std::max<int64_t>(1, std::min<int64_t>(t, std::min<int64_t>(n_rows, total_bytes / (256 << 10) + 1)));
+    std::vector<TokChunk> cks((size_t)t);
+    for (int q = 0; q < t; q++) {
+        cks[(size_t)q].r0 = n_rows * q / t;
+        cks[(size_t)q].r1 = n_rows * (q + 1) / t;
+    }
+    return cks;
+}
+
 }  // namespace
+
+// a1: tokeniser + first-appearance vocabulary + CSR (replaces sparse_feature_matrix, breakfast.py:193-215); row-parallel
+extern "C" int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                             int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off || !indptr_out || !indices_out || !nnz_out || !n_vocab_out || n_rows < 0 || (!buf && n_rows > 0 && row_off[n_rows] > 0))
+        return bfk_fail(BFK_EARG, "bfk_build_csr: null argument");
+    if (!sep || sep_len <= 0) return bfk_fail(BFK_EARG, "empty separator");
+    for (int64_t r = 0; r < n_rows; r++)
+        if (row_off[r + 1] < row_off[r] || row_off[r + 1] - row_off[r] > INT32_MAX) return bfk_fail(BFK_EARG, "bfk_build_csr: row_off not monotone");
+    std::vector<TokChunk> cks = make_chunks(n_rows, n_rows > 0 ? row_off[n_rows] - row_off[0] : 0);
+    const auto span = [&](int64_t r) { return Span{row_off[r], (int32_t)(row_off[r + 1] - row_off[r])}; };
+    parallel_chunks((int)cks.size(), [&](int q) { tokenize_chunk(buf, span, sep, sep_len, nullptr, cks[(size_t)q]); });
+    std::vector<Span> vocab;
+    merge_vocab(buf, cks, vocab);
+    int64_t nnz = 0;
+    std::vector<int64_t> base(cks.size());
+    for (size_t q = 0; q < cks.size(); q++) {
+        base[q] = nnz;
+        nnz += (int64_t)cks[q].ids.size();
+    }
+    if (nnz > (int64_t)INT32_MAX) return bfk_fail(BFK_EARG, "bfk_build_csr: more than 2^31-1 entries");
+    int32_t *out = (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(1, nnz));
+    if (!out) return bfk_fail(BFK_ENOMEM, "bfk_build_csr: out of memory");
+    indptr_out[0] = 0;
+    parallel_chunks((int)cks.size(), [&](int q) {
+        const TokChunk &c = cks[(size_t)q];
+        if (!c.ids.empty()) memcpy(out + base[(size_t)q], c.ids.data(), c.ids.size() * sizeof(int32_t));
+        for (int64_t r = c.r0; r < c.r1; r++) indptr_out[r + 1] = (int32_t)(base[(size_t)q] + c.row_end[(size_t)(r - c.r0)]);
+    });
+    *indices_out = out;
+    *nnz_out = nnz;
+    *n_vocab_out = (int32_t)vocab.size();
+    return BFK_OK;
+}
 
 struct bfk_table {
     std::vector<char> bytes;  // owned copy of the file / buffers
@@ -392,97 +591,52 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
     t->group.assign((size_t)n, 0);
     t->weight.clear();
     t->first_row.clear();
-    t->indptr.assign(1, 0);
-    t->indices.clear();
     t->invalid.clear();
     t->vocab.clear();
-    t->indices.reserve(t->bytes.size() / 6);
 
-    size_t tcap = 1u << 16, tcount = 0;
-    std::vector<TokSlot> tab(tcap, TokSlot{nullptr, 0, -1, 0, 0});
+    // phases A-C (row-parallel): tokens, verdicts, first-appearance vocabulary ids
+    std::vector<TokChunk> cks = make_chunks(n, (int64_t)t->bytes.size());
+    const auto span = [&](int64_t r) { return t->feats[(size_t)r]; };
+    parallel_chunks((int)cks.size(), [&](int q) { tokenize_chunk(b, span, sep2, sep2_len, filtering ? &cls : nullptr, cks[(size_t)q]); });
+    merge_vocab(b, cks, t->vocab);
+    for (const TokChunk &c : cks) t->invalid.insert(t->invalid.end(), c.invalid.begin(), c.invalid.end());
+
+    // identity of the (filtered) feature string: the kept token sequence when the string is re-joined, the raw bytes when
+    // it is passed through untouched.  Hashes row-parallel, the first-appearance grouping in row order.
+    std::vector<uint64_t> rh((size_t)n);
+    std::vector<const int32_t *> rp((size_t)n);  // the row's ids
+    std::vector<int32_t> rl((size_t)n);          // ... and how many
+    parallel_chunks((int)cks.size(), [&](int q) {
+        const TokChunk &c = cks[(size_t)q];
+        static const int32_t none = 0;
+        for (int64_t r = c.r0; r < c.r1; r++) {
+            const int64_t e0 = r == c.r0 ? 0 : c.row_end[(size_t)(r - c.r0 - 1)], e1 = c.row_end[(size_t)(r - c.r0)];
+            rp[(size_t)r] = c.ids.data() + e0;
+            rl[(size_t)r] = (int32_t)(e1 - e0);
+            const Span f = t->feats[(size_t)r];
+            rh[(size_t)r] = filtering ? bytes_hash((const char *)(e1 > e0 ? c.ids.data() + e0 : &none), (size_t)(e1 - e0) * sizeof(int32_t))
+                                      : bytes_hash(b + f.off, (size_t)f.len);
+        }
+    });
     size_t rcap = 1u << 12;
     while (rcap < (size_t)n * 2) rcap <<= 1;
     std::vector<int32_t> rtab(rcap, -1);  // row hash table -> unique index
-    std::vector<uint64_t> rhash;          // hash of every unique row
-    rhash.reserve((size_t)n);
-    std::vector<int32_t> row;  // kept token ids of the current row
-    const char s0 = sep2[0];
-
+    int64_t nnz = 0;
     for (int64_t r = 0; r < n; r++) {
-        const char *s = b + t->feats[(size_t)r].off;
-        const int64_t len = t->feats[(size_t)r].len;
-        row.clear();
-        int64_t pos = 0;
-        while (pos <= len) {
-            int64_t nx = -1;
-            if (sep2_len == 1) {
-                const void *f = pos < len ? memchr(s + pos, s0, (size_t)(len - pos)) : nullptr;
-                if (f) nx = (const char *)f - s;
-            } else {
-                for (int64_t i = pos; i + sep2_len <= len; i++)
-                    if (s[i] == s0 && memcmp(s + i, sep2, (size_t)sep2_len) == 0) {
-                        nx = i;
-                        break;
-                    }
-            }
-            const int64_t tl = (nx < 0 ? len : nx) - pos;
-            const char *tk = s + pos;
-            if (tl == 0) {
-                // empty token: never in the CSR (:208-209); with filtering its verdict still counts (it is
-                // "invalid" for most types and printed as such)
-                if (filtering) {
-                    const Verdict v = cls(tk, 0);
-                    if (v == INVALID) t->invalid.push_back(Span{tk - b, 0});
-                }
-            } else {
-                size_t i = bytes_hash(tk, (size_t)tl) & (tcap - 1);
-                while (tab[i].used && !(tab[i].len == (uint32_t)tl && memcmp(tab[i].p, tk, (size_t)tl) == 0)) i = (i + 1) & (tcap - 1);
-                if (!tab[i].used) {
-                    tab[i] = TokSlot{tk, (uint32_t)tl, -1, (int8_t)(filtering ? cls(tk, tl) : KEEP), 1};
-                    tcount++;
-                }
-                TokSlot &sl = tab[i];
-                if (sl.verdict == KEEP) {
-                    if (sl.id < 0) {
-                        sl.id = (int32_t)t->vocab.size();
-                        t->vocab.push_back(Span{tk - b, (int32_t)tl});
-                    }
-                    row.push_back(sl.id);
-                } else if (sl.verdict == INVALID) {
-                    t->invalid.push_back(Span{tk - b, (int32_t)tl});
-                }
-                if (tcount * 2 > tcap) {
-                    std::vector<TokSlot> nt(tcap * 2, TokSlot{nullptr, 0, -1, 0, 0});
-                    for (const TokSlot &o : tab)
-                        if (o.used) {
-                            size_t j = bytes_hash(o.p, o.len) & (tcap * 2 - 1);
-                            while (nt[j].used) j = (j + 1) & (tcap * 2 - 1);
-                            nt[j] = o;
-                        }
-                    tab.swap(nt);
-                    tcap *= 2;
-                }
-            }
-            if (nx < 0) break;
-            pos = nx + sep2_len;
-        }
-        // identity of the (filtered) feature string: the kept token sequence when the string is re-joined,
-        // the raw bytes when it is passed through untouched
-        static const int32_t none = 0;
-        const uint64_t h = filtering ? bytes_hash((const char *)(row.empty() ? &none : row.data()), row.size() * sizeof(int32_t))
-                                     : bytes_hash(s, (size_t)len);
+        const uint64_t h = rh[(size_t)r];
         size_t i = h & (rcap - 1);
         int32_t u = -1;
         while (rtab[i] >= 0) {
             const int32_t c = rtab[i];
-            if (rhash[(size_t)c] == h) {
+            const int64_t fr = t->first_row[(size_t)c];
+            if (rh[(size_t)fr] == h) {
                 bool same;
                 if (filtering) {
-                    const int32_t cb = t->indptr[(size_t)c], ce = t->indptr[(size_t)c + 1];
-                    same = (size_t)(ce - cb) == row.size() && (row.empty() || memcmp(&t->indices[(size_t)cb], row.data(), row.size() * sizeof(int32_t)) == 0);
+                    same = rl[(size_t)fr] == rl[(size_t)r] &&
+                           (rl[(size_t)r] == 0 || memcmp(rp[(size_t)fr], rp[(size_t)r], (size_t)rl[(size_t)r] * sizeof(int32_t)) == 0);
                 } else {
-                    const Span o = t->feats[(size_t)t->first_row[(size_t)c]];
-                    same = o.len == len && memcmp(b + o.off, s, (size_t)len) == 0;
+                    const Span o = t->feats[(size_t)fr], f = t->feats[(size_t)r];
+                    same = o.len == f.len && memcmp(b + o.off, b + f.off, (size_t)f.len) == 0;
                 }
                 if (same) {
                     u = c;
@@ -494,21 +648,34 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
         if (u < 0) {
             u = (int32_t)t->first_row.size();
             rtab[i] = u;
-            rhash.push_back(h);
             t->first_row.push_back((int32_t)r);
             t->weight.push_back(0);
-            if (t->indices.size() + row.size() > (size_t)INT32_MAX) return bfk_fail(BFK_EARG, "bfk_table_prepare: more than 2^31-1 entries");
-            t->indices.insert(t->indices.end(), row.begin(), row.end());
-            t->indptr.push_back((int32_t)t->indices.size());
+            nnz += rl[(size_t)r];
         }
         t->group[(size_t)r] = u;
         t->weight[(size_t)u]++;
     }
+    if (nnz > (int64_t)INT32_MAX) return bfk_fail(BFK_EARG, "bfk_table_prepare: more than 2^31-1 entries");
+    // CSR of the unique rows
+    const int64_t nu = (int64_t)t->first_row.size();
+    t->indptr.assign((size_t)nu + 1, 0);
+    for (int64_t u = 0; u < nu; u++) t->indptr[(size_t)u + 1] = t->indptr[(size_t)u] + rl[(size_t)t->first_row[(size_t)u]];
+    t->indices.reserve((size_t)std::max<int64_t>(nnz, 1));  // (data() must not be NULL for the views)
+    t->indices.resize((size_t)nnz);
+    {
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), nu / 8192 + 1));
+        parallel_chunks(parts, [&](int q) {
+            for (int64_t u = nu * q / parts; u < nu * (q + 1) / parts; u++) {
+                const int64_t fr = t->first_row[(size_t)u];
+                if (rl[(size_t)fr]) memcpy(t->indices.data() + t->indptr[(size_t)u], rp[(size_t)fr], (size_t)rl[(size_t)fr] * sizeof(int32_t));
+            }
+        });
+    }
     t->n_vocab = (int32_t)t->vocab.size();
     t->prepared = true;
     info->n_rows = n;
-    info->n_unique = (int64_t)t->first_row.size();
-    info->nnz = (int64_t)t->indices.size();
+    info->n_unique = nu;
+    info->nnz = nnz;
     info->n_invalid = (int64_t)t->invalid.size();
     info->n_vocab = t->n_vocab;
     info->filtered = filtering ? 1 : 0;
@@ -594,4 +761,25 @@ extern "C" int bfk_table_write(const bfk_table *t, const char *path, const int32
     if (fclose(f) != 0 || w != out.size()) return bfk_fail(BFK_EIO, std::string("short write on ") + path);
     if (n_clusters_out) *n_clusters_out = next;
     return BFK_OK;
+}
+
+extern "C" int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cluster_size, int32_t n_gpus, const char *path,
+                                       int64_t *n_clusters_out) {
+    if (!t || !t->prepared || !path || max_dist < 0 || min_cluster_size < 0) return bfk_fail(BFK_EARG, "bfk_table_cluster_write: bad argument");
+    const size_t nu = t->first_row.size();
+    std::vector<int32_t> labels(std::max<size_t>(nu, 1));
+    if (max_dist == 0) {
+        for (size_t u = 0; u < nu; u++) labels[u] = (int32_t)u;  // every unique string alone (:343-364)
+    } else if (int rc = bfk_front_cluster(t->indptr.data(), t->indices.data(), (int64_t)nu, max_dist, n_gpus, labels.data())) {
+        return rc;
+    }
+    // a component counts the ORIGINAL sequences of its rows (:329-339); labels are the component's smallest row
+    std::vector<int64_t> size(std::max<size_t>(nu, 1), 0);
+    for (size_t u = 0; u < nu; u++) {
+        if (labels[u] < 0 || (size_t)labels[u] >= nu) return bfk_fail(BFK_EARG, "bfk_table_cluster_write: label out of range");
+        size[(size_t)labels[u]] += t->weight[u];
+    }
+    std::vector<int32_t> cl(std::max<size_t>(nu, 1), 0);
+    for (size_t u = 0; u < nu; u++) cl[u] = size[(size_t)labels[u]] >= min_cluster_size ? labels[u] + 1 : 0;
+    return bfk_table_write(t, path, cl.data(), n_clusters_out);
 }

@@ -15,13 +15,8 @@
 
 using namespace bfk;
 
-static thread_local std::string g_err;
-
-static int fail(int code, const std::string &msg) {
-    g_err = msg;
-    return code;
-}
-int bfk_fail(int code, const std::string &msg) { return fail(code, msg); }  // for bfk_frontend.cpp
+int bfk_fail(int code, const std::string &msg);  // bfk_base.cpp (libbfk_front.so): sets the thread-local message
+static int fail(int code, const std::string &msg) { return bfk_fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -30,9 +25,7 @@ int bfk_fail(int code, const std::string &msg) { return fail(code, msg); }  // f
             return fail(BFK_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
 
-extern "C" int bfk_abi_version(void) { return BFK_ABI_VERSION; }
-extern "C" const char *bfk_last_error(void) { return g_err.c_str(); }
-extern "C" void bfk_free(void *p) { free(p); }
+// (bfk_abi_version, bfk_last_error, bfk_free: bfk_base.cpp)
 
 extern "C" int bfk_device_count(void) {
     int n = 0;
@@ -45,100 +38,7 @@ extern "C" int bfk_device_count(void) {
     return ok;
 }
 
-// ================================================================================================
-// a1: tokeniser + first-appearance vocabulary (replaces sparse_feature_matrix, breakfast.py:193-215)
-// ================================================================================================
-namespace {
-struct Slot {
-    const char *p;
-    uint32_t len;
-    int32_t id;
-};
-
-inline uint64_t tok_hash(const char *p, size_t n) {
-    // 8 bytes at a time multiply-mix (tokens are ~6-12 bytes: "C14408T", "del:11288:9")
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
-    while (n >= 8) {
-        uint64_t v;
-        memcpy(&v, p, 8);
-        h = (h ^ v) * 0xC4CEB9FE1A85EC53ull;
-        h ^= h >> 29;
-        p += 8;
-        n -= 8;
-    }
-    uint64_t v = 0;
-    memcpy(&v, p, n);
-    h = (h ^ v) * 0xC4CEB9FE1A85EC53ull;
-    return h ^ (h >> 32);
-}
-}  // namespace
-
-extern "C" int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
-                             int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out) {
-    if (!row_off || !indptr_out || !indices_out || !nnz_out || !n_vocab_out || n_rows < 0 || (!buf && n_rows > 0 && row_off[n_rows] > 0))
-        return fail(BFK_EARG, "bfk_build_csr: null argument");
-    if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
-    size_t tcap = 1u << 16, tcount = 0;
-    std::vector<Slot> tab(tcap, Slot{nullptr, 0, 0});
-    std::vector<int32_t> idx;
-    idx.reserve((size_t)std::max<int64_t>(1024, row_off[n_rows] / 6));
-    const char s0 = sep[0];
-    indptr_out[0] = 0;
-    for (int64_t r = 0; r < n_rows; r++) {
-        const char *s = buf + row_off[r];
-        const int64_t n = row_off[r + 1] - row_off[r];
-        if (n < 0) return fail(BFK_EARG, "bfk_build_csr: row_off not monotone");
-        int64_t pos = 0;
-        while (pos <= n) {
-            int64_t nx = -1;  // next separator at or after pos
-            if (sep_len == 1) {
-                const void *f = pos < n ? memchr(s + pos, s0, (size_t)(n - pos)) : nullptr;
-                if (f) nx = (const char *)f - s;
-            } else {
-                for (int64_t i = pos; i + sep_len <= n; i++)
-                    if (s[i] == s0 && memcmp(s + i, sep, (size_t)sep_len) == 0) {
-                        nx = i;
-                        break;
-                    }
-            }
-            const int64_t tl = (nx < 0 ? n : nx) - pos;
-            if (tl > 0) {
-                const char *t = s + pos;
-                size_t i = tok_hash(t, (size_t)tl) & (tcap - 1);
-                while (tab[i].p && !(tab[i].len == (uint32_t)tl && memcmp(tab[i].p, t, (size_t)tl) == 0))
-                    i = (i + 1) & (tcap - 1);
-                if (!tab[i].p) {
-                    tab[i] = Slot{t, (uint32_t)tl, (int32_t)tcount++};
-                    idx.push_back(tab[i].id);
-                    if (tcount * 2 > tcap) {
-                        std::vector<Slot> nt(tcap * 2, Slot{nullptr, 0, 0});
-                        for (const Slot &sl : tab)
-                            if (sl.p) {
-                                size_t j = tok_hash(sl.p, sl.len) & (tcap * 2 - 1);
-                                while (nt[j].p) j = (j + 1) & (tcap * 2 - 1);
-                                nt[j] = sl;
-                            }
-                        tab.swap(nt);
-                        tcap *= 2;
-                    }
-                } else {
-                    idx.push_back(tab[i].id);
-                }
-            }
-            if (nx < 0) break;
-            pos = nx + sep_len;
-        }
-        if (idx.size() > (size_t)INT32_MAX) return fail(BFK_EARG, "bfk_build_csr: more than 2^31-1 entries");
-        indptr_out[r + 1] = (int32_t)idx.size();
-    }
-    int32_t *out = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, idx.size()));
-    if (!out) return fail(BFK_ENOMEM, "bfk_build_csr: out of memory");
-    if (!idx.empty()) memcpy(out, idx.data(), sizeof(int32_t) * idx.size());
-    *indices_out = out;
-    *nnz_out = (int64_t)idx.size();
-    *n_vocab_out = (int32_t)tcount;
-    return BFK_OK;
-}
+// (a1, bfk_build_csr — tokeniser + first-appearance vocabulary — lives in bfk_frontend.cpp with the other text stages)
 
 // ================================================================================================
 // context
@@ -158,6 +58,8 @@ struct bfk_ctx {
     int *own_indptr = nullptr;
     uint32_t *own_indices = nullptr;
     int64_t own_n_cap = 0, own_nnz_cap = 0;
+    int *own_labels = nullptr, *own_gather = nullptr;  // one-shot entry points: labels; n_gpus > 1: the gathered label arrays
+    int64_t own_labels_cap = 0, own_gather_cap = 0;
     int64_t n = -1, nnz = 0;
     int kcap = 0;
     // workspace
@@ -264,7 +166,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,       c->d_start3, c->d_gkey,  c->d_srec,  c->d_sigu1,
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
-                    c->d_blk_stats, c->d_start3c, c->d_join};
+                    c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -950,23 +852,110 @@ static int default_ctx(bfk_ctx **out) {
     return BFK_OK;
 }
 
+// labels buffer of the one-shot entry points, kept with the context (no allocation per call)
+static int ctx_own_labels(bfk_ctx *c, int64_t n_rows) { return dev_realloc(&c->own_labels, &c->own_labels_cap, std::max<int64_t>(n_rows, 1)); }
+
+// Everything a first call pays that does not depend on the input: device context, stream, code-object load (first
+// launch), and — with size hints — the workspace allocations.  bfk_preload_start (bfk_base.cpp) runs it on a thread
+// while the input is parsed.
+extern "C" int bfk_warmup(int device, int64_t rows_hint, int64_t nnz_hint) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_default) {
+        if (const char *e = getenv("BFK_DEVICE")) device = atoi(e);
+        if (int rc = bfk_ctx_create(device, &g_default)) return rc;
+    }
+    bfk_ctx *c = g_default;
+    if (int rc = ctx_enter(c)) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 64, c->stream));
+    if (int e = launch_maxlen(c->d_small, 1, c->d_small + 4, c->stream))  // any kernel: loads the code object
+        return fail(BFK_EHIP, std::string("warm-up launch: ") + hipGetErrorString((hipError_t)e));
+    if (rows_hint > 0 && nnz_hint > 0 && rows_hint < ((int64_t)1 << 27) && nnz_hint < ((int64_t)1 << 30)) {
+        const int64_t n0 = c->n, nnz0 = c->nnz;
+        const int k0 = c->kcap;
+        int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, rows_hint + 1);
+        if (!rc) rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_hint + 1);
+        if (!rc) rc = ctx_own_labels(c, rows_hint);
+        c->n = rows_hint;
+        c->nnz = nnz_hint;
+        c->kcap = 128;
+        if (!rc) rc = ctx_size_workspace(c, 1);
+        if (!rc) rc = ctx_size_join(c);
+        c->n = n0;
+        c->nnz = nnz0;
+        c->kcap = k0;
+        c->need_zero = true;
+        c->join_clear = true;
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFK_OK;
+}
+
+// n_gpus > 1 from ONE process: a context per device, every device clusters its shard of the work (the CSR is replicated,
+// SURVEY 8e), the label arrays are copied to the first device over xGMI (peer copies) and merged there like after an
+// all_gather.  (The one-process-per-GPU form with RCCL collectives is breakfast_amd/distributed.py; this is the same
+// split behind the one-shot C-ABI, for callers without a process launcher.)  BFK_MULTI_ONE_DEVICE=1 rehearses it with
+// every context on device 0.
+static std::vector<bfk_ctx *> g_multi;
+
+static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist, int32_t n_gpus,
+                         int32_t *labels_out, bfk_stats *stats_out) {
+    const bool one = getenv("BFK_MULTI_ONE_DEVICE") && atoi(getenv("BFK_MULTI_ONE_DEVICE")) != 0;
+    const int ndev = bfk_device_count();
+    if (!one && n_gpus > ndev) return fail(BFK_ENODEV, "bfk_cluster_csr: n_gpus = " + std::to_string(n_gpus) + " but " + std::to_string(ndev) + " gfx950 device(s) visible");
+    while ((int)g_multi.size() < n_gpus) {
+        bfk_ctx *c = nullptr;
+        if (int rc = bfk_ctx_create(one ? 0 : (int)g_multi.size(), &c)) return rc;
+        g_multi.push_back(c);
+    }
+    for (int g = 0; g < n_gpus; g++) {
+        bfk_ctx *c = g_multi[(size_t)g];
+        if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
+        if (int rc = ctx_own_labels(c, n_rows)) return rc;
+    }
+    for (int g = 0; g < n_gpus; g++)  // asynchronous: the devices work side by side
+        if (int rc = bfk_ctx_cluster(g_multi[(size_t)g], max_dist, g, n_gpus, g_multi[(size_t)g]->own_labels)) return rc;
+    bfk_stats total{};
+    for (int g = 0; g < n_gpus; g++) {
+        bfk_stats st{};
+        if (int rc = bfk_ctx_sync(g_multi[(size_t)g], &st)) return rc;
+        if (g == 0) total = st;
+        else {
+            total.pairs_filtered += st.pairs_filtered;
+            total.n_candidates += st.n_candidates;
+            total.n_edges += st.n_edges;
+            total.n_retry_slices += st.n_retry_slices;
+        }
+    }
+    total.pairs_resolved = n_rows * (n_rows - 1) / 2;
+    bfk_ctx *c0 = g_multi[0];
+    if (int rc = ctx_enter(c0)) return rc;
+    if (n_rows > 0) {
+        if (int rc = dev_realloc(&c0->own_gather, &c0->own_gather_cap, n_rows * n_gpus)) return rc;
+        for (int g = 0; g < n_gpus; g++)
+            HIP_TRY(hipMemcpyPeerAsync(c0->own_gather + (size_t)g * n_rows, c0->device, g_multi[(size_t)g]->own_labels,
+                                       g_multi[(size_t)g]->device, (size_t)n_rows * 4, c0->stream));
+        if (int rc = bfk_ctx_merge_labels(c0, c0->own_gather, n_gpus, c0->own_labels, nullptr)) return rc;
+        if (int rc = bfk_ctx_sync(c0, nullptr)) return rc;
+        if (int rc = bfk_ctx_download(c0, c0->own_labels, labels_out, n_rows * 4)) return rc;
+    }
+    if (stats_out) *stats_out = total;
+    return BFK_OK;
+}
+
 extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
                                int32_t n_gpus, int32_t *labels_out, bfk_stats *stats_out) {
-    if (n_gpus > 1)
-        return fail(BFK_EARG, "bfk_cluster_csr drives one GPU; multi-GPU runs one process per GPU through bfk_ctx_*");
     if (n_rows < 0 || !indptr || (n_rows > 0 && !labels_out)) return fail(BFK_EARG, "bad arguments");
+    if (n_gpus < 1 || n_gpus > 64) return fail(BFK_EARG, "n_gpus must be 1..64");
     std::lock_guard<std::mutex> lk(g_mu);
+    if (n_gpus > 1) return cluster_multi(indptr, indices, n_rows, max_dist, n_gpus, labels_out, stats_out);
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
-    void *d_labels = nullptr;
-    if (int rc = bfk_ctx_device_alloc(c, n_rows * 4, &d_labels)) return rc;
-    int rc = bfk_ctx_cluster(c, max_dist, 0, 1, d_labels);
+    if (int rc = ctx_own_labels(c, n_rows)) return rc;
+    int rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
     if (!rc) rc = bfk_ctx_sync(c, stats_out);
-    if (!rc) rc = bfk_ctx_download(c, d_labels, labels_out, n_rows * 4);
-    std::string keep = g_err;
-    (void)bfk_ctx_device_free(c, d_labels);
-    g_err = keep;
+    if (!rc) rc = bfk_ctx_download(c, c->own_labels, labels_out, n_rows * 4);
     return rc;
 }
 
@@ -979,8 +968,8 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
-    void *d_labels = nullptr;
-    if (int rc = bfk_ctx_device_alloc(c, n_rows * 4, &d_labels)) return rc;
+    if (int rc = ctx_own_labels(c, n_rows)) return rc;
+    void *d_labels = c->own_labels;
     int32_t *edges = nullptr;
     int64_t ne = 0;
     int rc = BFK_OK;
@@ -993,9 +982,6 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
         if ((rc = ctx_size_cand(c, c->cand_cap_total * 4))) break;
     }
     bfk_ctx_set_edge_capture(c, 0);
-    std::string keep = g_err;
-    (void)bfk_ctx_device_free(c, d_labels);
-    g_err = keep;
     if (rc) return rc;
     // adjacency (both directions) + self, ascending
     std::vector<int64_t> deg((size_t)n_rows + 1, 0);

@@ -1,5 +1,6 @@
 """Native end-to-end path of the CLI (SURVEY.md 8 f1 + f3): reader, filter + collapse + CSR and the
-clusters.tsv writer run in libbfk (bfk_table_*), the clustering on the GPU; pandas is not imported.
+clusters.tsv writer run in libbfk (bfk_table_*), the clustering on the GPU; neither pandas nor numpy is imported, and the HIP library loads on a native thread
+while the input is parsed (_front.preload).
 
 Equivalent, byte for byte and print for print, to
 
@@ -13,14 +14,15 @@ missing columns ...), and when a cache is involved (the cache file stores pandas
 
 from __future__ import annotations
 
-import numpy as np
-
-from . import _lib
+from . import _front
 
 
 def cluster_ids(labels, weight, min_cluster_size):
     """breakfast.py:329-339 on canonical labels: a component counts the ORIGINAL sequences of its rows;
-    -> (cluster number per unique row, 0 = none; number of clusters)"""
+    -> (cluster number per unique row, 0 = none; number of clusters).  (numpy twin of what bfk_table_cluster_write does
+    natively; used by the API path and the tests)"""
+    import numpy as np
+
     uniq, inv = np.unique(labels, return_inverse=True)
     size = np.bincount(inv, weights=weight, minlength=len(uniq))
     keep = size >= min_cluster_size
@@ -29,15 +31,17 @@ def cluster_ids(labels, weight, min_cluster_size):
 
 
 def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
-        reference_length, max_dist, min_cluster_size, outdir, input_cache=None, output_cache=None) -> bool:
+        reference_length, max_dist, min_cluster_size, outdir, input_cache=None, output_cache=None, n_gpus=1) -> bool:
     if input_cache is not None or output_cache:
         return False
-    if var_type not in _lib.VAR_TYPES or len(sep2) == 0:
+    if var_type not in _front.VAR_TYPES or len(sep2) == 0:
         return False
+    if max_dist != 0:
+        _front.preload(input_file)  # HIP runtime + context + code object on a native thread while the input is parsed
     try:
-        table = _lib.Table.open(input_file, sep, id_col, clust_col)
+        table = _front.Table.open(input_file, sep, id_col, clust_col)
         info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
-    except _lib.Unsupported:
+    except _front.Unsupported:
         return False
     n, nu = int(info.n_rows), int(info.n_unique)
     print(f"Number of sequences: {n}")
@@ -45,21 +49,19 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
         print(f"Skipping invalid feature: '{table.invalid(i)}'")
     print(f"Number of duplicates: {n - nu}")
     print(f"Number of unique sequences: {nu}")
+    outdir.mkdir(parents=True, exist_ok=True)
     if max_dist == 0:
         print("Skip sparse matrix calculation since max-dist = 0")
-        labels = np.arange(nu, dtype=np.int32)
+        n_clusters = table.cluster_write(0, min_cluster_size, outdir / "clusters.tsv")
     else:
         if info.nnz == 0:
             # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
             raise ValueError("unable to infer matrix dimensions")
         print("Imported cached results are not available. "
               "Distance matrix of complete dataset will be calculated.")
-        labels, _ = _lib.cluster_csr(table.indptr, table.indices, max_dist)
+        n_clusters = table.cluster_write(max_dist, min_cluster_size, outdir / "clusters.tsv", n_gpus)
         print("Create graph and recover connected components")
         print("Save clusters")
-    cid, n_clusters = cluster_ids(labels, table.weight, min_cluster_size)
     print(f"Number of clusters found: {n_clusters}")
-    outdir.mkdir(parents=True, exist_ok=True)
-    table.write(outdir / "clusters.tsv", cid)
     table.close()
     return True

@@ -68,6 +68,10 @@ int bfk_device_count(void); /* number of visible gfx950 devices; 0 if none / no 
 const char *bfk_last_error(void);
 void bfk_free(void *p);
 
+/* Pay what a first call pays and that does not depend on the input — device context, stream, code-object load, and with
+ * size hints (> 0) the workspace allocations — e.g. on a thread while the input is read (bfk_preload_start). */
+int bfk_warmup(int device, int64_t rows_hint, int64_t nnz_hint);
+
 /* ---- a1: vocabulary + CSR --------------------------------------------------------------------
  * Replaces sparse_feature_matrix(features, feature_sep)            src/breakfast/breakfast.py:193-215.
  * Row r is the byte range buf[row_off[r] .. row_off[r+1]).  Tokens are split on `sep` (non-overlapping,
@@ -83,7 +87,9 @@ int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const
  *   n_features / band loop (:287-319) -> get_neighbours_batch (:223-276) -> sklearn _sparse_manhattan
  *   -> _reduce_func (:226-228) -> _to_graph (:93-113) -> networkx connected_components (:325-326).
  * indices may be unsorted and may contain repeats (multiset rows).  labels_out: int32[n_rows].
- * n_gpus must be 1 here (multi-GPU runs one process per GPU through the ctx API below).
+ * n_gpus > 1: one context per device in THIS process, the work sharded over the devices (CSR replicated), label arrays
+ * copied to the first device (peer copies over xGMI) and merged there; the one-process-per-GPU form with RCCL collectives
+ * goes through the ctx API below (breakfast_amd/distributed.py).  Same labels either way.
  * stats_out may be NULL.                                                                            */
 int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist, int32_t n_gpus,
                     int32_t *labels_out, bfk_stats *stats_out);
@@ -211,6 +217,17 @@ int bfk_table_invalid(const bfk_table *t, int64_t i, const char **tok_out, int64
 int bfk_table_feature(const bfk_table *t, int64_t u, char **str_out, int64_t *len_out);
 /* id of input row r (view) */
 int bfk_table_id(const bfk_table *t, int64_t r, const char **id_out, int64_t *len_out);
+
+/* ---- the CLI's whole tail in one call -----------------------------------------------------------------------------
+ * bfk_preload_start: a native thread loads `libbfk_path` (libbfk.so: HIP runtime, code object) and runs bfk_warmup(device,
+ * hints) while the caller parses its input with the bfk_table_* functions of libbfk_front.so (which has no HIP dependency).
+ * bfk_table_cluster_write: labels of the prepared table's unique rows (max_dist 0: every unique row alone,
+ * cluster_identical_features :343-364; else bfk_cluster_csr through the preloaded library), component sizes = summed
+ * weights against min_cluster_size (:329-339), then bfk_table_write.  Replaces cluster + write_output (console.py:166-170). */
+int bfk_preload_start(const char *libbfk_path, int device, int64_t rows_hint, int64_t nnz_hint);
+int bfk_preload_wait(void);
+int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cluster_size, int32_t n_gpus, const char *path,
+                            int64_t *n_clusters_out);
 
 /* write `path` = "id\tcluster_id" per input row in input order; cluster_of_unique[u] = any positive cluster
  * number or 0 for none; numbers are re-assigned 1.. by first appearance in input order (:51-60).       */

@@ -242,3 +242,29 @@ def test_cli_fastpath_declines_cache_and_dialects(tmp_path):
     p.write_text("accession\tdna_profile\na\tC300T\n")
     assert fastpath.run(p, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 0, 2,
                         tmp_path / "o", None, tmp_path / "cache.pkl") is False
+
+
+@pytest.mark.parametrize("indels", [False, True])
+def test_thread_count_never_changes_the_result(indels, monkeypatch):
+    """the text stages are row-parallel (BFK_THREADS); first-appearance vocabulary ids, the order of the invalid tokens and
+    the first-appearance unique rows must not depend on the number of chunks"""
+    from breakfast_amd.synth import generate_profiles
+
+    kw = dict(p_del=0.05, p_ins=0.02) if indels else {}
+    rows = generate_profiles(6000, **kw)
+    rows = rows + rows[:500] + ["bad:token " + rows[7], "", rows[3] + "  " + rows[5]]
+    ids = [f"s{i}" for i in range(len(rows))]
+    ref = None
+    for threads in ("1", "2", "3", "8", "16"):
+        monkeypatch.setenv("BFK_THREADS", threads)
+        ip, ix, nv = _lib.build_csr(rows, " ")
+        t = _lib.Table.from_lists(ids, rows)
+        info = t.prepare(" ", "covsonar_dna", True, not indels, 264, 228, 29903)
+        got = (ip.copy(), ix.copy(), nv, t.group.copy(), t.weight.copy(), t.indptr.copy(), t.indices.copy(),
+               [t.invalid(i) for i in range(int(info.n_invalid))], int(info.n_vocab))
+        t.close()
+        if ref is None:
+            ref = got
+            continue
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b

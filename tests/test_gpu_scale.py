@@ -281,3 +281,46 @@ def test_gpu_engine_sharded_steps_on_one_device(d, world):
         e.sync()
         assert np.array_equal(out[0, :n].cpu().numpy(), want)
     assert edges == st1["n_edges"]
+
+
+# ---- n_gpus > 1 behind the one-shot C-ABI and the CLI (one process, one context per device) ------------------------------
+@pytest.mark.parametrize("d,n_gpus", [(1, 2), (2, 3), (3, 8)])
+def test_cluster_csr_n_gpus_rehearsed_on_one_device(d, n_gpus, monkeypatch):
+    """bfk_cluster_csr(n_gpus > 1): shards on their own contexts, label arrays gathered by peer copies, merged on the first
+    device.  BFK_MULTI_ONE_DEVICE=1 puts every context on device 0 (the driver's 8-GPU node runs it on 8 devices)"""
+    indptr, indices = _driver_case()
+    want, st1 = _lib.cluster_csr(indptr, indices, d)
+    if _lib.load().bfk_device_count() < n_gpus:
+        monkeypatch.setenv("BFK_MULTI_ONE_DEVICE", "1")
+    got, st = _lib.cluster_csr(indptr, indices, d, n_gpus=n_gpus)
+    assert np.array_equal(got, want)
+    assert st["n_edges"] == st1["n_edges"] and st["pairs_resolved"] == st1["pairs_resolved"]
+
+
+def test_cluster_csr_rejects_more_gpus_than_devices():
+    indptr, indices = _driver_case()
+    have = _lib.load().bfk_device_count()
+    with pytest.raises(_lib.BfkError) as e:
+        _lib.cluster_csr(indptr, indices, 1, n_gpus=have + 1)
+    assert e.value.code == -3
+
+
+def test_cli_gpus_option(tmp_path, monkeypatch):
+    import hashlib
+
+    import click.testing
+
+    from breakfast_amd import console
+    from breakfast_amd.synth import generate_tsv
+
+    inp = tmp_path / "in.tsv"
+    generate_tsv(inp, 20000)
+    outs = []
+    for gpus in (1, 2):
+        if gpus > _lib.load().bfk_device_count():
+            monkeypatch.setenv("BFK_MULTI_ONE_DEVICE", "1")
+        out = tmp_path / f"g{gpus}"
+        res = click.testing.CliRunner().invoke(console.main, ["--input-file", str(inp), "--outdir", str(out), "--gpus", str(gpus)])
+        assert res.exit_code == 0, (res.output, res.exception)
+        outs.append(hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest())
+    assert outs[0] == outs[1]
