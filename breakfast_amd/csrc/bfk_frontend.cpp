@@ -432,10 +432,20 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     t->bytes[(size_t)sz] = '\n';  // sentinel: the last line always ends
     const char *b = t->bytes.data();
     const int64_t n = sz;
-    for (int64_t i = 0; i < n; i++) {
-        const unsigned char c = (unsigned char)b[i];
-        // CR is accepted only as part of a CRLF line end (the reference's own fixtures are CRLF files)
-        if (c >= 0x80 || c == '"' || c == 0 || (c == '\r' && b[i + 1] != '\n')) {
+    {   // byte checks, in parallel slices
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / (1 << 20) + 1));
+        std::atomic<int> bad{0};
+        parallel_chunks(parts, [&](int q) {
+            for (int64_t i = n * q / parts, e = n * (q + 1) / parts; i < e; i++) {
+                const unsigned char c = (unsigned char)b[i];
+                // CR is accepted only as part of a CRLF line end (the reference's own fixtures are CRLF files)
+                if (c >= 0x80 || c == '"' || c == 0 || (c == '\r' && b[i + 1] != '\n')) {
+                    bad.store(1);
+                    return;
+                }
+            }
+        });
+        if (bad.load()) {
             delete t;
             return unsupported("quote, lone CR, NUL or non-ASCII byte");
         }
@@ -486,42 +496,75 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
         return unsupported("column not found");
     }
     pos = header_lf + 1;
-    t->ids.reserve((size_t)(n / 256 + 16));
-    t->feats.reserve((size_t)(n / 256 + 16));
-    while (pos < n) {
-        int64_t le;
-        const int64_t lf = line_end(pos, &le);
-        if (le == pos) {  // blank line: skipped
-            pos = lf + 1;
-            continue;
+    {   // data lines, in parallel slices that start at line starts; the slices' rows are concatenated in order
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n - pos) / (1 << 20) + 1));
+        std::vector<int64_t> cut((size_t)parts + 1, n);
+        cut[0] = pos;
+        for (int q = 1; q < parts; q++) {
+            const int64_t at = std::max(cut[(size_t)q - 1], pos + (n - pos) * q / parts);
+            int64_t ce;
+            cut[(size_t)q] = at >= n ? n : std::min<int64_t>(n, line_end(at, &ce) + 1);  // the line straddling the cut stays with the slice before
         }
-        int col = 0;
-        Span id{0, -1}, ft{0, -1};
-        for (int64_t s = pos;;) {
-            const char *c = (const char *)memchr(b + s, sp, (size_t)(le - s));
-            const int64_t e = c ? c - b : le;
-            if (e - s > INT32_MAX) {
-                delete t;
-                return unsupported("field longer than 2 GiB");
+        std::vector<std::vector<Span>> pid((size_t)parts), pft((size_t)parts);
+        std::vector<const char *> why((size_t)parts, nullptr);
+        parallel_chunks(parts, [&](int q) {
+            int64_t p = cut[(size_t)q];
+            const int64_t pe = cut[(size_t)q + 1];
+            auto &vi = pid[(size_t)q];
+            auto &vf = pft[(size_t)q];
+            vi.reserve((size_t)((pe - p) / 256 + 16));
+            vf.reserve((size_t)((pe - p) / 256 + 16));
+            while (p < pe) {
+                int64_t le;
+                const int64_t lf = line_end(p, &le);
+                if (le == p) {  // blank line: skipped
+                    p = lf + 1;
+                    continue;
+                }
+                int col = 0;
+                Span id{0, -1}, ft{0, -1};
+                for (int64_t s0 = p;;) {
+                    const char *c = (const char *)memchr(b + s0, sp, (size_t)(le - s0));
+                    const int64_t e = c ? c - b : le;
+                    if (e - s0 > INT32_MAX) {
+                        why[(size_t)q] = "field longer than 2 GiB";
+                        return;
+                    }
+                    if (col == id_i) id = Span{s0, (int32_t)(e - s0)};
+                    if (col == ft_i) ft = Span{s0, (int32_t)(e - s0)};
+                    col++;
+                    if (!c) break;
+                    s0 = e + 1;
+                }
+                if (col != ncols) {
+                    why[(size_t)q] = "ragged row";
+                    return;
+                }
+                if (is_na(b + id.off, id.len)) {
+                    why[(size_t)q] = "NA-valued id";
+                    return;
+                }
+                if (is_na(b + ft.off, ft.len)) ft.len = 0;  // NaN -> "" (fillna, :28)
+                vi.push_back(id);
+                vf.push_back(ft);
+                p = lf + 1;
             }
-            if (col == id_i) id = Span{s, (int32_t)(e - s)};
-            if (col == ft_i) ft = Span{s, (int32_t)(e - s)};
-            col++;
-            if (!c) break;
-            s = e + 1;
+        });
+        size_t total = 0;
+        for (int q = 0; q < parts; q++) {
+            if (why[(size_t)q]) {
+                const std::string w = why[(size_t)q];
+                delete t;
+                return unsupported(w);
+            }
+            total += pid[(size_t)q].size();
         }
-        if (col != ncols) {
-            delete t;
-            return unsupported("ragged row");
+        t->ids.reserve(total);
+        t->feats.reserve(total);
+        for (int q = 0; q < parts; q++) {
+            t->ids.insert(t->ids.end(), pid[(size_t)q].begin(), pid[(size_t)q].end());
+            t->feats.insert(t->feats.end(), pft[(size_t)q].begin(), pft[(size_t)q].end());
         }
-        if (is_na(b + id.off, id.len)) {
-            delete t;
-            return unsupported("NA-valued id");
-        }
-        if (is_na(b + ft.off, ft.len)) ft.len = 0;  // NaN -> "" (fillna, :28)
-        t->ids.push_back(id);
-        t->feats.push_back(ft);
-        pos = lf + 1;
     }
     if (t->ids.empty()) {
         delete t;

@@ -268,3 +268,31 @@ def test_thread_count_never_changes_the_result(indels, monkeypatch):
             continue
         for a, b in zip(ref, got):
             assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
+def test_reader_slices_give_the_rows_of_one_pass(tmp_path, monkeypatch):
+    """the reader cuts files over 1 MiB into slices at line starts (one thread each): same rows, same order, CRLF line
+    ends and blank lines included, as the single-threaded pass"""
+    from breakfast_amd.synth import generate_profiles
+
+    rows = generate_profiles(12000)
+    inp = tmp_path / "in.tsv"
+    with open(inp, "w", newline="") as f:
+        f.write("x\taccession\tdna_profile\r\n")
+        for i, r in enumerate(rows):
+            f.write(f"{i % 7}\tseq{i:07d}\t{r}\r\n")
+            if i % 1000 == 999:
+                f.write("\r\n")
+    assert inp.stat().st_size > 3 << 20
+    outs = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("BFK_THREADS", threads)
+        t = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+        assert len(t) == len(rows)
+        info = t.prepare(" ", "covsonar_dna", True, True, 264, 228, 29903)
+        out = tmp_path / f"o{threads}.tsv"
+        t.write(out, (np.arange(int(info.n_unique)) % 5).astype(np.int32))
+        outs.append((out.read_bytes(), t.group.copy(), [t.id(0), t.id(len(rows) - 1)]))
+        t.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) and o[2] == outs[0][2] == ["seq0000000", f"seq{len(rows) - 1:07d}"]
