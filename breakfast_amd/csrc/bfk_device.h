@@ -22,6 +22,9 @@ constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-jo
 constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wave of k_join
 constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
+constexpr int PG_MAX_CLASSES = 8;       // pigeonhole path: max_dist + 1 token classes (max_dist <= 7)
+constexpr int PG_KEY_BITS = 40;         // bits of a class key that take part in the grouping (+ 3 class bits above them)
+
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 
 struct Counters {
@@ -81,11 +84,26 @@ struct Plan {
     int *labels;
     Counters *ctr;
     unsigned long long *dbg_t;
+    // pigeonhole path (max_dist >= 2, large inputs): the rows are grouped by (token class, hash of the row's tokens
+    // of that class) — rows within max_dist agree on at least one of max_dist + 1 classes — and the pair kernel scans
+    // groups instead of (k,f,g) bands.  The sorted order has pg_classes * n positions.
+    int pg, pg_classes;
+    unsigned long long *pg_keys, *pg_keys_s;  // [n][classes] records (class << 40 | key), row-major; sorted
+    int *pg_rows, *pg_rows_s;                 // the records' rows; sorted along
+    void *pg_temp;
+    size_t pg_temp_bytes;
+    uint32_t *pg_sig1;   // first-level signatures in group order
+    int4 *pg_srec;       // {row, length, second-level signature} in group order
+    int4 *pg_tiles;      // {first position, rows, end of the group, end of the group}
+    int *pg_tile_slots;
+    int pg_tile_cap;
     int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;
 };
 
+int sort_records(void *temp, size_t *temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const int *rows_in,
+                 int *rows_out, size_t n, int bits, hipStream_t st);  // bfk_sort.hip
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev);

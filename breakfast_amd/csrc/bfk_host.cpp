@@ -98,7 +98,14 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
-    int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies
+    int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 pigeonhole groups
+    // pigeonhole path (max_dist >= 2, large inputs): records, sorted records, group-order signatures, tiles
+    unsigned long long *pg_keys = nullptr, *pg_keys_s = nullptr;
+    int *pg_rows = nullptr, *pg_rows_s = nullptr, *pg_tile_slots = nullptr;
+    void *pg_temp = nullptr;
+    uint32_t *pg_sig1 = nullptr;
+    int4 *pg_srec = nullptr, *pg_tiles = nullptr;
+    int64_t pg_rec_cap = 0, pg_temp_cap = 0, pg_sig_cap = 0, pg_tile_cap = 0;
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
     int join_empty_shard = -1, join_empty_shards = 0;
@@ -166,7 +173,8 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,       c->d_start3, c->d_gkey,  c->d_srec,  c->d_sigu1,
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
-                    c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather};
+                    c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
+                    c->pg_rows_s, c->pg_tile_slots, c->pg_temp, c->pg_sig1, c->pg_srec, c->pg_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -198,7 +206,7 @@ extern "C" int bfk_ctx_set_profiling(bfk_ctx *c, int32_t enable) {
 
 extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
     if (!c) return fail(BFK_EARG, "null ctx");
-    if (mode < 0 || mode > 2) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join");
+    if (mode < 0 || mode > 3) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join, 3 pigeonhole groups");
     if (mode != c->path_mode) {  // the other path's per-step invariants (clean histogram / cleared table sets) are void
         c->need_zero = true;
         c->join_clear = true;
@@ -402,6 +410,55 @@ static int ctx_size_join(bfk_ctx *c) {
     return BFK_OK;
 }
 
+// The pigeonhole path serves max_dist 2..7 on large inputs (BFK_PG=0/1 or bfk_ctx_set_candidate_path(3) override): below
+// the threshold the sort and the extra passes over 6N records cost more than the band scan they save (measured: DESIGN 6d).
+static bool pg_wanted(const bfk_ctx *c, int max_dist) {
+    if (max_dist < 2 || max_dist + 1 > PG_MAX_CLASSES || c->n < 2 || c->nnz <= 0) return false;
+    if ((int64_t)c->n * (max_dist + 1) > (int64_t)INT32_MAX - 1024) return false;
+    if (c->path_mode) return c->path_mode == 3;
+    if (const char *e = getenv("BFK_PG")) return atoi(e) != 0;
+    // measured, ms per step band / groups: 1M rows d = 2: 1.45 / 1.88, d = 3: 4.80 / 3.67, d = 4 (indels): 14.5 / 7.0,
+    // d = 5 (indels): 24.9 / 18.3; 400k rows d = 5: 6.2 / 10.8 — the groups pay once the band scan is the bulk of a long step
+    return max_dist >= 3 && c->n >= 800000;
+}
+
+static int ctx_size_pg(bfk_ctx *c, int classes, int w1, size_t *temp_bytes) {
+    const int64_t total = c->n * classes;
+    if (total > c->pg_rec_cap) {
+        int64_t cap;
+        int rc = 0;
+        cap = 0; rc |= dev_realloc(&c->pg_keys, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_keys_s, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_rows, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_rows_s, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_srec, &cap, total + SIG_PAD_ROWS);
+        if (rc) return BFK_ENOMEM;
+        c->pg_rec_cap = total;
+    }
+    if ((total + SIG_PAD_ROWS) * w1 > c->pg_sig_cap) {
+        if (int rc = dev_realloc(&c->pg_sig1, &c->pg_sig_cap, (total + SIG_PAD_ROWS) * w1)) return rc;
+        HIP_TRY(hipMemsetAsync(c->pg_sig1, 0xFF, (size_t)c->pg_sig_cap * 4, c->stream));  // padding is read, never trusted
+    }
+    const int64_t tiles = total / 64 + 16;  // one per 64 positions of the group order
+    if (tiles > c->pg_tile_cap) {
+        int64_t cap = 0;
+        if (int rc = dev_realloc(&c->pg_tiles, &c->pg_tile_cap, tiles)) return rc;
+        if (int rc = dev_realloc(&c->pg_tile_slots, &cap, c->pg_tile_cap * PF_WAVES_MAX)) return rc;
+    }
+    size_t tb = 0;
+    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, PG_KEY_BITS + 3, c->stream))
+        return fail(BFK_EHIP, std::string("radix sort set-up: ") + hipGetErrorString((hipError_t)e));
+    if ((int64_t)tb > c->pg_temp_cap) {
+        if (c->pg_temp) (void)hipFree(c->pg_temp);
+        c->pg_temp = nullptr;
+        c->pg_temp_cap = 0;
+        if (hipMalloc(&c->pg_temp, tb + 256) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc(sort workspace) failed");
+        c->pg_temp_cap = (int64_t)tb + 256;
+    }
+    *temp_bytes = tb;
+    return BFK_OK;
+}
+
 static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out, bool allow_join);
 
 extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out) {
@@ -537,6 +594,26 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.mask = (uint32_t)(c->join_slots - 1);
         pl.ja.bmask = (uint32_t)(c->join_bits - 1);
         pl.ja.dbg = getenv("BFK_JOIN_DEBUG") ? atoi(getenv("BFK_JOIN_DEBUG")) : 0;
+    }
+    pl.pg = 0;
+    if (!pl.join && pg_wanted(c, max_dist)) {
+        size_t tb = 0;
+        if (int rc = ctx_size_pg(c, max_dist + 1, pl.w1, &tb)) return rc;
+        pl.pg = 1;
+        pl.pg_classes = max_dist + 1;
+        pl.pg_keys = c->pg_keys;
+        pl.pg_keys_s = c->pg_keys_s;
+        pl.pg_rows = c->pg_rows;
+        pl.pg_rows_s = c->pg_rows_s;
+        pl.pg_temp = c->pg_temp;
+        pl.pg_temp_bytes = tb;
+        pl.pg_sig1 = c->pg_sig1;
+        pl.pg_srec = c->pg_srec;
+        pl.pg_tiles = c->pg_tiles;
+        pl.pg_tile_slots = c->pg_tile_slots;
+        pl.pg_tile_cap = (int)std::min<int64_t>(c->pg_tile_cap, INT32_MAX);
+        pl.pf_waves = 2;
+        pl.tile_hint = (int)std::min<int64_t>(pl.pg_tile_cap, (c->n * (max_dist + 1) + 63) / 64);
     }
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
@@ -740,7 +817,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         }
         {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
             std::vector<int> ts((size_t)h.n_work * c->plan.pf_waves);
-            if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
+            if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->plan.pg ? c->pg_tile_slots : c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
             int64_t acc = 0;
             for (size_t t = 0; t < ts.size(); t++) acc += ts[t];  // tiles of other ranks' cells hold 0
             s.pairs_filtered = c->plan.join ? (c->nnz + n) / c->last_shards : acc;  // join: table lookups

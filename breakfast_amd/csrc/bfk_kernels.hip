@@ -521,6 +521,10 @@ struct PairArgs {
     int use_link;  // k_verify hooks its edges with 0 uf_union (find + hook), 1 uf_link (splicing), 2 first hops, then splicing
     int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
     int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
+    // pigeonhole path: a pair found in the group of class c is dropped when the rows also share a class below c (it is
+    // found there); position p of the group order belongs to class p / pg_rows
+    const unsigned long long *pg_keys;  // [rows][classes], NULL on the band path
+    int pg_classes, pg_rows;
     Counters *ctr;
 };
 
@@ -541,7 +545,13 @@ __device__ __forceinline__ void flush_pairs(const PairArgs &a, const int2 *sbuf,
                 ra = rp.x;
                 rb = rq.x;
                 const int c = __popc((uint32_t)(rp.z ^ rq.z)) + __popc((uint32_t)(rp.w ^ rq.w));
-                pass = (rq.y - rp.y <= a.d) && (c <= a.d);
+                pass = (abs(rq.y - rp.y) <= a.d) && (c <= a.d);
+                if (pass && a.pg_keys) {  // group order: not sorted by length; the pair counts in the lowest class the rows share
+                    const int cls = p / a.pg_rows;
+                    const unsigned long long *ka = a.pg_keys + (size_t)ra * a.pg_classes, *kb = a.pg_keys + (size_t)rb * a.pg_classes;
+                    pass = pass && q / a.pg_rows == cls && ka[cls] == kb[cls];  // rows of other groups (or classes) can meet in a tile
+                    for (int c2 = 0; c2 < cls; c2++) pass = pass && ka[c2] != kb[c2];
+                }
             }
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
@@ -662,7 +672,7 @@ struct BandArgs {
 // round), s_setprio for waves with long scans (no effect), issuing the tiles of big cells several times with
 // the columns divided (helps at 100k, costs 40% at 1M rows).
 // ------------------------------------------------------------------------------------------------
-template <int W, int R, int PW, bool DBG>
+template <int W, int R, int PW, bool DBG, bool PG = false>
 __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
                                                               int shard0, int nshards, int t_begin, int t_end,
                                                               PairArgs pa) {
@@ -703,6 +713,11 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         continue;
     }
     const int row0 = tile.x, nrows = tile.y;
+    if (PG && nrows == 0) {  // a tile with nothing of its groups behind its start
+        if (lane == 0) ba.tile_slots[t * PW + wslot] = 0;
+        item += (int)gridDim.x * PW;
+        continue;
+    }
     const int fb = ba.key.fb, gb = ba.key.gb, hb = ba.key.hb;
     // fb, gb, hb are powers of two
     const int h0 = tile.z & (hb - 1), g0 = (tile.z >> ba.key.hb_log) & (gb - 1);
@@ -720,13 +735,20 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     // 64 lanes is used: mode 3 = one range per (delta, f', g') with the h band contiguous inside (needs the
     // third key and (d+1)^3 <= 64), mode 2 = one per (delta, f') covering the g band and every h,
     // mode 1 = one per column length.
+    // (PG, the pigeonhole path: the tile is a piece of one GROUP of the (class, key) order and its one column range is
+    // the rest of that group, tile.z = the group's end)
     const int D = (int)d, D1 = D + 1;
-    const int mode = (hb > 1 && D1 * D1 * D1 <= 64) ? 3 : (D1 * D1 <= 64 ? 2 : 1);
-    const int ncand = mode == 3 ? D1 * D1 * D1 : (mode == 2 ? D1 * D1 : D1);
+    const int mode = PG ? 0 : ((hb > 1 && D1 * D1 * D1 <= 64) ? 3 : (D1 * D1 <= 64 ? 2 : 1));
+    const int ncand = PG ? 1 : (mode == 3 ? D1 * D1 * D1 : (mode == 2 ? D1 * D1 : D1));
     for (int cbase = 0; cbase < ncand; cbase += 64) {  // more than 64 candidates only when d >= 64
         const int c = cbase + lane;
         int my_cb = 0, my_ce = 0;
-        if (c < ncand) {
+        if (PG) {
+            if (c == 0) {
+                my_cb = row0;
+                my_ce = tile.z;
+            }
+        } else if (c < ncand) {
             // c -> (delta, fi, gi) without divisions: 16-bit reciprocals of D1 and D1^2 (c < 64)
             int delta = c, fi = 0, gi = 0;
             if (mode == 3) {
@@ -1708,6 +1730,103 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 }
 
 // ------------------------------------------------------------------------------------------------
+// The pigeonhole path (max_dist >= 2, large inputs): candidates from GROUPS instead of (k,f,g) bands.
+//   The tokens are dealt into C = max_dist + 1 classes by a hash of the token id.  Two rows within max_dist differ in at
+//   most max_dist token occurrences, hence in at most max_dist classes: in at least one class their sub-multisets
+//   are EQUAL, and so is any hash of them.  k_pgkeys leaves C records (class << 40 | additive multiset hash of the
+//   row's tokens of that class : row) per row; a device radix sort (rocPRIM) orders them; k_pgplace lays the rows'
+//   signatures out in that order and cuts every group (run of equal records) of two or more rows into tiles of at
+//   most 64 positions; k_prefilter<.., PG> scans, per tile, the rest of the tile's group with the same signature
+//   compare, hit queue and second level as on the band path; a pair that shares several classes is kept in the
+//   lowest one (flush_pairs).  Exact for the same reason as the band path: grouping is a necessary condition (a hash
+//   collision or the 40-bit truncation only merges groups), the verify is exact.
+//   On tree-like data the groups hold 8-11x fewer pairs than the reference's length band at max_dist 5 (measured on
+//   the configs[4] generator at 100k / 300k rows) — an early ancestor's tokens of one class are shared by every
+//   descendant that never mutated in that class, so the groups are not small, only far smaller than the band.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int nnz,
+                                                int classes, unsigned long long *__restrict__ keys, int *__restrict__ rows,
+                                                Counters *ctr) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) ctr->n_work = 0;  // the tile count of k_cells: k_pgplace counts its own tiles here
+    if (r >= n) return;
+    const int b = indptr[r], e = indptr[r + 1];
+    unsigned long long acc[PG_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < PG_MAX_CLASSES; c++) acc[c] = 0ull;
+    for (int j = b; j < e; j++) {  // (one lane per row: rows are short, the CSR is L2-resident)
+        const uint32_t hs = jh_stage(indices[j]);
+        const unsigned long long h = ((unsigned long long)jh2_of(hs) << 32) | (unsigned long long)jh1_of(hs);
+        const int cls = (int)((((hs >> 4) & 0xFFFFu) * (uint32_t)classes) >> 16);
+#pragma unroll
+        for (int c = 0; c < PG_MAX_CLASSES; c++) acc[c] += c == cls ? h : 0ull;
+    }
+    const unsigned long long kmask = (1ull << PG_KEY_BITS) - 1ull;
+#pragma unroll
+    for (int c = 0; c < PG_MAX_CLASSES; c++)
+        if (c < classes) {
+            keys[(size_t)r * classes + c] = ((unsigned long long)c << PG_KEY_BITS) | ((acc[c] ^ (acc[c] >> PG_KEY_BITS)) & kmask);
+            rows[(size_t)r * classes + c] = r;
+        }
+}
+
+// one thread per position of the sorted records: the signatures of the position's row in group order, and ONE tile per
+// 64 aligned positions (a wave): its rows are those positions, its columns everything from the tile's start to the end
+// of the last group that begins (or continues) in it — groups are runs, so that end covers every row of the tile.  Rows
+// of different groups that meet in a tile are compared too; flush_pairs drops what does not share the class's key.
+// (One tile per group piece instead — up to 32 per 64 positions where the groups are pairs — made the pair kernel 7x
+// slower per pair slot at 1M rows, max_dist 5: 642k tiles, most of them two or three rows.)
+template <int W>
+__global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__restrict__ keys_s, const int *__restrict__ rows_s,
+                                                 int total, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu1,
+                                                 const uint32_t *__restrict__ sigu2, uint32_t *__restrict__ sig1,
+                                                 int4 *__restrict__ srec, int4 *__restrict__ tiles, int tile_cap, Counters *ctr) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long key = 0ull;
+    bool head = false;
+    if (p < total) {
+        key = keys_s[p];
+        const int row = rows_s[p];
+#pragma unroll
+        for (int x = 0; x < W; x++) sig1[(size_t)p * W + x] = sigu1[(size_t)row * W + x];
+        srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
+        head = lane == 0 || keys_s[p - 1] != key;
+    }
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
+    if (hm == 0ull) return;  // (a wave past the end)
+    const int last = 63 - (int)__builtin_clzll(hm);  // the last group that begins in this tile ends last
+    int gend = 0;
+    if (lane == last) {
+        // end of that group: first position behind p with another key (the records are sorted)
+        int lo = p + 1, hi = total;
+        if (lo < total && keys_s[lo] == key) {
+            int step = 64;  // gallop, then bisect: most groups are short
+            while (lo + step < total && keys_s[lo + step] == key) {
+                lo += step;
+                step <<= 1;
+            }
+            hi = min(total, lo + step);
+            while (hi - lo > 1) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (keys_s[mid] == key) lo = mid;
+                else hi = mid;
+            }
+            gend = hi;
+        } else {
+            gend = lo;
+        }
+    }
+    gend = __shfl(gend, last);
+    if (lane == 0) {
+        const int t = p >> 6;
+        if (t < tile_cap) tiles[t] = make_int4(p, gend - p >= 2 ? min(64, total - p) : 0, gend, t);  // nothing behind its start: no pairs
+        else atomicOr(&ctr->err, ERR_WORKCAP);
+        if (p + 64 >= total) ctr->n_work = (unsigned)min(t + 1, tile_cap);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
 // k_compress: parent[i] = root(i) in place, between the two phases of a two-phase verify (only roots are written:
@@ -1809,6 +1928,8 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.part_lo = 0;
     pa.part_hi = pa.part_den = 1;
     pa.stats_off = 0;
+    pa.pg_keys = nullptr;
+    pa.pg_classes = pa.pg_rows = 1;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
     // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
     // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
@@ -1878,10 +1999,17 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev) {
     const int n = pl.n;
     PairArgs pa = make_pair_args(pl);
+    if (pl.pg) {
+        pa.srec = pl.pg_srec;
+        pa.n = pl.n * pl.pg_classes;  // positions of the group order
+        pa.pg_keys = pl.pg_keys;
+        pa.pg_classes = pl.pg_classes;
+        pa.pg_rows = pl.n;
+    }
     BandArgs ba;
     ba.start3 = pl.start3;
-    ba.tiles = pl.tiles;
-    ba.tile_slots = pl.tile_slots;
+    ba.tiles = pl.pg ? pl.pg_tiles : pl.tiles;
+    ba.tile_slots = pl.pg ? pl.pg_tile_slots : pl.tile_slots;
     ba.dbg_t = (pl.dbg & 4) ? pl.dbg_t : nullptr;
     ba.key.fb = pl.fb;
     ba.key.gb = pl.gb;
@@ -1898,9 +2026,21 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.d = pl.d;
     // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
     // previous step's count (tile_hint) and the kernel strides over whatever the count turns out to be
-    const long long span = (long long)std::min(std::min(t_end, pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
+    const long long span = (long long)std::min(std::min(t_end, pl.pg ? pl.pg_tile_cap : pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
     const int grid = std::max(1, (int)std::min<long long>(span, pl.pf_blocks));  // every rank walks all tiles, skips foreign cells
 
+    if (pl.pg) {  // pigeonhole path: groups of the (class, key) order; 64-row tiles, two waves per tile
+#define PG_CASE(W)                                                                                                     \
+    hipLaunchKernelGGL((k_prefilter<W, 1, 2, false, true>), dim3(grid), dim3(128), 0, st, pl.pg_sig1, ba, pl.n * pl.pg_classes, \
+                       pl.shard, pl.n_shards, t_begin, t_end, pa)
+        if (pl.w1 == 1) { PG_CASE(1); }
+        else if (pl.w1 == 2) { PG_CASE(2); }
+        else { PG_CASE(4); }
+#undef PG_CASE
+        LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[2], st);
+        return launch_verify(pl, pa, st, ev);
+    }
 // the instrumented instantiations (BFK_PF_DEBUG: per-wave stamps, phase switches) double the code of the pair
 // kernel: they are compiled only with `make PF_DEBUG=1`
 #ifdef BFK_WITH_PF_DEBUG
@@ -2019,6 +2159,26 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
             return -1;
     }
     LAUNCH_CHECK();
+    if (pl.pg) {  // pigeonhole path: records, sort, group order + tiles (the prep above supplied the signatures)
+        const int total = n * pl.pg_classes;
+        hipLaunchKernelGGL(k_pgkeys, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.pg_classes, pl.pg_keys,
+                           pl.pg_rows, pl.ctr);
+        LAUNCH_CHECK();
+        size_t tb = pl.pg_temp_bytes;
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, PG_KEY_BITS + 3, st))
+            return e;
+        const dim3 g((total + 255) / 256), b(256);
+        if (pl.w1 == 1)
+            hipLaunchKernelGGL(k_pgplace<1>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
+        else if (pl.w1 == 2)
+            hipLaunchKernelGGL(k_pgplace<2>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
+        else
+            hipLaunchKernelGGL(k_pgplace<4>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
+        LAUNCH_CHECK();
+    }
     if (ev) (void)hipEventRecord(ev[1], st);
     if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
     return launch_flatten(pl, st, ev);

@@ -783,3 +783,40 @@ def test_allreduce_min_merge_reaches_the_fix_point():
     assert rounds >= 2  # at least one confirming round
     for l in cur:
         assert np.array_equal(l, want)
+
+
+# ---- pigeonhole groups (max-dist >= 2 on large inputs) against the band kernels and the oracle ------------------------
+@pytest.mark.parametrize("n,d,indels", [(3000, 2, False), (20000, 3, True), (20000, 5, True), (60000, 4, True), (777, 7, True)])
+def test_pigeonhole_groups_equal_the_band_path(n, d, indels):
+    """bfk_ctx_set_candidate_path(3): candidates from (token class, class-key) groups instead of (k,f,g) bands — same
+    labels, same number of edges (every pair counted once, in the lowest class its rows share), same neighbour lists"""
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    uf = list(dict.fromkeys(generate_profiles(n, **kw)))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    nu = len(uf)
+    want, st_band = _lib.cluster_csr(indptr, indices, d)
+    assert st_band["n_work_items"] > 0
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("pigeonhole")
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * nu)
+    for _ in range(2):  # (a dense first run may grow the candidate queue: the second is a single pass)
+        ctx.cluster(d, d_out)
+        st = ctx.sync()
+    assert np.array_equal(ctx.download_i32(d_out, nu), want)
+    assert st["n_edges"] == st_band["n_edges"] and st["n_retry_slices"] == 0
+    assert st["n_work_items"] == (nu * (d + 1) + 63) // 64  # one tile per 64 positions of the group order
+    ctx.close()
+    if n <= 3000:
+        assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_pigeonhole_groups_on_random_multisets(seed, monkeypatch):
+    """shuffled rows, repeated tokens, empty rows, rows shorter than the number of classes"""
+    monkeypatch.setenv("BFK_PG", "1")
+    for d in (2, 3, 6):
+        indptr, indices = _random_multisets(900, 100 * seed + d, alphabet=60, kmax=3 * d)
+        want = orc.cluster_csr(indptr, indices, d, n_threads=8)
+        got, st = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want["labels"]), (seed, d)
