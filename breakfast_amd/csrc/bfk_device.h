@@ -89,7 +89,6 @@ struct Plan {
     // groups instead of (k,f,g) bands.  The sorted order has pg_classes * n positions.
     int pg, pg_classes;
     unsigned long long *pg_keys, *pg_keys_s;  // [n][classes] records (class << 40 | key), row-major; sorted
-    unsigned long long *pg_poskeys;           // the rows' records again, per position of the group order: [positions][classes]
     int *pg_rows, *pg_rows_s;                 // the records' rows; sorted along
     void *pg_temp;
     size_t pg_temp_bytes;

@@ -100,8 +100,7 @@ struct bfk_ctx {
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
     int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 pigeonhole groups
     // pigeonhole path (max_dist >= 2, large inputs): records, sorted records, group-order signatures, tiles
-    unsigned long long *pg_keys = nullptr, *pg_keys_s = nullptr, *pg_poskeys = nullptr;
-    int64_t pg_poskeys_cap = 0;
+    unsigned long long *pg_keys = nullptr, *pg_keys_s = nullptr;
     int *pg_rows = nullptr, *pg_rows_s = nullptr, *pg_tile_slots = nullptr;
     void *pg_temp = nullptr;
     uint32_t *pg_sig1 = nullptr;
@@ -175,7 +174,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_tile_slots, c->pg_temp, c->pg_sig1, c->pg_srec, c->pg_tiles, c->pg_poskeys};
+                    c->pg_rows_s, c->pg_tile_slots, c->pg_temp, c->pg_sig1, c->pg_srec, c->pg_tiles};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -436,7 +435,6 @@ static int ctx_size_pg(bfk_ctx *c, int classes, int w1, size_t *temp_bytes) {
         if (rc) return BFK_ENOMEM;
         c->pg_rec_cap = total;
     }
-    if (int rc = dev_realloc(&c->pg_poskeys, &c->pg_poskeys_cap, (total + SIG_PAD_ROWS) * classes)) return rc;
     if ((total + SIG_PAD_ROWS) * w1 > c->pg_sig_cap) {
         if (int rc = dev_realloc(&c->pg_sig1, &c->pg_sig_cap, (total + SIG_PAD_ROWS) * w1)) return rc;
         HIP_TRY(hipMemsetAsync(c->pg_sig1, 0xFF, (size_t)c->pg_sig_cap * 4, c->stream));  // padding is read, never trusted
@@ -605,7 +603,6 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.pg_classes = max_dist + 1;
         pl.pg_keys = c->pg_keys;
         pl.pg_keys_s = c->pg_keys_s;
-        pl.pg_poskeys = c->pg_poskeys;
         pl.pg_rows = c->pg_rows;
         pl.pg_rows_s = c->pg_rows_s;
         pl.pg_temp = c->pg_temp;

@@ -524,7 +524,6 @@ struct PairArgs {
     // pigeonhole path: a pair found in the group of class c is dropped when the rows also share a class below c (it is
     // found there); position p of the group order belongs to class p / pg_rows
     const unsigned long long *pg_keys;  // [rows][classes], NULL on the band path
-    const unsigned long long *pg_poskeys;  // the same records per POSITION of the group order: [positions][classes]
     int pg_classes, pg_rows;
     Counters *ctr;
 };
@@ -547,7 +546,7 @@ __device__ __forceinline__ void flush_pairs(const PairArgs &a, const int2 *sbuf,
                 rb = rq.x;
                 const int c = __popc((uint32_t)(rp.z ^ rq.z)) + __popc((uint32_t)(rp.w ^ rq.w));
                 pass = (abs(rq.y - rp.y) <= a.d) && (c <= a.d);
-                if (pass && a.pg_keys && !a.pg_poskeys) {  // (flush_hits has done this already when the per-position keys exist)
+                if (pass && a.pg_keys) {  // group order: not sorted by length; the pair counts in the lowest class the rows share
                     const int cls = p / a.pg_rows;
                     const unsigned long long *ka = a.pg_keys + (size_t)ra * a.pg_classes, *kb = a.pg_keys + (size_t)rb * a.pg_classes;
                     pass = pass && q / a.pg_rows == cls && ka[cls] == kb[cls];  // rows of other groups (or classes) can meet in a tile
@@ -594,7 +593,7 @@ __device__ __forceinline__ uint32_t sigdist(const uint32_t (&a)[W], const uint32
 // lane (64 entries per instruction), instead of in the scan loop where a hit costs the whole wave a serial
 // rescan: the 16 row dwords and the column signature are re-read from L2, the exact (row, column) pairs are
 // compacted into `pairs` (LDS, PF_PAIR_LIST entries per round) with a wave prefix sum, and flush_pairs does the rest.
-template <int W, bool PG = false>
+template <int W>
 __device__ __forceinline__ void flush_hits(const PairArgs &a, const uint32_t *__restrict__ sig1, const int2 *coarse, int cnt,
                                            int row_end, int2 *pairs, int shard) {
     constexpr int SB = 16 / W;
@@ -617,23 +616,6 @@ __device__ __forceinline__ void flush_hits(const PairArgs &a, const uint32_t *__
 #pragma unroll
             for (int j = 0; j < SB; j++)
                 if (pb + j < row_end && sigdist<W>(cq, &rw[j * W]) <= d) mask |= 1u << j;
-            if (PG && mask) {
-                // pigeonhole path: a pair counts in the LOWEST class its rows share, and only inside one group of that class
-                // (rows of other groups or of the next class can meet in a tile).  Decided here, on the per-position class keys,
-                // before the pair costs its row records, extents and a queue slot: a true candidate is hit in every class its rows
-                // share (3-5 of 6 at max-dist 5) and all but one of those hits end here.
-                const int C = a.pg_classes;
-                const unsigned long long *kq = a.pg_poskeys + (size_t)q * C;
-                const int clsq = q / a.pg_rows;
-                for (uint32_t mm = mask; mm; mm &= mm - 1) {
-                    const int j = __ffs((int)mm) - 1;
-                    const int p = pb + j;
-                    const unsigned long long *kp = a.pg_poskeys + (size_t)p * C;
-                    bool keep = p / a.pg_rows == clsq && kp[clsq] == kq[clsq];
-                    for (int c2 = 0; keep && c2 < clsq; c2++) keep = kp[c2] != kq[c2];
-                    if (!keep) mask &= ~(1u << j);
-                }
-            }
         }
         const int mine = __popc(mask);
         const int incl = wave_incl_scan_add(mine);
@@ -877,7 +859,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        flush_hits<W, PG>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);
+                        flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);
                         // drain: with an unknown number of stores in flight the compiler would wait for ALL loads
                         // (vmcnt(0)) at every sub-batch, i.e. for the chunk requested a moment ago; after a full
                         // drain it can count again
@@ -904,7 +886,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (DBG) t_main = wall_clock64();
-    if (qn > 0 && !(DBG && (pa.dbg & 1))) flush_hits<W, PG>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
+    if (qn > 0 && !(DBG && (pa.dbg & 1))) flush_hits<W>(pa, sig1, myq, qn, row0 + nrows, spairs[wave], qshard);  // one flush per wave
     if (DBG && ba.dbg_t && lane == 0) {
         unsigned long long *o = ba.dbg_t + (size_t)(t * PW + wslot) * 8;
         o[0] = t_start;
@@ -1798,9 +1780,7 @@ template <int W>
 __global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__restrict__ keys_s, const int *__restrict__ rows_s,
                                                  int total, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu1,
                                                  const uint32_t *__restrict__ sigu2, uint32_t *__restrict__ sig1,
-                                                 int4 *__restrict__ srec, int4 *__restrict__ tiles, int tile_cap, Counters *ctr,
-                                                 const unsigned long long *__restrict__ keys, unsigned long long *__restrict__ poskeys,
-                                                 int classes) {
+                                                 int4 *__restrict__ srec, int4 *__restrict__ tiles, int tile_cap, Counters *ctr) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     unsigned long long key = 0ull;
@@ -1808,7 +1788,6 @@ __global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__res
     if (p < total) {
         key = keys_s[p];
         const int row = rows_s[p];
-        for (int c = 0; c < classes; c++) poskeys[(size_t)p * classes + c] = keys[(size_t)row * classes + c];
 #pragma unroll
         for (int x = 0; x < W; x++) sig1[(size_t)p * W + x] = sigu1[(size_t)row * W + x];
         srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
@@ -1950,7 +1929,6 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.part_hi = pa.part_den = 1;
     pa.stats_off = 0;
     pa.pg_keys = nullptr;
-    pa.pg_poskeys = nullptr;
     pa.pg_classes = pa.pg_rows = 1;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
     // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
@@ -2025,7 +2003,6 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         pa.srec = pl.pg_srec;
         pa.n = pl.n * pl.pg_classes;  // positions of the group order
         pa.pg_keys = pl.pg_keys;
-        pa.pg_poskeys = pl.pg_poskeys;
         pa.pg_classes = pl.pg_classes;
         pa.pg_rows = pl.n;
     }
@@ -2193,13 +2170,13 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         const dim3 g((total + 255) / 256), b(256);
         if (pl.w1 == 1)
             hipLaunchKernelGGL(k_pgplace<1>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr, pl.pg_keys, pl.pg_poskeys, pl.pg_classes);
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
         else if (pl.w1 == 2)
             hipLaunchKernelGGL(k_pgplace<2>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr, pl.pg_keys, pl.pg_poskeys, pl.pg_classes);
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
         else
             hipLaunchKernelGGL(k_pgplace<4>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr, pl.pg_keys, pl.pg_poskeys, pl.pg_classes);
+                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
         LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[1], st);
