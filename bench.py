@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="only the timed steps + roofline (no host / CLI / CPU legs)")
-    ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join", "pigeonhole"], help="candidate generator of the main leg")
+    ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join", "prefix"], help="candidate generator of the main leg")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="experiment (not the contract's default): P independent contexts on P streams take the steps "
                          "round-robin, so that the label exchange of one step overlaps the kernels of the next")

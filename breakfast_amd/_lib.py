@@ -368,7 +368,7 @@ class Context:
         _check(self.lib.bfk_ctx_set_profiling(self.h, 1 if on else 0))
 
     def set_candidate_path(self, mode: str = "auto"):
-        _check(self.lib.bfk_ctx_set_candidate_path(self.h, {"auto": 0, "allpairs": 1, "join": 2, "pigeonhole": 3}[mode]))
+        _check(self.lib.bfk_ctx_set_candidate_path(self.h, {"auto": 0, "allpairs": 1, "join": 2, "prefix": 3}[mode]))
 
     def upload_csr(self, indptr, indices):
         indptr = np.ascontiguousarray(indptr, dtype=np.int32)

@@ -22,8 +22,9 @@ constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-jo
 constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wave of k_join
 constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
-constexpr int PG_MAX_CLASSES = 8;       // pigeonhole path: max_dist + 1 token classes (max_dist <= 7)
-constexpr int PG_KEY_BITS = 40;         // bits of a class key that take part in the grouping (+ 3 class bits above them)
+constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
+constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
+constexpr int PG_SORT_BITS = 50;        // key bits of a prefix record (12 count + 31 token + 6 occurrence, + 1, sentinel bit 49)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 
@@ -84,19 +85,17 @@ struct Plan {
     int *labels;
     Counters *ctr;
     unsigned long long *dbg_t;
-    // pigeonhole path (max_dist >= 2, large inputs): the rows are grouped by (token class, hash of the row's tokens
-    // of that class) — rows within max_dist agree on at least one of max_dist + 1 classes — and the pair kernel scans
-    // groups instead of (k,f,g) bands.  The sorted order has pg_classes * n positions.
-    int pg, pg_classes;
-    unsigned long long *pg_keys, *pg_keys_s;  // [n][classes] records (class << 40 | key), row-major; sorted
-    int *pg_rows, *pg_rows_s;                 // the records' rows; sorted along
+    // prefix-group path (max_dist >= 2, large inputs): the rows are grouped by the elements of their PREFIX (the
+    // max_dist + 1 rarest tokens) — rows within max_dist share one — and the pair kernel scans groups instead of (k,f,g)
+    // bands.  The sorted order has pg_recs * n positions (pg_recs = max_dist + 2 records per row).
+    int pg, pg_recs;
+    uint32_t *pg_cnt;                         // sampled token counts (2^PG_CNT_BITS hashed counters)
+    unsigned long long *pg_keys, *pg_keys_s;  // [n][recs] records, row-major; sorted
+    int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along
     void *pg_temp;
     size_t pg_temp_bytes;
-    uint32_t *pg_sig1;   // first-level signatures in group order
     int4 *pg_srec;       // {row, length, second-level signature} in group order
-    int4 *pg_tiles;      // {first position, rows, end of the group, end of the group}
-    int *pg_tile_slots;
-    int pg_tile_cap;
+    int *pg_recpos;      // [n][recs]: position of every record in the group order
     int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;

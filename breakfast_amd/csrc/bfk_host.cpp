@@ -98,14 +98,15 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
-    int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 pigeonhole groups
-    // pigeonhole path (max_dist >= 2, large inputs): records, sorted records, group-order signatures, tiles
+    int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 prefix groups
+    // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
+    uint32_t *pg_cnt = nullptr;
+    int64_t n_short = 0;  // rows of at most 2 * PG_MAX_DIST tokens (bind time): they all meet in one group
     unsigned long long *pg_keys = nullptr, *pg_keys_s = nullptr;
-    int *pg_rows = nullptr, *pg_rows_s = nullptr, *pg_tile_slots = nullptr;
+    int *pg_rows = nullptr, *pg_rows_s = nullptr, *pg_recpos = nullptr;
     void *pg_temp = nullptr;
-    uint32_t *pg_sig1 = nullptr;
-    int4 *pg_srec = nullptr, *pg_tiles = nullptr;
-    int64_t pg_rec_cap = 0, pg_temp_cap = 0, pg_sig_cap = 0, pg_tile_cap = 0;
+    int4 *pg_srec = nullptr;
+    int64_t pg_rec_cap = 0, pg_temp_cap = 0;
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
     int join_empty_shard = -1, join_empty_shards = 0;
@@ -174,7 +175,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_tile_slots, c->pg_temp, c->pg_sig1, c->pg_srec, c->pg_tiles};
+                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -206,7 +207,7 @@ extern "C" int bfk_ctx_set_profiling(bfk_ctx *c, int32_t enable) {
 
 extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
     if (!c) return fail(BFK_EARG, "null ctx");
-    if (mode < 0 || mode > 3) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join, 3 pigeonhole groups");
+    if (mode < 0 || mode > 3) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join, 3 prefix groups");
     if (mode != c->path_mode) {  // the other path's per-step invariants (clean histogram / cleared table sets) are void
         c->need_zero = true;
         c->join_clear = true;
@@ -319,13 +320,13 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
 static int ctx_after_bind(bfk_ctx *c) {
     c->last_tiles = 0;  // another CSR: no tile count known yet
     // nnz and the longest row come back once per bind (set-up, not part of a timed step)
-    int h[2] = {0, 0};
+    int h[3] = {0, 0, 0};
     HIP_TRY(hipMemsetAsync(c->d_small, 0, 16, c->stream));
     int nnz32 = 0;
     if (c->n > 0) {
         if (int e = launch_maxlen(c->d_indptr, (int)c->n, c->d_small, c->stream))
             return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
-        HIP_TRY(hipMemcpyAsync(h, c->d_small, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h, c->d_small, 12, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&nnz32, c->d_indptr + c->n, 4, hipMemcpyDeviceToHost, c->stream));
         int first = 0;
         HIP_TRY(hipMemcpyAsync(&first, c->d_indptr, 4, hipMemcpyDeviceToHost, c->stream));
@@ -334,6 +335,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     }
     c->nnz = nnz32;
     c->kcap = h[0];
+    c->n_short = h[2];
     c->ran = false;
     c->need_zero = true;  // bins are laid out by kcap
     c->join_clear = true;
@@ -410,20 +412,27 @@ static int ctx_size_join(bfk_ctx *c) {
     return BFK_OK;
 }
 
-// The pigeonhole path serves max_dist 2..7 on large inputs (BFK_PG=0/1 or bfk_ctx_set_candidate_path(3) override): below
-// the threshold the sort and the extra passes over 6N records cost more than the band scan they save (measured: DESIGN 6d).
+// The prefix-group path serves max_dist 2..7 on large inputs (BFK_PG=0/1 or bfk_ctx_set_candidate_path(3) override): below the
+// thresholds the sort and the passes over (d + 2) N records cost more than the band scan they save (measured: DESIGN 6d).
+// Rows of at most 2 * max_dist tokens all meet in ONE group (prefix filtering says nothing about them): an input with
+// many of those stays on the band path.
+// measured, ms per step band / prefix groups: 1M rows d = 2: 1.45 / 3.4, d = 3: 4.8 / 5.1, d = 4: 14.5 / 6.7, d = 5: 24.9 / 10.5;
+// 400k rows d = 5: 6.2 / 5.2; 100k rows d = 3: 0.48 / 1.02, d = 5: 2.19 / 1.78 — the records, their sort and the row-by-row
+// walk are ~0.5 ms at 100k rows and ~2 ms at 1M whatever max_dist is, the band scan they replace grows steeply with it
+static int64_t PG_MIN_ROWS(int max_dist) { return max_dist >= 4 ? 100000 : ((int64_t)1 << 40); }
+
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {
-    if (max_dist < 2 || max_dist + 1 > PG_MAX_CLASSES || c->n < 2 || c->nnz <= 0) return false;
-    if ((int64_t)c->n * (max_dist + 1) > (int64_t)INT32_MAX - 1024) return false;
+    if (max_dist < 2 || max_dist > PG_MAX_DIST || c->n < 2 || c->nnz <= 0) return false;
+    if ((int64_t)c->n * (max_dist + 2) > (int64_t)INT32_MAX - 1024) return false;
     if (c->path_mode) return c->path_mode == 3;
     if (const char *e = getenv("BFK_PG")) return atoi(e) != 0;
-    // measured, ms per step band / groups: 1M rows d = 2: 1.45 / 1.88, d = 3: 4.80 / 3.67, d = 4 (indels): 14.5 / 7.0,
-    // d = 5 (indels): 24.9 / 18.3; 400k rows d = 5: 6.2 / 10.8 — the groups pay once the band scan is the bulk of a long step
-    return max_dist >= 3 && c->n >= 800000;
+    if (c->n_short > 4096) return false;
+    return c->n >= PG_MIN_ROWS(max_dist);
 }
 
-static int ctx_size_pg(bfk_ctx *c, int classes, int w1, size_t *temp_bytes) {
-    const int64_t total = c->n * classes;
+static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
+    const int64_t total = c->n * recs;
+    if (!c->pg_cnt && hipMalloc((void **)&c->pg_cnt, sizeof(uint32_t) << PG_CNT_BITS) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc(token counts) failed");
     if (total > c->pg_rec_cap) {
         int64_t cap;
         int rc = 0;
@@ -432,21 +441,12 @@ static int ctx_size_pg(bfk_ctx *c, int classes, int w1, size_t *temp_bytes) {
         cap = 0; rc |= dev_realloc(&c->pg_rows, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_rows_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_srec, &cap, total + SIG_PAD_ROWS);
+        cap = 0; rc |= dev_realloc(&c->pg_recpos, &cap, total);
         if (rc) return BFK_ENOMEM;
         c->pg_rec_cap = total;
     }
-    if ((total + SIG_PAD_ROWS) * w1 > c->pg_sig_cap) {
-        if (int rc = dev_realloc(&c->pg_sig1, &c->pg_sig_cap, (total + SIG_PAD_ROWS) * w1)) return rc;
-        HIP_TRY(hipMemsetAsync(c->pg_sig1, 0xFF, (size_t)c->pg_sig_cap * 4, c->stream));  // padding is read, never trusted
-    }
-    const int64_t tiles = total / 64 + 16;  // one per 64 positions of the group order
-    if (tiles > c->pg_tile_cap) {
-        int64_t cap = 0;
-        if (int rc = dev_realloc(&c->pg_tiles, &c->pg_tile_cap, tiles)) return rc;
-        if (int rc = dev_realloc(&c->pg_tile_slots, &cap, c->pg_tile_cap * PF_WAVES_MAX)) return rc;
-    }
     size_t tb = 0;
-    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, PG_KEY_BITS + 3, c->stream))
+    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, PG_SORT_BITS, c->stream))
         return fail(BFK_EHIP, std::string("radix sort set-up: ") + hipGetErrorString((hipError_t)e));
     if ((int64_t)tb > c->pg_temp_cap) {
         if (c->pg_temp) (void)hipFree(c->pg_temp);
@@ -598,22 +598,18 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     pl.pg = 0;
     if (!pl.join && pg_wanted(c, max_dist)) {
         size_t tb = 0;
-        if (int rc = ctx_size_pg(c, max_dist + 1, pl.w1, &tb)) return rc;
+        if (int rc = ctx_size_pg(c, max_dist + 2, &tb)) return rc;
         pl.pg = 1;
-        pl.pg_classes = max_dist + 1;
+        pl.pg_recs = max_dist + 2;
+        pl.pg_cnt = c->pg_cnt;
         pl.pg_keys = c->pg_keys;
         pl.pg_keys_s = c->pg_keys_s;
         pl.pg_rows = c->pg_rows;
         pl.pg_rows_s = c->pg_rows_s;
         pl.pg_temp = c->pg_temp;
         pl.pg_temp_bytes = tb;
-        pl.pg_sig1 = c->pg_sig1;
         pl.pg_srec = c->pg_srec;
-        pl.pg_tiles = c->pg_tiles;
-        pl.pg_tile_slots = c->pg_tile_slots;
-        pl.pg_tile_cap = (int)std::min<int64_t>(c->pg_tile_cap, INT32_MAX);
-        pl.pf_waves = 2;
-        pl.tile_hint = (int)std::min<int64_t>(pl.pg_tile_cap, (c->n * (max_dist + 1) + 63) / 64);
+        pl.pg_recpos = c->pg_recpos;
     }
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
@@ -816,9 +812,9 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             s.pairs_in_band = (int64_t)acc;
         }
         {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
-            std::vector<int> ts((size_t)h.n_work * c->plan.pf_waves);
-            if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->plan.pg ? c->pg_tile_slots : c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
-            int64_t acc = 0;
+            std::vector<int> ts(c->plan.pg ? (size_t)0 : (size_t)h.n_work * c->plan.pf_waves);
+            if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
+            int64_t acc = c->plan.pg ? (int64_t)h.pairs_filtered : 0;  // prefix groups: members of the rows' groups visited
             for (size_t t = 0; t < ts.size(); t++) acc += ts[t];  // tiles of other ranks' cells hold 0
             s.pairs_filtered = c->plan.join ? (c->nnz + n) / c->last_shards : acc;  // join: table lookups
         }

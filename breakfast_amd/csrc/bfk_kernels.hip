@@ -138,7 +138,7 @@ __device__ __forceinline__ uint32_t hash3(uint32_t x) {
 // ------------------------------------------------------------------------------------------------
 // k_maxlen: validate indptr, find the longest row (bind time only)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err*/) {
+__global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens*/) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int k = 0;
     if (i < n) {
@@ -147,6 +147,8 @@ __global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=m
             atomicOr(out + 1, 1);
             k = 0;
         }
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(k <= 2 * PG_MAX_DIST);
+        if (sm != 0ull && (threadIdx.x & 63) == (int)__builtin_ctzll(sm)) atomicAdd(out + 2, (int)__popcll(sm));
     }
     for (int s = 32; s > 0; s >>= 1) k = max(k, __shfl_xor(k, s));
     if ((threadIdx.x & 63) == 0 && k > 0) atomicMax(out, k);
@@ -521,10 +523,6 @@ struct PairArgs {
     int use_link;  // k_verify hooks its edges with 0 uf_union (find + hook), 1 uf_link (splicing), 2 first hops, then splicing
     int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
     int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
-    // pigeonhole path: a pair found in the group of class c is dropped when the rows also share a class below c (it is
-    // found there); position p of the group order belongs to class p / pg_rows
-    const unsigned long long *pg_keys;  // [rows][classes], NULL on the band path
-    int pg_classes, pg_rows;
     Counters *ctr;
 };
 
@@ -545,13 +543,7 @@ __device__ __forceinline__ void flush_pairs(const PairArgs &a, const int2 *sbuf,
                 ra = rp.x;
                 rb = rq.x;
                 const int c = __popc((uint32_t)(rp.z ^ rq.z)) + __popc((uint32_t)(rp.w ^ rq.w));
-                pass = (abs(rq.y - rp.y) <= a.d) && (c <= a.d);
-                if (pass && a.pg_keys) {  // group order: not sorted by length; the pair counts in the lowest class the rows share
-                    const int cls = p / a.pg_rows;
-                    const unsigned long long *ka = a.pg_keys + (size_t)ra * a.pg_classes, *kb = a.pg_keys + (size_t)rb * a.pg_classes;
-                    pass = pass && q / a.pg_rows == cls && ka[cls] == kb[cls];  // rows of other groups (or classes) can meet in a tile
-                    for (int c2 = 0; c2 < cls; c2++) pass = pass && ka[c2] != kb[c2];
-                }
+                pass = (rq.y - rp.y <= a.d) && (c <= a.d);
             }
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
@@ -672,7 +664,7 @@ struct BandArgs {
 // round), s_setprio for waves with long scans (no effect), issuing the tiles of big cells several times with
 // the columns divided (helps at 100k, costs 40% at 1M rows).
 // ------------------------------------------------------------------------------------------------
-template <int W, int R, int PW, bool DBG, bool PG = false>
+template <int W, int R, int PW, bool DBG>
 __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restrict__ sig1, BandArgs ba, int n,
                                                               int shard0, int nshards, int t_begin, int t_end,
                                                               PairArgs pa) {
@@ -713,11 +705,6 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
         continue;
     }
     const int row0 = tile.x, nrows = tile.y;
-    if (PG && nrows == 0) {  // a tile with nothing of its groups behind its start
-        if (lane == 0) ba.tile_slots[t * PW + wslot] = 0;
-        item += (int)gridDim.x * PW;
-        continue;
-    }
     const int fb = ba.key.fb, gb = ba.key.gb, hb = ba.key.hb;
     // fb, gb, hb are powers of two
     const int h0 = tile.z & (hb - 1), g0 = (tile.z >> ba.key.hb_log) & (gb - 1);
@@ -735,20 +722,13 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     // 64 lanes is used: mode 3 = one range per (delta, f', g') with the h band contiguous inside (needs the
     // third key and (d+1)^3 <= 64), mode 2 = one per (delta, f') covering the g band and every h,
     // mode 1 = one per column length.
-    // (PG, the pigeonhole path: the tile is a piece of one GROUP of the (class, key) order and its one column range is
-    // the rest of that group, tile.z = the group's end)
     const int D = (int)d, D1 = D + 1;
-    const int mode = PG ? 0 : ((hb > 1 && D1 * D1 * D1 <= 64) ? 3 : (D1 * D1 <= 64 ? 2 : 1));
-    const int ncand = PG ? 1 : (mode == 3 ? D1 * D1 * D1 : (mode == 2 ? D1 * D1 : D1));
+    const int mode = (hb > 1 && D1 * D1 * D1 <= 64) ? 3 : (D1 * D1 <= 64 ? 2 : 1);
+    const int ncand = mode == 3 ? D1 * D1 * D1 : (mode == 2 ? D1 * D1 : D1);
     for (int cbase = 0; cbase < ncand; cbase += 64) {  // more than 64 candidates only when d >= 64
         const int c = cbase + lane;
         int my_cb = 0, my_ce = 0;
-        if (PG) {
-            if (c == 0) {
-                my_cb = row0;
-                my_ce = tile.z;
-            }
-        } else if (c < ncand) {
+        if (c < ncand) {
             // c -> (delta, fi, gi) without divisions: 16-bit reciprocals of D1 and D1^2 (c < 64)
             int delta = c, fi = 0, gi = 0;
             if (mode == 3) {
@@ -1730,100 +1710,218 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 }
 
 // ------------------------------------------------------------------------------------------------
-// The pigeonhole path (max_dist >= 2, large inputs): candidates from GROUPS instead of (k,f,g) bands.
-//   The tokens are dealt into C = max_dist + 1 classes by a hash of the token id.  Two rows within max_dist differ in at
-//   most max_dist token occurrences, hence in at most max_dist classes: in at least one class their sub-multisets
-//   are EQUAL, and so is any hash of them.  k_pgkeys leaves C records (class << 40 | additive multiset hash of the
-//   row's tokens of that class : row) per row; a device radix sort (rocPRIM) orders them; k_pgplace lays the rows'
-//   signatures out in that order and cuts every group (run of equal records) of two or more rows into tiles of at
-//   most 64 positions; k_prefilter<.., PG> scans, per tile, the rest of the tile's group with the same signature
-//   compare, hit queue and second level as on the band path; a pair that shares several classes is kept in the
-//   lowest one (flush_pairs).  Exact for the same reason as the band path: grouping is a necessary condition (a hash
-//   collision or the 40-bit truncation only merges groups), the verify is exact.
-//   On tree-like data the groups hold 8-11x fewer pairs than the reference's length band at max_dist 5 (measured on
-//   the configs[4] generator at 100k / 300k rows) — an early ancestor's tokens of one class are shared by every
-//   descendant that never mutated in that class, so the groups are not small, only far smaller than the band.
+// The prefix-group path (max_dist >= 2, large inputs): candidates from GROUPS instead of (k,f,g) bands.
+//   Prefix filtering (the AllPairs / PPJoin idea of set-similarity joins, here for a symmetric-difference bound on
+//   multisets): fix ANY total order on the elements — an element is (token, which occurrence of it in the row) — and
+//   let the PREFIX of a row be its first max_dist + 1 elements in that order.  If two rows with at least
+//   max_dist + 1 elements share no prefix element, then the max_dist + 1 prefix elements of the row whose prefix ends
+//   first are all missing from the other row (an element of the other row that early would be in ITS prefix), so the
+//   distance exceeds max_dist.  Rows within max_dist therefore share a prefix element — unless one of them has
+//   max_dist elements or fewer; then both have at most 2*max_dist, and every such row also carries the SHORT record.
+//   The order puts rare tokens first (a sampled token count, then the higher token id: vocabulary ids are handed out by
+//   first appearance, so higher = newer = rarer), which makes the groups — rows that share a prefix element — small:
+//   on the configs[4] generator 1.4e7 pairs inside groups at 100k rows, max_dist 5 (the length band has 3.1e9,
+//   grouping by hash classes of the tokens 3.7e8), 144 per row, 178 at 300k.  The order affects only the work, never
+//   the result.
+//   k_pgfreq counts the tokens of a sample of the rows; k_pgkeys leaves max_dist + 2 records per row (prefix elements,
+//   SHORT or unique sentinels : row, slot); a device radix sort (rocPRIM) orders them; k_pgplace lays {row, length,
+//   64-bit signature} out in that order and notes where every record went; k_pgjoin walks, row by row, the groups of
+//   the row's records and queues every member that passes the second level, once (see there).  Exact: sharing a prefix
+//   element is a necessary condition, so is the signature level, the verify is exact, and every pair is queued once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int nnz,
-                                                int classes, unsigned long long *__restrict__ keys, int *__restrict__ rows,
-                                                Counters *ctr) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r == 0) ctr->n_work = 0;  // the tile count of k_cells: k_pgplace counts its own tiles here
+constexpr unsigned long long PG_SENTINEL = 1ull << 49;  // above every element key; + a unique number
+
+__device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - PG_CNT_BITS); }
+
+__global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int stride,
+                                                uint32_t *__restrict__ cnt) {
+    const int r = (blockIdx.x * 256 + threadIdx.x) * stride;
     if (r >= n) return;
-    const int b = indptr[r], e = indptr[r + 1];
-    unsigned long long acc[PG_MAX_CLASSES];
-#pragma unroll
-    for (int c = 0; c < PG_MAX_CLASSES; c++) acc[c] = 0ull;
-    for (int j = b; j < e; j++) {  // (one lane per row: rows are short, the CSR is L2-resident)
-        const uint32_t hs = jh_stage(indices[j]);
-        const unsigned long long h = ((unsigned long long)jh2_of(hs) << 32) | (unsigned long long)jh1_of(hs);
-        const int cls = (int)((((hs >> 4) & 0xFFFFu) * (uint32_t)classes) >> 16);
-#pragma unroll
-        for (int c = 0; c < PG_MAX_CLASSES; c++) acc[c] += c == cls ? h : 0ull;
-    }
-    const unsigned long long kmask = (1ull << PG_KEY_BITS) - 1ull;
-#pragma unroll
-    for (int c = 0; c < PG_MAX_CLASSES; c++)
-        if (c < classes) {
-            keys[(size_t)r * classes + c] = ((unsigned long long)c << PG_KEY_BITS) | ((acc[c] ^ (acc[c] >> PG_KEY_BITS)) & kmask);
-            rows[(size_t)r * classes + c] = r;
-        }
+    for (int j = indptr[r], e = indptr[r + 1]; j < e; j++) atomicAdd(&cnt[pg_cnt_slot(indices[j])], 1u);
 }
 
-// one thread per position of the sorted records: the signatures of the position's row in group order, and ONE tile per
-// 64 aligned positions (a wave): its rows are those positions, its columns everything from the tile's start to the end
-// of the last group that begins (or continues) in it — groups are runs, so that end covers every row of the tile.  Rows
-// of different groups that meet in a tile are compared too; flush_pairs drops what does not share the class's key.
-// (One tile per group piece instead — up to 32 per 64 positions where the groups are pairs — made the pair kernel 7x
-// slower per pair slot at 1M rows, max_dist 5: 642k tiles, most of them two or three rows.)
-template <int W>
-__global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__restrict__ keys_s, const int *__restrict__ rows_s,
-                                                 int total, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu1,
-                                                 const uint32_t *__restrict__ sigu2, uint32_t *__restrict__ sig1,
-                                                 int4 *__restrict__ srec, int4 *__restrict__ tiles, int tile_cap, Counters *ctr) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    unsigned long long key = 0ull;
-    bool head = false;
-    if (p < total) {
-        key = keys_s[p];
-        const int row = rows_s[p];
-#pragma unroll
-        for (int x = 0; x < W; x++) sig1[(size_t)p * W + x] = sigu1[(size_t)row * W + x];
-        srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
-        head = lane == 0 || keys_s[p - 1] != key;
+// one lane per row: the row's `recs - 1` first elements in the global order (kept in a sorted register list), as keys
+//   (sampled count, saturated : 0x7FFFFFFF - token : occurrence, saturated) + 1   — smaller = earlier in the order
+__global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int nnz,
+                                                int recs, int max_dist, const uint32_t *__restrict__ cnt,
+                                                unsigned long long *__restrict__ keys, int *__restrict__ rows, Counters *ctr) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) {
+        ctr->n_work = (unsigned)((n + 63) >> 6);  // work items of k_pgjoin: blocks of 64 rows (k_cells left its tile count here)
+        ctr->pairs_filtered = 0ull;
     }
-    const unsigned long long hm = __builtin_amdgcn_ballot_w64(head);
-    if (hm == 0ull) return;  // (a wave past the end)
-    const int last = 63 - (int)__builtin_clzll(hm);  // the last group that begins in this tile ends last
-    int gend = 0;
-    if (lane == last) {
-        // end of that group: first position behind p with another key (the records are sorted)
-        int lo = p + 1, hi = total;
-        if (lo < total && keys_s[lo] == key) {
-            int step = 64;  // gallop, then bisect: most groups are short
-            while (lo + step < total && keys_s[lo + step] == key) {
-                lo += step;
-                step <<= 1;
-            }
-            hi = min(total, lo + step);
-            while (hi - lo > 1) {
-                const int mid = lo + ((hi - lo) >> 1);
-                if (keys_s[mid] == key) lo = mid;
-                else hi = mid;
-            }
-            gend = hi;
-        } else {
-            gend = lo;
+    if (r >= n) return;
+    const int b = indptr[r], e = indptr[r + 1];
+    constexpr int L = PG_MAX_DIST + 1;
+    unsigned long long lst[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) lst[i] = ~0ull;
+    for (int j = b; j < e; j++) {  // (rows are short, the CSR is L2-resident)
+        const uint32_t t = indices[j] & 0x7FFFFFFFu;
+        const unsigned long long base = ((unsigned long long)min(cnt[pg_cnt_slot(t)], 4094u) << 37) | ((unsigned long long)(0x7FFFFFFFu - t) << 6);
+        int m = 0;  // occurrences of this token already in the list
+#pragma unroll
+        for (int i = 0; i < L; i++) m += (lst[i] >> 6) == (base >> 6) ? 1 : 0;
+        if (m > 63) continue;  // (multiplicities are capped at 64: a contraction, the bound stays valid)
+        unsigned long long key = base | (unsigned long long)m;
+        if (key >= lst[L - 1]) continue;
+#pragma unroll
+        for (int i = 0; i < L; i++) {  // insert, keeping the list ascending
+            const unsigned long long lo = min(lst[i], key), hi = max(lst[i], key);
+            lst[i] = lo;
+            key = hi;
         }
     }
-    gend = __shfl(gend, last);
-    if (lane == 0) {
-        const int t = p >> 6;
-        if (t < tile_cap) tiles[t] = make_int4(p, gend - p >= 2 ? min(64, total - p) : 0, gend, t);  // nothing behind its start: no pairs
-        else atomicOr(&ctr->err, ERR_WORKCAP);
-        if (p + 64 >= total) ctr->n_work = (unsigned)min(t + 1, tile_cap);
+    const int pre = recs - 1;  // = max_dist + 1
+#pragma unroll
+    for (int i = 0; i < L; i++)
+        if (i < pre) {
+            keys[(size_t)r * recs + i] = lst[i] != ~0ull ? lst[i] + 1ull : (PG_SENTINEL | (unsigned long long)((size_t)r * recs + i));
+            rows[(size_t)r * recs + i] = r * recs + i;  // the sort carries (row, slot)
+        }
+    // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
+    // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
+    keys[(size_t)r * recs + pre] = (e - b) <= 2 * max_dist ? 0ull : (PG_SENTINEL | (unsigned long long)((size_t)r * recs + pre));
+    rows[(size_t)r * recs + pre] = r * recs + pre;
+}
+
+// one thread per position of the sorted records: {row, length, second-level signature} of the position's row in group
+// order (k_pgjoin reads the members of a group as one coalesced stream), and where each record of a row went
+__global__ __launch_bounds__(256) void k_pgplace(const int *__restrict__ vals_s, int total, int recs, const int *__restrict__ indptr,
+                                                 const uint32_t *__restrict__ sigu2, int4 *__restrict__ srec, int *__restrict__ recpos) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int v = vals_s[p];
+    const int row = v / recs;
+    srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
+    recpos[v] = p;
+}
+
+// k_pgjoin: candidates of the prefix-group path, row by row.  One wave per row A: its records in the global order (the SHORT
+// record first, then the prefix elements), and for each the members BEHIND A's record in that record's group — the radix
+// sort is stable and the records were written row by row, so a group lists its rows ascending and every unordered pair is
+// seen from its smaller row.  A member B passes the second level (length difference and 64-bit signature distance within
+// max_dist) or is dropped; a pair must be queued once although its rows share several prefix elements: the FIRST element
+// they share is the first of A's records in whose group B shows up, so "seen in an earlier group of A" is the whole test —
+// a hash set in the wave's LDS, holding only members that passed (a row has ~16 of those at max_dist 5).  A set that
+// fills up (a hub row with thousands of neighbours) stops taking entries; from then on a member that is not in it is
+// checked the slow, equally exact way: is one of A's earlier elements among B's records.
+// Work items are blocks of 64 rows (t_begin / t_end and the multi-GPU owner rule count in those).
+__global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__restrict__ keys_s, const int4 *__restrict__ srec,
+                                                const int *__restrict__ recpos, const unsigned long long *__restrict__ keys, int n,
+                                                int recs, int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
+    constexpr int SCAP = 1024, WAVES = 4;
+    __shared__ int s_set[WAVES][SCAP];
+    __shared__ unsigned long long s_slots;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+    int *set = s_set[wave];
+    if (threadIdx.x == 0) s_slots = 0ull;
+    for (int i = lane; i < SCAP; i += 64) set[i] = -1;
+    __syncthreads();
+    int cshard = (blockIdx.x * WAVES + wave) & (CAND_SHARDS - 1);
+    unsigned long long visits = 0;
+    const int d = pa.d;
+    const int r_begin = t_begin * 64, r_end = min(n, (int)min((long long)t_end * 64, (long long)n));
+    for (int A = r_begin + blockIdx.x * WAVES + wave; A < r_end; A += (int)gridDim.x * WAVES) {
+        if (nshards > 1 && ((A >> 6) % nshards) != shard0) continue;  // another rank's block of rows
+        // lane i < recs: record i of A (position, key); the order to walk them: SHORT record (key 0) first, then 0 .. recs - 2
+        int mypos = 0;
+        unsigned long long mykey = ~0ull;
+        if (lane < recs) {
+            mypos = recpos[(size_t)A * recs + lane];
+            mykey = keys_s[mypos];
+        }
+        const int4 arec = srec[__builtin_amdgcn_readfirstlane(mypos)];  // {A, k_A, signature}
+        int n_in = 0;         // entries of the set (wave-uniform)
+        bool full = false;    // the set stopped taking entries
+        for (int step = 0; step < recs; step++) {
+            const int slot = step == 0 ? recs - 1 : step - 1;
+            const unsigned long long x = __shfl(mykey, slot);
+            if (step == 0 && x != 0ull) continue;           // no SHORT record
+            if (x >= PG_SENTINEL) continue;                  // no such prefix element
+            const int p = __shfl(mypos, slot);
+            for (int q0 = p + 1;; q0 += 64) {
+                const int q = q0 + lane;
+                const bool inb = q < total;
+                const unsigned long long kq = inb ? keys_s[q] : ~0ull;
+                const int4 rec = inb ? srec[q] : make_int4(0, 0, 0, 0);
+                const bool same = inb && kq == x;
+                const unsigned long long sm = __builtin_amdgcn_ballot_w64(same);
+                if (sm == 0ull) break;
+                visits += (unsigned long long)__popcll(sm);
+                const int B = rec.x;
+                bool pass = same && abs(rec.y - arec.y) <= d &&
+                            __popc((uint32_t)(rec.z ^ arec.z)) + __popc((uint32_t)(rec.w ^ arec.w)) <= d;
+                // seen in an earlier group of A?  (members of one group are distinct rows: no two lanes insert the same B)
+                bool fresh = false, unknown = false;
+                if (pass) {
+                    uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 22;  // SCAP = 1024 slots
+                    for (;;) {
+                        const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
+                        if (old == B) break;                     // seen: a duplicate
+                        if (old == -1) {
+                            fresh = !full;                       // (just inserted)
+                            unknown = full;                      // not in the set, and the set is incomplete
+                            break;
+                        }
+                        h = (h + 1) & (SCAP - 1);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(unknown) != 0ull) {
+                    // the slow exact test: one of A's earlier elements among B's records
+                    bool dup = false;
+                    if (unknown) {
+                        const unsigned long long *kb = keys + (size_t)B * recs;
+                        unsigned long long kbv[PG_MAX_DIST + 2];
+#pragma unroll
+                        for (int j = 0; j < PG_MAX_DIST + 2; j++) kbv[j] = j < recs ? kb[j] : ~0ull;
+                        for (int e2 = 0; e2 < step; e2++) {
+                            const int sl2 = e2 == 0 ? recs - 1 : e2 - 1;
+                            const unsigned long long y = keys[(size_t)A * recs + sl2];
+                            if (y >= PG_SENTINEL || (e2 == 0 && y != 0ull)) continue;
+#pragma unroll
+                            for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || kbv[j] == y;
+                        }
+                    }
+                    fresh = fresh || (unknown && !dup);
+                }
+                n_in += __popcll(__builtin_amdgcn_ballot_w64(fresh && !full));
+                if (n_in > SCAP * 3 / 4) full = true;  // (wave-uniform; entries made so far stay valid)
+                // queue the fresh pairs for k_verify
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
+                if (fm != 0ull) {
+                    cshard = (cshard + 1) & (CAND_SHARDS - 1);
+                    int base = 0;
+                    if (lane == 0) base = (int)atomicAdd(&pa.ctr->ncand[cshard], (unsigned)__popcll(fm));
+                    int ba = 0, bb = 0;
+                    if (fresh) {
+                        ba = pa.indptr[A];
+                        bb = pa.indptr[B];
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (fresh) {
+                        const int idx = base + below(fm);
+                        if (idx < pa.cand_cap_shard) {
+                            const size_t o = (size_t)cshard * pa.cand_cap_shard + idx;
+                            pa.cand[o] = make_int4(A, B, ba, bb);
+                            pa.candk[o] = make_int2(arec.y, rec.y);
+                        } else {
+                            pa.ctr->overflow = 1;  // dropped: the host re-runs the row range in smaller slices
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(inb && !same) != 0ull || !__builtin_amdgcn_ballot_w64(inb)) break;  // the group ended in this chunk
+            }
+        }
+        // clean the set for the next row
+        if (n_in > 0 || full)
+            for (int i = lane; i < SCAP; i += 64) set[i] = -1;
     }
+    if (lane == 0 && visits) atomicAdd(&s_slots, visits);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_slots) atomicAdd(&pa.ctr->pairs_filtered, s_slots);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1928,8 +2026,6 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.part_lo = 0;
     pa.part_hi = pa.part_den = 1;
     pa.stats_off = 0;
-    pa.pg_keys = nullptr;
-    pa.pg_classes = pa.pg_rows = 1;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
     // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
     // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
@@ -1999,17 +2095,10 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev) {
     const int n = pl.n;
     PairArgs pa = make_pair_args(pl);
-    if (pl.pg) {
-        pa.srec = pl.pg_srec;
-        pa.n = pl.n * pl.pg_classes;  // positions of the group order
-        pa.pg_keys = pl.pg_keys;
-        pa.pg_classes = pl.pg_classes;
-        pa.pg_rows = pl.n;
-    }
     BandArgs ba;
     ba.start3 = pl.start3;
-    ba.tiles = pl.pg ? pl.pg_tiles : pl.tiles;
-    ba.tile_slots = pl.pg ? pl.pg_tile_slots : pl.tile_slots;
+    ba.tiles = pl.tiles;
+    ba.tile_slots = pl.tile_slots;
     ba.dbg_t = (pl.dbg & 4) ? pl.dbg_t : nullptr;
     ba.key.fb = pl.fb;
     ba.key.gb = pl.gb;
@@ -2026,17 +2115,14 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
     ba.d = pl.d;
     // one block per tile of this shard; the tile count lives on the device, so the grid is sized from the
     // previous step's count (tile_hint) and the kernel strides over whatever the count turns out to be
-    const long long span = (long long)std::min(std::min(t_end, pl.pg ? pl.pg_tile_cap : pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
+    const long long span = (long long)std::min(std::min(t_end, pl.tile_cap), t_begin + pl.tile_hint) - t_begin;
     const int grid = std::max(1, (int)std::min<long long>(span, pl.pf_blocks));  // every rank walks all tiles, skips foreign cells
 
-    if (pl.pg) {  // pigeonhole path: groups of the (class, key) order; 64-row tiles, two waves per tile
-#define PG_CASE(W)                                                                                                     \
-    hipLaunchKernelGGL((k_prefilter<W, 1, 2, false, true>), dim3(grid), dim3(128), 0, st, pl.pg_sig1, ba, pl.n * pl.pg_classes, \
-                       pl.shard, pl.n_shards, t_begin, t_end, pa)
-        if (pl.w1 == 1) { PG_CASE(1); }
-        else if (pl.w1 == 2) { PG_CASE(2); }
-        else { PG_CASE(4); }
-#undef PG_CASE
+    if (pl.pg) {  // prefix-group path: one wave per row walks the row's groups (work items = blocks of 64 rows)
+        const int items = std::max(0, std::min(t_end, (n + 63) / 64) - t_begin);
+        const int blocks = std::max(1, std::min(pl.pf_blocks, (int)std::min<long long>((long long)items * 16, 1 << 20)));
+        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_keys_s, pl.pg_srec, pl.pg_recpos, pl.pg_keys, n, pl.pg_recs,
+                           n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         return launch_verify(pl, pa, st, ev);
@@ -2159,24 +2245,21 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
             return -1;
     }
     LAUNCH_CHECK();
-    if (pl.pg) {  // pigeonhole path: records, sort, group order + tiles (the prep above supplied the signatures)
-        const int total = n * pl.pg_classes;
-        hipLaunchKernelGGL(k_pgkeys, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.pg_classes, pl.pg_keys,
-                           pl.pg_rows, pl.ctr);
+    if (pl.pg) {  // prefix-group path: sampled token counts, records, sort, group order + tiles (the prep above supplied the signatures)
+        const int total = n * pl.pg_recs;
+        if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
+        const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
+        const int sampled = (n + stride - 1) / stride;
+        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pgkeys, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.pg_recs, pl.d, pl.pg_cnt,
+                           pl.pg_keys, pl.pg_rows, pl.ctr);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, PG_KEY_BITS + 3, st))
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, PG_SORT_BITS, st))
             return e;
-        const dim3 g((total + 255) / 256), b(256);
-        if (pl.w1 == 1)
-            hipLaunchKernelGGL(k_pgplace<1>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
-        else if (pl.w1 == 2)
-            hipLaunchKernelGGL(k_pgplace<2>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
-        else
-            hipLaunchKernelGGL(k_pgplace<4>, g, b, 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.indptr, pl.sigu1, pl.sigu2, pl.pg_sig1,
-                               pl.pg_srec, pl.pg_tiles, pl.pg_tile_cap, pl.ctr);
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_rows_s, total, pl.pg_recs, pl.indptr, pl.sigu2,
+                           pl.pg_srec, pl.pg_recpos);
         LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[1], st);

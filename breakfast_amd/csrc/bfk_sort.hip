@@ -1,4 +1,4 @@
-// bfk_sort.hip — the one library primitive of the pigeonhole path: a device radix sort of (64-bit key, row) records
+// bfk_sort.hip — the one library primitive of the prefix-group path: a device radix sort of (64-bit key, row) records
 // (rocPRIM, header-only).  In a translation unit of its own: the rocPRIM templates take longer to compile than all
 // of bfk_kernels.hip.
 #include <cstring>

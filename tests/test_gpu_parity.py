@@ -785,19 +785,27 @@ def test_allreduce_min_merge_reaches_the_fix_point():
         assert np.array_equal(l, want)
 
 
-# ---- pigeonhole groups (max-dist >= 2 on large inputs) against the band kernels and the oracle ------------------------
+# ---- prefix groups (max-dist >= 4 on large inputs; any max-dist 2..7 when forced) against the band kernels and the oracle ----
 @pytest.mark.parametrize("n,d,indels", [(3000, 2, False), (20000, 3, True), (20000, 5, True), (60000, 4, True), (777, 7, True)])
-def test_pigeonhole_groups_equal_the_band_path(n, d, indels):
-    """bfk_ctx_set_candidate_path(3): candidates from (token class, class-key) groups instead of (k,f,g) bands — same
-    labels, same number of edges (every pair counted once, in the lowest class its rows share), same neighbour lists"""
+def test_prefix_groups_equal_the_band_path(n, d, indels):
+    """bfk_ctx_set_candidate_path(3): candidates from the groups of the rows' prefix elements instead of (k,f,g)
+    bands — same labels, same number of edges (every pair queued once, at the first element its rows share)"""
     kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
     uf = list(dict.fromkeys(generate_profiles(n, **kw)))
     indptr, indices, _ = _lib.build_csr(uf, " ")
     nu = len(uf)
-    want, st_band = _lib.cluster_csr(indptr, indices, d)
+    ctxb = _lib.Context(0)
+    ctxb.set_candidate_path("allpairs")
+    ctxb.upload_csr(indptr, indices)
+    d_b = ctxb.alloc(4 * nu)
+    for _ in range(2):
+        ctxb.cluster(d, d_b)
+        st_band = ctxb.sync()
+    want = ctxb.download_i32(d_b, nu).copy()
+    ctxb.close()
     assert st_band["n_work_items"] > 0
     ctx = _lib.Context(0)
-    ctx.set_candidate_path("pigeonhole")
+    ctx.set_candidate_path("prefix")
     ctx.upload_csr(indptr, indices)
     d_out = ctx.alloc(4 * nu)
     for _ in range(2):  # (a dense first run may grow the candidate queue: the second is a single pass)
@@ -805,18 +813,41 @@ def test_pigeonhole_groups_equal_the_band_path(n, d, indels):
         st = ctx.sync()
     assert np.array_equal(ctx.download_i32(d_out, nu), want)
     assert st["n_edges"] == st_band["n_edges"] and st["n_retry_slices"] == 0
-    assert st["n_work_items"] == (nu * (d + 1) + 63) // 64  # one tile per 64 positions of the group order
+    assert st["n_work_items"] == (nu + 63) // 64  # work items of the prefix-group path: blocks of 64 rows
     ctx.close()
     if n <= 3000:
         assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_pigeonhole_groups_on_random_multisets(seed, monkeypatch):
-    """shuffled rows, repeated tokens, empty rows, rows shorter than the number of classes"""
+def test_prefix_groups_on_random_multisets(seed, monkeypatch):
+    """shuffled rows, repeated tokens, empty rows, rows shorter than the prefix (they meet in the SHORT group)"""
     monkeypatch.setenv("BFK_PG", "1")
     for d in (2, 3, 6):
         indptr, indices = _random_multisets(900, 100 * seed + d, alphabet=60, kmax=3 * d)
         want = orc.cluster_csr(indptr, indices, d, n_threads=8)
         got, st = _lib.cluster_csr(indptr, indices, d)
         assert np.array_equal(got, want["labels"]), (seed, d)
+
+
+def test_prefix_groups_hub_row_overflows_the_lds_set(monkeypatch):
+    """one row with 3000 neighbours at distance 1..2: the wave's LDS set (1024 slots) fills up and the rest of the row's
+    members are de-duplicated by the slow exact test; every pair still counted once"""
+    monkeypatch.setenv("BFK_PG", "1")
+    rng = np.random.default_rng(5)
+    hub = np.arange(100, 140, dtype=np.int32)
+    rows = [hub]
+    for i in range(3000):
+        extra = rng.integers(1000, 200000, size=int(rng.integers(1, 3)))
+        rows.append(np.concatenate([hub, extra.astype(np.int32)]))
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32)
+    for d in (2, 4):
+        want = orc.cluster_csr(indptr, indices, d, n_threads=8)
+        got, st = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want["labels"])
+        monkeypatch.setenv("BFK_PG", "0")
+        _, st_band = _lib.cluster_csr(indptr, indices, d)
+        monkeypatch.setenv("BFK_PG", "1")
+        assert st["n_edges"] == st_band["n_edges"]
