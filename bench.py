@@ -196,7 +196,7 @@ def cli_wall(n_rows: int, d: int, indels: bool):
     args = ["--input-file", str(inp), "--max-dist", str(d)] + (["--no-skip-del", "--no-skip-ins"] if indels else [])
     runs = []
     digest = None
-    for i in range(3):
+    for i in range(5):
         out = tmp / f"out{i}"
         t0 = time.perf_counter()
         r = subprocess.run([sys.executable, "-m", "breakfast_amd", *args, "--outdir", str(out)], cwd=str(ROOT),
@@ -206,8 +206,10 @@ def cli_wall(n_rows: int, d: int, indels: bool):
             return {"error": r.stderr.decode(errors="replace")[-400:]}
         runs.append(round(dt, 4))
         digest = hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest()
-    res = {"seconds": min(runs), "runs_s": runs, "what": "python -m breakfast_amd --input-file <tsv> --outdir <dir>, fresh "
-           "process each (interpreter start, imports, libbfk + HIP runtime load, context, kernels, writer); min of 3",
+    res = {"seconds": min(runs), "median_s": sorted(runs)[len(runs) // 2], "runs_s": runs,
+           "what": "python -m breakfast_amd --input-file <tsv> --outdir <dir>, fresh process each (interpreter start, imports, "
+                   "libbfk + HIP runtime load, context, kernels, writer); min of 5 (the HIP runtime's device open varies by "
+                   "0.1-0.2 s between runs on one box)",
            "rows": n_rows, "clusters_sha256": digest}
     gold = json.loads((ROOT / "tests" / "golden" / "sha256.json").read_text())
     key = f"syn{n_rows}_d{d}"
@@ -419,7 +421,8 @@ def main():
         warm(5)
 
     # ---- the all-pairs kernels on the same workload (north_star's design), when the main leg ran the join
-    join = d == 1 and st["n_work_items"] == 0 and n_u > 0
+    join = st.get("path", 0) == 1 and n_u > 0
+    prefix = st.get("path", 0) == 2
     allpairs = None
     if full and join:
         eng.ctx.set_candidate_path("allpairs")
@@ -452,6 +455,7 @@ def main():
         b_ref, merged_pairs, resolved = reference_equivalent_bytes(k, d, nnz)
         t_dom = st["ms_prefilter"] * 1e-3
         w = st["sig_words"]
+        k_mean = nnz / max(n_u, 1)
         if join:
             dom = "k_join"
             # what k_join must move: every token once (4 nnz), row extents (4 N), row hashes (8 N); its table / bitmap
@@ -459,14 +463,30 @@ def main():
             comp = (4 * nnz + 12 * n_u) / world
             comp_what = "4*nnz tokens + 4*N_u extents + 8*N_u row hashes, read once"
             step_bytes = (8 * nnz + 44 * n_u) / world
+        elif prefix:
+            # prefix groups: the exact verify is the longest kernel; it must read both rows of every candidate
+            # (4 B per token) and the 24-byte queue record
+            recs = d + 2
+            if st["ms_verify"] >= st["ms_prefilter"]:
+                dom = "k_verify"
+                t_dom = st["ms_verify"] * 1e-3
+                comp = st["n_candidates"] * (8 * k_mean + 24)
+                comp_what = "per candidate: both rows' tokens (8*k_mean B) + its 24-byte queue record"
+            else:
+                dom = "k_pgjoin"
+                comp = st["pairs_filtered"] * 24 + 12 * recs * n_u / world
+                comp_what = "24 B per group member visited (8-byte key + 16-byte row record) + the row's record positions and keys"
+            step_bytes = (2 * 4 * nnz + (84 + 16 * w) * n_u + 2 * 12 * recs * n_u * 8 + 36 * recs * n_u) / world + \
+                st["pairs_filtered"] * 24 + st["n_candidates"] * (8 * k_mean + 48)
         else:
             dom = f"k_prefilter<W={w}>"
             comp = (4 * w * n_u + 16 * n_u) / world
             comp_what = "sorted first-level signatures (4*W*N_u) + row records (16*N_u), read once"
             step_bytes = (4 * nnz + (84 + 16 * w) * n_u) / world
         achieved = comp / t_dom / 1e9 if t_dom > 0 else None
-        wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'allpairs'}"
-        tr = measured_traffic("k_join" if join else "k_prefilter", wl_key) if world == 1 else None
+        wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'prefix' if prefix else 'allpairs'}"
+        tr = measured_traffic("bfk::k_join" if join else "void bfk::k_verify" if (prefix and dom == "k_verify") else
+                              "bfk::k_pgjoin" if prefix else "void bfk::k_prefilter", wl_key) if world == 1 else None
         roof = {
             "bound": "hbm", "kernel": dom,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -474,7 +494,7 @@ def main():
             "traffic": tr["bytes"] if tr else None,
             "traffic_detail": tr,
             "algorithmic_bytes_per_launch": comp, "algorithmic_bytes_what": comp_what,
-            "kernel_ms": st["ms_prefilter"],
+            "kernel_ms": t_dom * 1e3,
             "kernel_ms_source": "HIP events on the launch stream around the kernel, mean of 64 steps (includes the "
                                 "launch gap, ~3 us more than rocprofv3's kernel time: profiles/)",
             "whole_step": {"bytes": step_bytes, "GBps": step_bytes / (ms_step * 1e-3) / 1e9,
@@ -487,7 +507,7 @@ def main():
                         "8 B per pruned pair: what an untiled all-pairs merge touches.  These kernels never stream those "
                         "operands, so this is an algorithmic-speedup figure, not a bandwidth claim"},
         }
-        if not join:
+        if not join and not prefix:
             t_pf = t_dom
             cyc_per_slot = w * (2.6 + 4.3) + 4.3
             ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
@@ -496,8 +516,12 @@ def main():
                             "frac_of_measured_ceiling": st["pairs_filtered"] / t_pf / ceiling if t_pf > 0 else None,
                             "note": "the pair kernel is VALU-issue-bound (xor + popcount + min per 32-bit signature "
                                     "word per pair slot), its working set lives in L2; this is the binding roofline"}
-        else:
+        elif join:
             roof["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
+        else:
+            roof["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges": st["n_edges"],
+                              "note": "prefix groups: candidates come from the groups of the rows' rarest tokens (no band scan); the "
+                                      "step is bound by the exact verify of the candidates and by round trips, not by VALU or HBM"}
         out = {
             "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step) + clusters.tsv wall-clock",
             "value": resolved * a.steps / elapsed,
@@ -517,8 +541,11 @@ def main():
                             f"max-dist {d}",
                 "workload_key": wl_key, "kernel_source_digest": kernel_source_digest(),
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
-                "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else "all-pairs kernels (k_sig .. k_prefilter .. k_verify)"),
+                "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else
+                                   "prefix groups (k_pgkeys .. radix sort .. k_pgjoin .. k_verify, DESIGN 6d)" if prefix else
+                                   "all-pairs band kernels (k_sig .. k_prefilter .. k_verify)"),
                 "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
+                             f"blocks of 64 rows (the walks of their groups) round-robin over {world} rank(s)" if prefix else
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM (host-inclusive figures: t_cluster_host_ms)",

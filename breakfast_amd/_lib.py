@@ -30,7 +30,7 @@ class Stats(C.Structure):
         ("pairs_filtered", C.c_int64), ("n_candidates", C.c_int64), ("n_edges", C.c_int64), ("n_retry_slices", C.c_int64),
         ("max_row_len", C.c_int32), ("sig_words", C.c_int32), ("n_work_items", C.c_int32), ("profiled", C.c_int32),
         ("ms_prep", C.c_float), ("ms_prefilter", C.c_float), ("ms_verify", C.c_float), ("ms_flatten", C.c_float),
-        ("ms_total", C.c_float),
+        ("ms_total", C.c_float), ("path", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):

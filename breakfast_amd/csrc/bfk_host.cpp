@@ -823,6 +823,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.n_retry_slices = retry_slices;
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;
+        s.path = c->plan.join ? 1 : (c->plan.pg ? 2 : 0);
         c->last_tiles = (int64_t)h.n_work;
         if (c->profiling && c->n_prof_calls > 0) {
             const int used = std::min(c->n_prof_calls, (int)bfk_ctx::EV_SLOTS);

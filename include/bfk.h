@@ -60,6 +60,8 @@ typedef struct bfk_stats {
     float ms_verify;         /* exact check of the candidates + union-find hooks */
     float ms_flatten;        /* label flatten */
     float ms_total;          /* first launch to last launch completion */
+    int32_t path;            /* candidate generator of the step: 0 band kernels, 1 variant join, 2 prefix groups (pairs_filtered = group members visited) */
+    int32_t reserved_;
 } bfk_stats;
 
 /* ---- library ------------------------------------------------------------------------------- */
