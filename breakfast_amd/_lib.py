@@ -90,6 +90,8 @@ EXPORTS = {
     "bfk_table_feature": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_id": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_write": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i64p]),
+    "bfk_table_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
+    "bfk_table_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_cluster_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, c_i64p]),
     "bfk_warmup": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
     "bfk_preload_start": (C.c_int, [C.c_char_p, C.c_int, C.c_int64, C.c_int64]),
@@ -324,6 +326,24 @@ class Table:
 
     def id(self, r):
         return self._str(self.lib.bfk_table_id, r, False)
+
+    def _strings(self, fn, n):
+        """bulk accessor -> list of n str (one decode, n slices)"""
+        p, o = C.c_void_p(), c_i64p()
+        _check(fn(self.h, C.byref(p), C.byref(o)))
+        off = np.ctypeslib.as_array(o, shape=(int(n) + 1,)).tolist()
+        blob = C.string_at(p, off[-1]).decode("ascii")
+        self.lib.bfk_free(p)
+        self.lib.bfk_free(o)
+        return [blob[off[i]: off[i + 1]] for i in range(int(n))]
+
+    def features(self):
+        """filtered feature strings of the unique rows (collapse_duplicates order)"""
+        return self._strings(self.lib.bfk_table_features, self.info.n_unique)
+
+    def ids(self):
+        """ids of the input rows"""
+        return self._strings(self.lib.bfk_table_ids, len(self))
 
     def write(self, path, cluster_of_unique) -> int:
         c = np.ascontiguousarray(cluster_of_unique, dtype=np.int32)

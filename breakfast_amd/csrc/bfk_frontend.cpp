@@ -826,3 +826,73 @@ extern "C" int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int
     for (size_t u = 0; u < nu; u++) cl[u] = size[(size_t)labels[u]] >= min_cluster_size ? labels[u] + 1 : 0;
     return bfk_table_write(t, path, cl.data(), n_clusters_out);
 }
+
+// bulk accessors for callers that need the strings themselves (the cache path keeps the reference's pickle format, which
+// stores the unique rows' feature strings and id tuples): one buffer + offsets instead of a call per row
+extern "C" int bfk_table_features(const bfk_table *t, char **buf_out, int64_t **off_out) {
+    if (!t || !t->prepared || !buf_out || !off_out) return bfk_fail(BFK_EARG, "bfk_table_features: bad argument");
+    const size_t nu = t->first_row.size();
+    int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (nu + 1));
+    if (!off) return bfk_fail(BFK_ENOMEM, "bfk_table_features: out of memory");
+    off[0] = 0;
+    const size_t sl = t->sep2.size();
+    for (size_t u = 0; u < nu; u++) {
+        int64_t len = 0;
+        if (!t->filtered) {
+            len = t->feats[(size_t)t->first_row[u]].len;
+        } else {
+            const int32_t b = t->indptr[u], e = t->indptr[u + 1];
+            for (int32_t j = b; j < e; j++) len += t->vocab[(size_t)t->indices[(size_t)j]].len;
+            if (e > b) len += (int64_t)sl * (e - b - 1);
+        }
+        off[u + 1] = off[u] + len;
+    }
+    char *buf = (char *)malloc((size_t)std::max<int64_t>(off[nu], 1));
+    if (!buf) {
+        free(off);
+        return bfk_fail(BFK_ENOMEM, "bfk_table_features: out of memory");
+    }
+    const char *base = t->bytes.data();
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), nu / 8192 + 1));
+    parallel_chunks(parts, [&](int q) {
+        for (size_t u = nu * (size_t)q / (size_t)parts; u < nu * (size_t)(q + 1) / (size_t)parts; u++) {
+            char *o = buf + off[u];
+            if (!t->filtered) {
+                const Span f = t->feats[(size_t)t->first_row[u]];
+                memcpy(o, base + f.off, (size_t)f.len);
+            } else {
+                for (int32_t j = t->indptr[u]; j < t->indptr[u + 1]; j++) {
+                    if (j > t->indptr[u]) {
+                        memcpy(o, t->sep2.data(), sl);
+                        o += sl;
+                    }
+                    const Span v = t->vocab[(size_t)t->indices[(size_t)j]];
+                    memcpy(o, base + v.off, (size_t)v.len);
+                    o += v.len;
+                }
+            }
+        }
+    });
+    *buf_out = buf;
+    *off_out = off;
+    return BFK_OK;
+}
+
+extern "C" int bfk_table_ids(const bfk_table *t, char **buf_out, int64_t **off_out) {
+    if (!t || !buf_out || !off_out) return bfk_fail(BFK_EARG, "bfk_table_ids: bad argument");
+    const size_t n = t->ids.size();
+    int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    if (!off) return bfk_fail(BFK_ENOMEM, "bfk_table_ids: out of memory");
+    off[0] = 0;
+    for (size_t r = 0; r < n; r++) off[r + 1] = off[r] + t->ids[r].len;
+    char *buf = (char *)malloc((size_t)std::max<int64_t>(off[n], 1));
+    if (!buf) {
+        free(off);
+        return bfk_fail(BFK_ENOMEM, "bfk_table_ids: out of memory");
+    }
+    const char *base = t->bytes.data();
+    for (size_t r = 0; r < n; r++) memcpy(buf + off[r], base + t->ids[r].off, (size_t)t->ids[r].len);
+    *buf_out = buf;
+    *off_out = off;
+    return BFK_OK;
+}

@@ -9,7 +9,8 @@ Equivalent, byte for byte and print for print, to
 
 for every input the native reader accepts; it declines (returns False, nothing printed or written) whenever
 the result could depend on pandas' CSV dialect handling or a reference exception is due (duplicate ids,
-missing columns ...), and when a cache is involved (the cache file stores pandas objects).
+missing columns ...).  Cache runs keep the reference's pickle format (pandas is imported for that alone) on the same
+native host stages.
 """
 
 from __future__ import annotations
@@ -32,10 +33,11 @@ def cluster_ids(labels, weight, min_cluster_size):
 
 def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
         reference_length, max_dist, min_cluster_size, outdir, input_cache=None, output_cache=None, n_gpus=1) -> bool:
-    if input_cache is not None or output_cache:
-        return False
     if var_type not in _front.VAR_TYPES or len(sep2) == 0:
         return False
+    if (input_cache is not None or output_cache) and max_dist != 0:
+        return _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+                               reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache)
     if max_dist != 0:
         _front.preload(input_file)  # HIP runtime + context + code object on a native thread while the input is parsed
     try:
@@ -63,5 +65,49 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
         print("Create graph and recover connected components")
         print("Save clusters")
     print(f"Number of clusters found: {n_clusters}")
+    table.close()
+    return True
+
+
+def _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+                    reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache) -> bool:
+    """--input-cache / --output-cache on the native host stages: reader, filter, collapse, CSR and writer as above; the cache
+    logic itself (cache.py: the reference's gzip-pickle of a DataFrame[id tuple, feature string] and a list of index arrays)
+    needs the unique rows' strings and pandas for the pickle, nothing more.  Replaces the pandas reader, the per-token
+    Python filter and the pandas writer of the mirror path for cache runs."""
+    import numpy as np
+    import pandas as pd
+
+    from . import _lib, cache as ca
+
+    try:
+        table = _lib.Table.open(input_file, sep, id_col, clust_col)
+        info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
+    except _lib.Unsupported:
+        return False
+    n, nu = int(info.n_rows), int(info.n_unique)
+    print(f"Number of sequences: {n}")
+    for i in range(int(info.n_invalid)):
+        print(f"Skipping invalid feature: '{table.invalid(i)}'")
+    print(f"Number of duplicates: {n - nu}")
+    print(f"Number of unique sequences: {nu}")
+    if info.nnz == 0:
+        raise ValueError("unable to infer matrix dimensions")  # (the reference dies here, :214)
+    indptr, indices = table.indptr, table.indices
+    # the frame cache.py works on: id = tuple of the accessions of a unique row (input order), feature = its filtered string
+    ids = table.ids()
+    order = np.argsort(table.group, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(table.weight)]).tolist()
+    order = order.tolist()
+    meta = pd.DataFrame({"id": [tuple(ids[j] for j in order[bounds[u]: bounds[u + 1]]) for u in range(nu)],
+                         "feature": table.features()})
+    meta["n_features"] = np.diff(indptr).astype(np.int64)
+    labels = ca.cluster_with_cache(meta, indptr, indices, max_dist, input_cache, output_cache)
+    print("Create graph and recover connected components")
+    print("Save clusters")
+    cid, n_clusters = cluster_ids(labels, table.weight, min_cluster_size)
+    print(f"Number of clusters found: {n_clusters}")
+    outdir.mkdir(parents=True, exist_ok=True)
+    table.write(outdir / "clusters.tsv", cid)
     table.close()
     return True

@@ -220,6 +220,11 @@ int bfk_table_invalid(const bfk_table *t, int64_t i, const char **tok_out, int64
 int bfk_table_feature(const bfk_table *t, int64_t u, char **str_out, int64_t *len_out);
 /* id of input row r (view) */
 int bfk_table_id(const bfk_table *t, int64_t r, const char **id_out, int64_t *len_out);
+/* the same in bulk, for callers that need the strings themselves (the cache path: the reference's pickle stores the unique
+ * rows' feature strings and id tuples, src/breakfast/cache.py:18-32): concatenated bytes + N+1 offsets, both library-allocated
+ * (bfk_free).  bfk_table_features: the filtered feature strings of the n_unique rows; bfk_table_ids: the ids of the n_rows rows. */
+int bfk_table_features(const bfk_table *t, char **buf_out, int64_t **off_out);
+int bfk_table_ids(const bfk_table *t, char **buf_out, int64_t **off_out);
 
 /* ---- the CLI's whole tail in one call -----------------------------------------------------------------------------
  * bfk_preload_start: a native thread loads `libbfk_path` (libbfk.so: HIP runtime, code object) and runs bfk_warmup(device,

@@ -233,15 +233,17 @@ def test_cli_fastpath_synthetic_dist0_with_invalid_tokens(tmp_path, monkeypatch)
     assert "Skipping invalid feature: 'bogus!'" in r1.output
 
 
-def test_cli_fastpath_declines_cache_and_dialects(tmp_path):
+def test_cli_fastpath_declines_dialects_and_ignores_the_cache_at_dist0(tmp_path):
     p = tmp_path / "in.tsv"
     p.write_text('accession\tdna_profile\n"a"\tC300T\n')
     ok = fastpath.run(p, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 0, 2,
                       tmp_path / "o")
     assert ok is False and not (tmp_path / "o").exists()
+    # max-dist 0 never touches a cache (cluster() goes to cluster_identical_features, breakfast.py:82-89): the native path runs
     p.write_text("accession\tdna_profile\na\tC300T\n")
     assert fastpath.run(p, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 0, 2,
-                        tmp_path / "o", None, tmp_path / "cache.pkl") is False
+                        tmp_path / "o", None, tmp_path / "cache.pkl") is True
+    assert (tmp_path / "o" / "clusters.tsv").exists() and not (tmp_path / "cache.pkl").exists()
 
 
 @pytest.mark.parametrize("indels", [False, True])

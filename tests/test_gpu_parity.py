@@ -319,8 +319,11 @@ def _run_cli(args):
     return res
 
 
-@pytest.fixture
-def own_cache(tmp_path, monkeypatch):
+@pytest.fixture(params=["native", "pandas"])
+def own_cache(request, tmp_path, monkeypatch):
+    """a cache written by this build: through the native host stages (fastpath._run_with_cache) and through the pandas mirror"""
+    if request.param == "pandas":
+        monkeypatch.setenv("BFK_NO_FASTPATH", "1")
     monkeypatch.chdir(FIX)
     cache = tmp_path / "cache_dir" / "cache"  # parent directory is created on demand (test_caching.py:106-125)
     _run_cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "init"), "--output-cache", str(cache),
@@ -328,14 +331,19 @@ def own_cache(tmp_path, monkeypatch):
     assert cache.exists()
     assert (tmp_path / "init" / "clusters.tsv").read_text() == json.loads(
         (GOLD / "cli_runs.json").read_text())["dist1"]["clusters_tsv"]
+    monkeypatch.delenv("BFK_NO_FASTPATH", raising=False)
     return cache
 
 
+@pytest.mark.parametrize("reader", ["native", "pandas"])
 @pytest.mark.parametrize("which", ["own", "reference"])
 @pytest.mark.parametrize("idx,name", list(enumerate(CACHE_INPUTS, 1)))
-def test_cache_scenarios(idx, name, which, own_cache, cli_runs, tmp_path, monkeypatch):
-    """the 8 cache scenarios of the reference, with a cache written by this build and with one written by the
-    reference itself (same pickle format): clusters.tsv equals what the reference produced"""
+def test_cache_scenarios(idx, name, which, reader, own_cache, cli_runs, tmp_path, monkeypatch):
+    """the 8 cache scenarios of the reference, with a cache written by this build (either host path) and with one written
+    by the reference itself (same pickle format), read through either host path: clusters.tsv equals what the reference
+    produced"""
+    if reader == "pandas":
+        monkeypatch.setenv("BFK_NO_FASTPATH", "1")
     monkeypatch.chdir(FIX)
     cache = own_cache if which == "own" else GOLD / "ref_cache_testfile_d1.pkl.gz"
     inp = f"testfile_caching{idx:02d}_{name}.tsv"
