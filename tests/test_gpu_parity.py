@@ -640,10 +640,14 @@ def test_variant_join_fuzz_vs_oracle(seed):
     assert by_join >= 15, by_join
 
 
+@pytest.mark.parametrize("generator", ["band", "prefix"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
-def test_all_pairs_fuzz_vs_oracle(seed):
+def test_all_pairs_fuzz_vs_oracle(seed, generator, monkeypatch):
     """the general path on many small inputs at max-dist 2 .. 5 (splicing and find + hook unions, one- and two-phase
-    verify, both certificates and the counting table): labels against the oracle, edge counts against brute force"""
+    verify, both certificates and the counting table), with the candidates from the band kernels and from the prefix
+    groups (tiny alphabets, rows shorter than the prefix, repeated tokens, shuffled rows): labels against the oracle, edge
+    counts against brute force"""
+    monkeypatch.setenv("BFK_PG", "1" if generator == "prefix" else "0")
     rng = np.random.default_rng(5000 + seed)
     for it in range(20):
         d = int(rng.integers(2, 6))
