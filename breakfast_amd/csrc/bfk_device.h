@@ -24,6 +24,8 @@ constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant jo
 
 constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
 constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
+constexpr int PG_GIVE_UP = 4096;        // group members behind a row's records, per row (sampled), beyond which the band path is used
+constexpr int PG_EST_STRIDE = 1024;     // every so many positions of the sorted records measure their walk (power of two)
 constexpr int PG_SORT_BITS = 50;        // key bits of a prefix record (12 count + 31 token + 6 occurrence, + 1, sentinel bit 49)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
@@ -36,6 +38,8 @@ struct Counters {
     unsigned int ticket;   // arrival order of the k_cells blocks
     unsigned int n_dup;    // variant join: entries of the dup list (k_jhash fills, k_join reads, k_flatten resets)
     int join_fail;         // variant join gave up (probe chain too long): the host re-runs on the all-pairs path
+    int pg_fail;           // prefix groups gave up (the groups are too big to pay: k_pgjoin did nothing): the host re-runs on the band path
+    unsigned long long pg_est;  // members behind every PG_EST_STRIDE-th position of the sorted records in its group (k_pgplace)
     int overflow;
     unsigned long long pairs_in_band;
     unsigned long long pairs_filtered;

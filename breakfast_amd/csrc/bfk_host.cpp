@@ -98,6 +98,7 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
+    bool pg_off = false;     // this CSR made the prefix groups give up once (groups too big): band kernels from now on
     int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 prefix groups
     // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
     uint32_t *pg_cnt = nullptr;
@@ -340,6 +341,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->need_zero = true;  // bins are laid out by kcap
     c->join_clear = true;
     c->join_off = false;
+    c->pg_off = false;
     c->join_empty_shard = -1;
     return ctx_size_workspace(c, 0);
 }
@@ -419,10 +421,10 @@ static int ctx_size_join(bfk_ctx *c) {
 // measured, ms per step band / prefix groups: 1M rows d = 2: 1.45 / 3.4, d = 3: 4.8 / 5.1, d = 4: 14.5 / 6.7, d = 5: 24.9 / 10.5;
 // 400k rows d = 5: 6.2 / 5.2; 100k rows d = 3: 0.48 / 1.02, d = 5: 2.19 / 1.78 — the records, their sort and the row-by-row
 // walk are ~0.5 ms at 100k rows and ~2 ms at 1M whatever max_dist is, the band scan they replace grows steeply with it
-static int64_t PG_MIN_ROWS(int max_dist) { return max_dist >= 4 ? 100000 : ((int64_t)1 << 40); }
+static int64_t PG_MIN_ROWS(int max_dist) { return max_dist >= 4 ? 80000 : ((int64_t)1 << 40); }
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {
-    if (max_dist < 2 || max_dist > PG_MAX_DIST || c->n < 2 || c->nnz <= 0) return false;
+    if (max_dist < 2 || max_dist > PG_MAX_DIST || c->n < 2 || c->nnz <= 0 || c->pg_off) return false;
     if ((int64_t)c->n * (max_dist + 2) > (int64_t)INT32_MAX - 1024) return false;
     if (c->path_mode) return c->path_mode == 3;
     if (const char *e = getenv("BFK_PG")) return atoi(e) != 0;
@@ -739,7 +741,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
         if (h.err & ERR_LABEL) return fail(BFK_EARG, "merge: label out of range");
         if (getenv("BFK_DEBUG"))
-            fprintf(stderr, "[bfk] k_cells %.1f us, %u tiles\n", (h.dbg[1] - h.dbg[0]) / 100.0, h.n_work);
+            fprintf(stderr, "[bfk] k_cells %.1f us, %u tiles; prefix groups: %d, estimate %llu sampled members, gave up %d\n",
+                    (h.dbg[1] - h.dbg[0]) / 100.0, h.n_work, c->plan.pg, h.pg_est, h.pg_fail);
         if (c->plan.dbg_t) {
             std::vector<unsigned long long> t((size_t)h.n_work * c->plan.pf_waves * 8);
             (void)hipMemcpy(t.data(), c->plan.dbg_t, t.size() * 8, hipMemcpyDeviceToHost);
@@ -759,6 +762,16 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             c->join_empty_shard = -1;
             c->need_zero = true;
             c->join_clear = true;
+            if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
+            c->last_tiles = (int64_t)h.n_work;
+            retry_slices = 1;
+        }
+        if (c->plan.pg && h.pg_fail) {
+            // the prefix groups are too big to pay (k_pgjoin did nothing): the step is redone on the band kernels
+            c->pg_off = true;
+            c->need_zero = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));

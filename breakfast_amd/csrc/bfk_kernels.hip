@@ -1734,8 +1734,12 @@ constexpr unsigned long long PG_SENTINEL = 1ull << 49;  // above every element k
 __device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - PG_CNT_BITS); }
 
 __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int stride,
-                                                uint32_t *__restrict__ cnt) {
+                                                uint32_t *__restrict__ cnt, Counters *ctr) {
     const int r = (blockIdx.x * 256 + threadIdx.x) * stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctr->pg_est = 0ull;
+        ctr->pg_fail = 0;
+    }
     if (r >= n) return;
     for (int j = indptr[r], e = indptr[r + 1]; j < e; j++) atomicAdd(&cnt[pg_cnt_slot(indices[j])], 1u);
 }
@@ -1787,14 +1791,35 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
 
 // one thread per position of the sorted records: {row, length, second-level signature} of the position's row in group
 // order (k_pgjoin reads the members of a group as one coalesced stream), and where each record of a row went
-__global__ __launch_bounds__(256) void k_pgplace(const int *__restrict__ vals_s, int total, int recs, const int *__restrict__ indptr,
-                                                 const uint32_t *__restrict__ sigu2, int4 *__restrict__ srec, int *__restrict__ recpos) {
+__global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__restrict__ keys_s, const int *__restrict__ vals_s, int total,
+                                                 int recs, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu2,
+                                                 int4 *__restrict__ srec, int *__restrict__ recpos, Counters *ctr) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const int v = vals_s[p];
     const int row = v / recs;
     srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
     recpos[v] = p;
+    if ((p & (PG_EST_STRIDE - 1)) == 0) {
+        // every PG_EST_STRIDE-th position measures what k_pgjoin would walk from it — the members of its group behind it
+        // (gallop + bisect over the sorted keys) — so that the walk can be called off when the groups are too big
+        const unsigned long long key = keys_s[p];
+        int lo = p, hi = total;  // last position of the group in [lo, hi)
+        if (key < PG_SENTINEL) {
+            int step = 1;
+            while (lo + step < total && keys_s[lo + step] == key) {
+                lo += step;
+                step <<= 1;
+            }
+            hi = min(total, lo + step);
+            while (hi - lo > 1) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (keys_s[mid] == key) lo = mid;
+                else hi = mid;
+            }
+            if (lo > p) atomicAdd(&ctr->pg_est, (unsigned long long)(lo - p));
+        }
+    }
 }
 
 // k_pgjoin: candidates of the prefix-group path, row by row.  One wave per row A: its records in the global order (the SHORT
@@ -1811,6 +1836,14 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
                                                 const int *__restrict__ recpos, const unsigned long long *__restrict__ keys, int n,
                                                 int recs, int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
     constexpr int SCAP = 1024, WAVES = 4;
+    // A token that many rows carry can still be among a row's first d + 1 (small alphabets, random rows): the groups are then a
+    // large part of all rows and walking them is quadratic.  k_pgplace measured the walk from every PG_EST_STRIDE-th position
+    // of the sorted records: beyond PG_GIVE_UP members per row the kernel does nothing and the host redoes the step on the
+    // band kernels (and keeps this CSR there).
+    if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) pa.ctr->pg_fail = 1;
+        return;
+    }
     __shared__ int s_set[WAVES][SCAP];
     __shared__ unsigned long long s_slots;
     const int lane = threadIdx.x & 63;
@@ -2250,7 +2283,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
         const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
         const int sampled = (n + stride - 1) / stride;
-        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt);
+        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pgkeys, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.pg_recs, pl.d, pl.pg_cnt,
                            pl.pg_keys, pl.pg_rows, pl.ctr);
@@ -2258,8 +2291,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         size_t tb = pl.pg_temp_bytes;
         if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, PG_SORT_BITS, st))
             return e;
-        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_rows_s, total, pl.pg_recs, pl.indptr, pl.sigu2,
-                           pl.pg_srec, pl.pg_recpos);
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.indptr,
+                           pl.sigu2, pl.pg_srec, pl.pg_recpos, pl.ctr);
         LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[1], st);

@@ -867,3 +867,35 @@ def test_prefix_groups_hub_row_overflows_the_lds_set(monkeypatch):
         _, st_band = _lib.cluster_csr(indptr, indices, d)
         monkeypatch.setenv("BFK_PG", "1")
         assert st["n_edges"] == st_band["n_edges"]
+
+
+def test_prefix_groups_give_up_on_big_groups(monkeypatch):
+    """random rows over a small alphabet: every token is in a quarter of the rows, so the 'rarest' tokens of a row still
+    group thousands of rows and walking the groups would be quadratic.  The sampled counts say so before any walk:
+    k_pgjoin does nothing, the step is redone on the band kernels (n_retry_slices = 1) and the CSR stays there"""
+    rng = np.random.default_rng(11)
+    n = 20000
+    rows = [np.sort(rng.choice(60, size=15, replace=False)).astype(np.int32) for _ in range(n)]
+    indptr = (np.arange(n + 1) * 15).astype(np.int32)
+    indices = np.concatenate(rows)
+    ctxb = _lib.Context(0)
+    ctxb.set_candidate_path("allpairs")
+    ctxb.upload_csr(indptr, indices)
+    d_b = ctxb.alloc(4 * n)
+    ctxb.cluster(4, d_b)
+    st_band = ctxb.sync()
+    want = ctxb.download_i32(d_b, n).copy()
+    ctxb.close()
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("prefix")
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * n)
+    ctx.cluster(4, d_out)
+    st = ctx.sync()
+    assert st["n_retry_slices"] == 1 and st["path"] == 0      # redone on the band kernels
+    assert np.array_equal(ctx.download_i32(d_out, n), want) and st["n_edges"] == st_band["n_edges"]
+    ctx.cluster(4, d_out)
+    st2 = ctx.sync()
+    assert st2["n_retry_slices"] == 0 and st2["path"] == 0    # and stays there for this CSR
+    assert np.array_equal(ctx.download_i32(d_out, n), want)
+    ctx.close()
