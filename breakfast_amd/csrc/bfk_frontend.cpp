@@ -315,10 +315,15 @@ void merge_vocab(const char *base, std::vector<TokChunk> &cks, std::vector<Span>
     });
 }
 
+// bytes of text a thread is worth starting for (BFK_CHUNK_BYTES: test knob — tiny inputs in many chunks)
+int64_t chunk_bytes(int64_t dflt) {
+    if (const char *e = getenv("BFK_CHUNK_BYTES")) return std::max<int64_t>(1, atoll(e));
+    return dflt;
+}
+
 std::vector<TokChunk> make_chunks(int64_t n_rows, int64_t total_bytes) {
     int t = host_threads();
-    // a thread is worth starting for ~256 KiB of text
-    t = (int)std::max<int64_t>(1, std::min<int64_t>(t, std::min<int64_t>(n_rows, total_bytes / (256 << 10) + 1)));
+    t = (int)std::max<int64_t>(1, std::min<int64_t>(t, std::min<int64_t>(n_rows, total_bytes / chunk_bytes(256 << 10) + 1)));
     std::vector<TokChunk> cks((size_t)t);
     for (int q = 0; q < t; q++) {
         cks[(size_t)q].r0 = n_rows * q / t;
@@ -433,7 +438,7 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     const char *b = t->bytes.data();
     const int64_t n = sz;
     {   // byte checks, in parallel slices
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / (1 << 20) + 1));
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / chunk_bytes(1 << 20) + 1));
         std::atomic<int> bad{0};
         parallel_chunks(parts, [&](int q) {
             for (int64_t i = n * q / parts, e = n * (q + 1) / parts; i < e; i++) {
@@ -497,7 +502,7 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     }
     pos = header_lf + 1;
     {   // data lines, in parallel slices that start at line starts; the slices' rows are concatenated in order
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n - pos) / (1 << 20) + 1));
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n - pos) / chunk_bytes(1 << 20) + 1));
         std::vector<int64_t> cut((size_t)parts + 1, n);
         cut[0] = pos;
         for (int q = 1; q < parts; q++) {

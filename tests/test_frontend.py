@@ -133,7 +133,13 @@ def _both_readers(path, sep="\t", id_col="id", feat="f"):
     ("id\tf\r\na\tX\r\n\r\nb\tY Z\r\n", "\t"),   # CRLF file (the reference's fixtures are)
     ("id\tf\r\na\tX\r", "\t"),                 # CR at end of file
 ])
-def test_reader_accepts_and_matches_pandas(text, sep, tmp_path):
+@pytest.mark.parametrize("chunk_bytes", [None, "1", "5"])
+def test_reader_accepts_and_matches_pandas(text, sep, chunk_bytes, tmp_path, monkeypatch):
+    """(chunk_bytes: the reader and the tokeniser cut their input into one slice per so many bytes — normally 1 MiB / 256 KiB;
+    with 1 or 5 bytes even these tiny files are read in several slices, cut at line starts)"""
+    if chunk_bytes:
+        monkeypatch.setenv("BFK_CHUNK_BYTES", chunk_bytes)
+        monkeypatch.setenv("BFK_THREADS", "6")
     p = tmp_path / "in.tsv"
     p.write_text(text)
     _both_readers(p, sep)
@@ -153,7 +159,11 @@ def test_reader_accepts_and_matches_pandas(text, sep, tmp_path):
     "id\tf\na\tXé\n",            # non-ASCII
     "id\tf\n   \nc\td\n",             # whitespace-only line
 ])
-def test_reader_declines(text, tmp_path):
+@pytest.mark.parametrize("chunk_bytes", [None, "3"])
+def test_reader_declines(text, chunk_bytes, tmp_path, monkeypatch):
+    if chunk_bytes:
+        monkeypatch.setenv("BFK_CHUNK_BYTES", chunk_bytes)
+        monkeypatch.setenv("BFK_THREADS", "6")
     p = tmp_path / "in.tsv"
     p.write_text(text)
     with pytest.raises(_lib.Unsupported):
