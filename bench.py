@@ -557,7 +557,7 @@ def main():
             },
             "roofline": roof,
             "phases_ms": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
-            "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges",
+            "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges", "n_connected",
                                                "n_retry_slices", "n_work_items", "max_row_len")},
             "result": {"components": int(len(np.unique(labels))), "labels_crc": int(np.bitwise_xor.reduce(
                 (labels.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(13)))},

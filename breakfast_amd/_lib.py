@@ -30,7 +30,7 @@ class Stats(C.Structure):
         ("pairs_filtered", C.c_int64), ("n_candidates", C.c_int64), ("n_edges", C.c_int64), ("n_retry_slices", C.c_int64),
         ("max_row_len", C.c_int32), ("sig_words", C.c_int32), ("n_work_items", C.c_int32), ("profiled", C.c_int32),
         ("ms_prep", C.c_float), ("ms_prefilter", C.c_float), ("ms_verify", C.c_float), ("ms_flatten", C.c_float),
-        ("ms_total", C.c_float), ("path", C.c_int32), ("reserved_", C.c_int32),
+        ("ms_total", C.c_float), ("path", C.c_int32), ("reserved_", C.c_int32), ("n_connected", C.c_int64),
     ]
 
     def as_dict(self):
@@ -76,6 +76,7 @@ EXPORTS = {
     "bfk_ctx_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "bfk_ctx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bfk_ctx_set_edge_capture": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bfk_ctx_set_exact_edges": (C.c_int, [C.c_void_p, C.c_int32]),
     "bfk_ctx_edges": (C.c_int, [C.c_void_p, C.POINTER(c_i32p), c_i64p]),
     "bfk_table_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfk_table_from_buffers": (C.c_int, [C.c_char_p, c_i64p, C.c_char_p, c_i64p, C.c_int64, C.POINTER(C.c_void_p)]),
@@ -386,6 +387,11 @@ class Context:
 
     def set_profiling(self, on=True):
         _check(self.lib.bfk_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def set_exact_edges(self, on: bool = True):
+        """on: every candidate pair is checked, `n_edges` is the number of edges of the graph; off (default): labels-only
+        steps at max_dist >= 3 drop candidates whose rows are already in one component (`n_connected`)."""
+        _check(self.lib.bfk_ctx_set_exact_edges(self.h, 1 if on else 0))
 
     def set_candidate_path(self, mode: str = "auto"):
         _check(self.lib.bfk_ctx_set_candidate_path(self.h, {"auto": 0, "allpairs": 1, "join": 2, "prefix": 3}[mode]))

@@ -46,6 +46,7 @@ struct Counters {
     unsigned long long n_cand_total;
     unsigned long long n_edges;
     unsigned long long n_edges_cap;
+    unsigned long long n_connected;  // k_verify_connected: candidates dropped because their rows were in one tree already
     unsigned long long dbg[8];  // phase stamps of k_plan (s_memrealtime, 100 MHz), printed with BFK_DEBUG=1
 };
 
@@ -69,6 +70,7 @@ struct Plan {
     int rows_per_lane, fb, gb, hb;
     int shard, n_shards;
     int verify_phases, verify_phase2_union;  // > 1: two-phase verify (first 1/phases of every shard, compress, the rest)
+    int skip_connected;  // labels-only step: k_verify_connected drops candidates whose rows are connected already
     int verify_grid, wave_table_d;  // k_verify: per-wave hash table up to this max_dist, per-group tables beyond
     int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)

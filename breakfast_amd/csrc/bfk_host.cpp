@@ -48,6 +48,7 @@ struct bfk_ctx {
     int n_cus = 256;
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool profiling = false, edge_capture = false;
+    int exact_edges = -1;  // -1: library default (BFK_EXACT_EDGES, else off), 0 / 1: bfk_ctx_set_exact_edges
     static constexpr int EV_SLOTS = 64;  // ring of per-step event sets: up to 64 steps are averaged per sync
     hipEvent_t ev[EV_SLOTS][5] = {};
     bool ev_ready = false;
@@ -216,6 +217,12 @@ extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
         c->last_tiles = 0;
     }
     c->path_mode = mode;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_set_exact_edges(bfk_ctx *c, int32_t enable) {
+    if (!c) return fail(BFK_EARG, "null ctx");
+    c->exact_edges = enable != 0;
     return BFK_OK;
 }
 
@@ -506,6 +513,17 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     // where the hooks of a dense graph fight over few roots — measured (verify kernel, one / two phases): 100k rows
     // d = 3: 374 / 273 us, d = 4: 590 / 470 us; no gain at d = 5 (849 / 849: the exact counts dominate), a loss at
     // 1M rows (d = 3: 1.49 / 1.85 ms, d = 5: 5.1 / 5.7 ms) and nothing to win at d <= 2 (sparse forests, splicing)
+    // Labels-only steps of dense graphs (max_dist >= 3) drop a candidate whose rows are in one tree already without
+    // computing its distance (k_verify_connected); n_edges then counts the edges that were checked, n_connected the rest.
+    // bfk_ctx_set_exact_edges(ctx, 1) / BFK_EXACT_EDGES=1 / edge capture: every candidate is checked.
+    {
+        int skip = max_dist >= 3;
+        if (const char *e = getenv("BFK_SKIP_CONNECTED")) skip = atoi(e) != 0;
+        int exact = 0;
+        if (const char *e = getenv("BFK_EXACT_EDGES")) exact = atoi(e) != 0;
+        if (c->exact_edges >= 0) exact = c->exact_edges;
+        pl.skip_connected = skip && !exact && !c->edge_capture;
+    }
     pl.verify_phases = ((max_dist == 3 || max_dist == 4) && c->n < 400000) ? 8 : 1;
     pl.verify_phase2_union = 0;
     if (const char *e = getenv("BFK_VERIFY_PHASES")) pl.verify_phases = std::max(1, std::min(64, atoi(e)));
@@ -678,14 +696,14 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
     std::vector<std::pair<int, int>> todo;
     const int step0 = std::max(1, (uhi - ulo) / 16);
     for (int b = uhi; b > ulo; b -= step0) todo.push_back({std::max(ulo, b - step0), b});
-    h->n_edges = h->n_cand_total = h->n_edges_cap = 0;
-    unsigned long long edges_acc = 0, cand_acc = 0;
+    h->n_edges = h->n_cand_total = h->n_edges_cap = h->n_connected = 0;
+    unsigned long long edges_acc = 0, cand_acc = 0, conn_acc = 0;  // (a slice that overflows is redone: only finished slices count)
     while (!todo.empty()) {
         auto [b, e] = todo.back();
         todo.pop_back();
         for (auto &x : h->ncand) x = 0;
         h->overflow = 0;
-        h->n_edges = h->n_cand_total = 0;
+        h->n_edges = h->n_cand_total = h->n_connected = 0;
         const unsigned long long cap_mark = h->n_edges_cap;
         HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
         if (int er = launch_pairs(pl, b, e, c->stream, nullptr))
@@ -714,9 +732,11 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
         if (int rc = ctx_pair_stats(c, h)) return rc;
         edges_acc += h->n_edges;
         cand_acc += h->n_cand_total;
+        conn_acc += h->n_connected;
     }
     h->n_edges = edges_acc;
     h->n_cand_total = cand_acc;
+    h->n_connected = conn_acc;
     h->overflow = 0;
     HIP_TRY(hipMemcpyAsync(c->d_head, h, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
     if (int er = launch_flatten(pl, c->stream, nullptr))
@@ -833,6 +853,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         }
         s.n_candidates = (int64_t)h.n_cand_total;
         s.n_edges = (int64_t)h.n_edges;
+        s.n_connected = (int64_t)h.n_connected;
         s.n_retry_slices = retry_slices;
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;

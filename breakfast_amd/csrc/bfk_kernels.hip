@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         if (threadIdx.x == 64) {
             a.ctr->err = 0;
             a.ctr->overflow = 0;
-            a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = 0;
+            a.ctr->n_edges = a.ctr->n_cand_total = a.ctr->n_edges_cap = a.ctr->n_connected = 0;
         }
     }
     const int c = bid * 1024 + threadIdx.x;
@@ -523,6 +523,7 @@ struct PairArgs {
     int use_link;  // k_verify hooks its edges with 0 uf_union (find + hook), 1 uf_link (splicing), 2 first hops, then splicing
     int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
     int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
+    int skip_connected;              // labels-only step: candidates whose rows are in one tree already are dropped unchecked
     Counters *ctr;
 };
 
@@ -1027,6 +1028,96 @@ __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t
     return dist;
 }
 
+// The exact test of one candidate by the 16 lanes of a group: is the multiset distance of rows rec.x and rec.y (tokens at
+// rows + rec.z / rec.w, lengths kk) within pa.d?  Group-uniform result; false for pairs with more than VERIFY_MAX_TOKENS
+// tokens (k_verify_long takes those).  With WAVE_TABLE all four groups of the wave must call it together.
+template <int STEPS, bool WAVE_TABLE>
+__device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int lane, int l16, const int4 &rec, const int2 &kk) {
+    // lane l16 of the group holds, per step st, position j = 16 st + l16 of row A, of row B, and of row B
+    // shifted by the length difference s = k_b - k_a
+    auto tokens = [&](uint32_t(&a)[STEPS], uint32_t(&b0)[STEPS], uint32_t(&bs)[STEPS]) {
+        const int sft = kk.y - kk.x;
+        const uint32_t *A = pa.rows + rec.z + l16, *B = pa.rows + rec.w + l16;  // one address per row, then
+        const uint32_t *Bs = B + sft;                                           // constant offsets 64 st
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) {
+            const int j = st * 16 + l16;
+            a[st] = j < kk.x ? A[st * 16] : 0u;
+            b0[st] = j < kk.y ? B[st * 16] : 0u;
+            bs[st] = (uint32_t)(j + sft) < (uint32_t)kk.y ? Bs[st * 16] : 0u;
+        }
+    };
+    uint32_t a[STEPS], b0[STEPS], bs[STEPS];
+    tokens(a, b0, bs);
+    const int ka = kk.x, kb = kk.y, kt = ka + kb;
+    bool is_edge = false;
+    if (kt <= VERIFY_MAX_TOKENS) {  // longer pairs: k_verify_long
+        // Certificate first.  Profiles list their mutations in a fixed order (by genome position), so two
+        // rows within d of each other are almost always the same sequence with a few tokens inserted: with
+        // t = first position where the rows differ and s = k_b - k_a, the pairs (i, i) for i < t and
+        // (i, i + s) for i >= max(t, t - s) with equal tokens are a matching of A into B (no position is
+        // used twice), so distance <= k_a + k_b - 2 * matched holds for ANY two rows, whatever their
+        // order.  If that bound is <= d the pair is an edge; otherwise it is counted exactly below.
+        const int sft = kb - ka, kmin = min(ka, kb);
+        uint32_t e0 = 0, es = 0;
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) {
+            const int j = st * 16 + l16;
+            e0 |= (uint32_t)(j < kmin && a[st] == b0[st]) << st;
+            es |= (uint32_t)(j < ka && (uint32_t)(j + sft) < (uint32_t)kb && a[st] == bs[st]) << st;
+        }
+        const int fst = __builtin_ctz(~e0);  // first step at which this lane's position differs (>= STEPS: none)
+        const int t = min(row16_allmin(fst * 16 + l16), kmin);
+        const int from = sft < 0 ? t - sft : t;              // first suffix position of row A
+        const int st0 = max(0, (from - l16 + 15) >> 4);        // first step of this lane inside the suffix
+        const int mine = st0 < STEPS ? __popc(es >> st0) : 0;
+        const int matched = t + row16_allsum(mine);
+        int dist = kt - 2 * matched;  // upper bound
+        // not certified: count exactly
+        if (WAVE_TABLE) {  // the wave's groups that need the table take turns
+            unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
+            while (want != 0ull) {
+                const int g = (int)(__builtin_ctzll(want) >> 4);
+                if ((lane >> 4) == g) dist = table_distance<STEPS, false>(mt, l16, a, b0, ka, kb);
+                want &= ~(0xFFFFull << (g * 16));
+            }
+        } else if (dist > pa.d && pa.d > 3) {
+            dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
+        } else if (dist > pa.d) {
+            // Second certificate (d = 2, 3; with more edits allowed it rarely holds and only costs): pairs with two separate edits — e.g. one token inserted near
+            // the front and one near the end — match under shift 0 before the first edit, under shift s
+            // after the last, and under ONE other shift in between.  With r = last position of A that does
+            // not match under shift s, the middle segment [t, r] is tried with shifts -1 and +1; its pairs
+            // (i, i + sigma) are kept only while t <= i + sigma <= r + s, i.e. between the B positions
+            // the prefix and the suffix use, so the three segments together are still a matching.
+            int hi = -1;
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                const int j = st * 16 + l16;
+                if (j >= from && j < ka && !((es >> st) & 1u)) hi = j;
+            }
+            const int r = max(row16_allmax(hi), from - 1);
+            const uint32_t *Bn = pa.rows + rec.w + l16;
+            int cm = 0, cp = 0;
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                const int j = st * 16 + l16;
+                const bool mid = j >= t && j <= r && j < ka;
+                const bool vm = mid && j - 1 >= t && j - 1 <= r + sft && j - 1 < kb;
+                const bool vp = mid && j + 1 >= t && j + 1 <= r + sft && j + 1 < kb;
+                const uint32_t xm = vm ? Bn[st * 16 - 1] : 0u, xp = vp ? Bn[st * 16 + 1] : 0u;
+                cm += (int)(vm && a[st] == xm);
+                cp += (int)(vp && a[st] == xp);
+            }
+            const int matched2 = t + max(row16_allsum(cm), row16_allsum(cp)) + (ka - 1 - r);
+            dist = min(dist, kt - 2 * matched2);
+            if (dist > pa.d) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
+        }
+        is_edge = dist <= pa.d;
+    }
+    return is_edge;
+}
+
 // STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
 // all are left to k_verify_long).  WAVE_TABLE: one hash table per wave, its groups take turns (d <= 1: nearly
 // every candidate is certified without the table, and 8 KiB of LDS per block keeps 6+ blocks per CU resident);
@@ -1077,92 +1168,11 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
         // A group has only ~2 candidates (32k groups are resident: 8 waves per SIMD), so latency is hidden by
         // occupancy, not by a deep pipeline per group: only the next queue record is fetched ahead.
         const int last = cnt - 1;
-        // lane l16 of the group holds, per step st, position j = 16 st + l16 of row A, of row B, and of row B
-        // shifted by the length difference s = k_b - k_a
-        auto tokens = [&](const int4 &rec, const int2 &kk, uint32_t(&a)[STEPS], uint32_t(&b0)[STEPS], uint32_t(&bs)[STEPS]) {
-            const int sft = kk.y - kk.x;
-            const uint32_t *A = pa.rows + rec.z + l16, *B = pa.rows + rec.w + l16;  // one address per row, then
-            const uint32_t *Bs = B + sft;                                           // constant offsets 64 st
-#pragma unroll
-            for (int st = 0; st < STEPS; st++) {
-                const int j = st * 16 + l16;
-                a[st] = j < kk.x ? A[st * 16] : 0u;
-                b0[st] = j < kk.y ? B[st * 16] : 0u;
-                bs[st] = (uint32_t)(j + sft) < (uint32_t)kk.y ? Bs[st * 16] : 0u;
-            }
-        };
         for (int e = e_first; e < e_hi; e += jstep) {
             const int e2 = min(e + 2 * jstep, last);
             const int4 rec_nn = pa.cand[base + e2];
             const int2 kk_nn = pa.candk[base + e2];
-            uint32_t a[STEPS], b0[STEPS], bs[STEPS];
-            tokens(rec, kk, a, b0, bs);
-            const int ka = kk.x, kb = kk.y, kt = ka + kb;
-            bool is_edge = false;
-            if (kt <= VERIFY_MAX_TOKENS) {  // longer pairs: k_verify_long
-                // Certificate first.  Profiles list their mutations in a fixed order (by genome position), so two
-                // rows within d of each other are almost always the same sequence with a few tokens inserted: with
-                // t = first position where the rows differ and s = k_b - k_a, the pairs (i, i) for i < t and
-                // (i, i + s) for i >= max(t, t - s) with equal tokens are a matching of A into B (no position is
-                // used twice), so distance <= k_a + k_b - 2 * matched holds for ANY two rows, whatever their
-                // order.  If that bound is <= d the pair is an edge; otherwise it is counted exactly below.
-                const int sft = kb - ka, kmin = min(ka, kb);
-                uint32_t e0 = 0, es = 0;
-#pragma unroll
-                for (int st = 0; st < STEPS; st++) {
-                    const int j = st * 16 + l16;
-                    e0 |= (uint32_t)(j < kmin && a[st] == b0[st]) << st;
-                    es |= (uint32_t)(j < ka && (uint32_t)(j + sft) < (uint32_t)kb && a[st] == bs[st]) << st;
-                }
-                const int fst = __builtin_ctz(~e0);  // first step at which this lane's position differs (>= STEPS: none)
-                const int t = min(row16_allmin(fst * 16 + l16), kmin);
-                const int from = sft < 0 ? t - sft : t;              // first suffix position of row A
-                const int st0 = max(0, (from - l16 + 15) >> 4);        // first step of this lane inside the suffix
-                const int mine = st0 < STEPS ? __popc(es >> st0) : 0;
-                const int matched = t + row16_allsum(mine);
-                int dist = kt - 2 * matched;  // upper bound
-                // not certified: count exactly
-                if (WAVE_TABLE) {  // the wave's groups that need the table take turns
-                    unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
-                    while (want != 0ull) {
-                        const int g = (int)(__builtin_ctzll(want) >> 4);
-                        if ((lane >> 4) == g) dist = table_distance<STEPS, false>(mt, l16, a, b0, ka, kb);
-                        want &= ~(0xFFFFull << (g * 16));
-                    }
-                } else if (dist > pa.d && pa.d > 3) {
-                    dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
-                } else if (dist > pa.d) {
-                    // Second certificate (d = 2, 3; with more edits allowed it rarely holds and only costs): pairs with two separate edits — e.g. one token inserted near
-                    // the front and one near the end — match under shift 0 before the first edit, under shift s
-                    // after the last, and under ONE other shift in between.  With r = last position of A that does
-                    // not match under shift s, the middle segment [t, r] is tried with shifts -1 and +1; its pairs
-                    // (i, i + sigma) are kept only while t <= i + sigma <= r + s, i.e. between the B positions
-                    // the prefix and the suffix use, so the three segments together are still a matching.
-                    int hi = -1;
-#pragma unroll
-                    for (int st = 0; st < STEPS; st++) {
-                        const int j = st * 16 + l16;
-                        if (j >= from && j < ka && !((es >> st) & 1u)) hi = j;
-                    }
-                    const int r = max(row16_allmax(hi), from - 1);
-                    const uint32_t *Bn = pa.rows + rec.w + l16;
-                    int cm = 0, cp = 0;
-#pragma unroll
-                    for (int st = 0; st < STEPS; st++) {
-                        const int j = st * 16 + l16;
-                        const bool mid = j >= t && j <= r && j < ka;
-                        const bool vm = mid && j - 1 >= t && j - 1 <= r + sft && j - 1 < kb;
-                        const bool vp = mid && j + 1 >= t && j + 1 <= r + sft && j + 1 < kb;
-                        const uint32_t xm = vm ? Bn[st * 16 - 1] : 0u, xp = vp ? Bn[st * 16 + 1] : 0u;
-                        cm += (int)(vm && a[st] == xm);
-                        cp += (int)(vp && a[st] == xp);
-                    }
-                    const int matched2 = t + max(row16_allsum(cm), row16_allsum(cp)) + (ka - 1 - r);
-                    dist = min(dist, kt - 2 * matched2);
-                    if (dist > pa.d) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
-                }
-                is_edge = dist <= pa.d;
-            }
+            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, rec, kk);
             if (is_edge) {  // group-uniform
                 if (l16 == (nkept & ubm)) {
                     my_a = rec.x;
@@ -1196,6 +1206,89 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     }
 }
 
+// k_verify_connected: k_verify for steps that only want the components (no edge list, no exact edge count).  A candidate
+// whose rows are in one tree already cannot change the result, so its distance is not needed: each lane looks one queue
+// record up and compares the roots of its two rows (64 finds of a wave in flight together); the survivors are packed in
+// LDS and the wave's four groups take them four at a time through the same exact test as k_verify; the edges of the round
+// are then hooked one per lane.  In the dense graphs of max_dist >= 3 (1M rows, max_dist 5: 2.1e7 candidates, 1.3e7 edges,
+// 68 components) nearly all of the queue is dropped once the first unions have gone in.  A stale "not connected" only costs
+// a check; "connected" is never stale (trees only merge), and the labels — the smallest row of each component — do not
+// depend on which edges were used.
+template <int STEPS, bool WAVE_TABLE>
+__global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_stats) {
+    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}
+    __shared__ int4 s_rec[4][64];                              // the round's survivors of each wave
+    __shared__ int2 s_kk[4][64];
+    __shared__ unsigned int blk_edges, blk_cands, blk_conn;
+    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;  // 0..15 in the block
+    const int wave = threadIdx.x >> 6, gw = (threadIdx.x >> 4) & 3;
+    uint2 *mt = tab[WAVE_TABLE ? wave : grp];
+    if (threadIdx.x == 0) blk_edges = blk_cands = blk_conn = 0;
+    __syncthreads();
+    // the same map of groups to queue entries as k_verify: group u works on shard u % CAND_SHARDS, entries j0, j0 + jstep, ..
+    const int u = blockIdx.x * 16 + grp, U = gridDim.x * 16;
+    const int shard = u & (CAND_SHARDS - 1), j0 = u / CAND_SHARDS, jstep = U / CAND_SHARDS;
+    const size_t base = (size_t)shard * pa.cand_cap_shard;
+    const int cnt = (int)min(pa.ctr->ncand[shard], (unsigned)pa.cand_cap_shard);
+    if (j0 == 0 && l16 == 0 && cnt && pa.part_lo == 0) atomicAdd(&blk_cands, (unsigned)cnt);
+    const int e_lo = (int)((long long)cnt * pa.part_lo / pa.part_den), e_hi = (int)((long long)cnt * pa.part_hi / pa.part_den);
+    int e_first = j0;
+    if (e_lo > j0) e_first = j0 + (e_lo - j0 + jstep - 1) / jstep * jstep;
+    auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+    unsigned n_edges = 0, n_conn = 0;  // wave-uniform
+    for (int e = e_first + l16 * jstep;; e += 16 * jstep) {
+        const bool have = e < e_hi;
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+        int4 rec = make_int4(0, 0, 0, 0);
+        int2 kk = make_int2(0, 0);
+        bool todo = false, conn = false;
+        if (have) {
+            rec = pa.cand[base + e];
+            kk = pa.candk[base + e];
+            if (kk.x + kk.y <= VERIFY_MAX_TOKENS) {  // (longer pairs: k_verify_long, which looks their roots up itself)
+                const int p0 = ld_agent(pa.parent + rec.x), p1 = ld_agent(pa.parent + rec.y);
+                todo = p0 != p1 && uf_find_from(pa.parent, rec.x, p0) != uf_find_from(pa.parent, rec.y, p1);
+                conn = !todo;
+            }
+        }
+        const unsigned long long tm = __builtin_amdgcn_ballot_w64(todo);
+        n_conn += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(conn));
+        const int ns = __popcll(tm), rank = below(tm);
+        if (todo) {
+            s_rec[wave][rank] = rec;
+            s_kk[wave][rank] = kk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long em = 0ull;  // survivors (by rank) that are edges
+        for (int i = 0; i < ns; i += 4) {
+            const bool valid = i + gw < ns;
+            const int4 r = valid ? s_rec[wave][i + gw] : make_int4(0, 0, 0, 0);
+            const int2 k = valid ? s_kk[wave][i + gw] : make_int2(0, 0);
+            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, r, k) && valid;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(is_edge);
+            em |= ((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull)) << i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        n_edges += (unsigned)__popcll(em);
+        if (todo && ((em >> rank) & 1ull)) {  // one edge per lane: the chains of the wave's edges overlap
+            if (pa.use_link == 1) uf_link(pa.parent, rec.x, rec.y); else if (pa.use_link == 2) uf_link_checked(pa.parent, rec.x, rec.y); else uf_union(pa.parent, rec.x, rec.y);
+        }
+    }
+    if (lane == 0) {
+        if (n_edges) atomicAdd(&blk_edges, n_edges);
+        if (n_conn) atomicAdd(&blk_conn, n_conn);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // plain stores, summed by the host (no same-word global atomics)
+        blk_stats[pa.stats_off + 2 * blockIdx.x] = (int)blk_edges;
+        blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = (int)blk_cands;
+        if (blk_conn) atomicAdd(&pa.ctr->n_connected, (unsigned long long)blk_conn);
+    }
+}
+
 // k_verify_long: pairs with more tokens than a group table holds: one block per pair, table in dynamic LDS
 // (up to LONG_TABLE slots) or, beyond that, in the block's slice of a global scratch table.
 __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey, int *gcnt, unsigned gslots, int2 *edges,
@@ -1211,6 +1304,16 @@ __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey
         const int ka = kk.x, kb = kk.y, kt = ka + kb;
         if (kt <= VERIFY_MAX_TOKENS) continue;  // done by k_verify
         const int4 rec = pa.cand[slot];
+        if (pa.skip_connected) {  // one thread decides for the block (trees merge while the block looks)
+            if (threadIdx.x == 0) {
+                sdist = uf_find(pa.parent, rec.x) == uf_find(pa.parent, rec.y) ? 1 : 0;
+                if (sdist) atomicAdd(&pa.ctr->n_connected, 1ull);
+            }
+            __syncthreads();
+            const bool conn = sdist != 0;
+            __syncthreads();
+            if (conn) continue;
+        }
         uint32_t tsz = 1024;
         while ((unsigned long long)tsz * 3ull < (unsigned long long)kt * 4ull) tsz <<= 1;
         uint32_t *mk;
@@ -1328,7 +1431,7 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
             ctr->err = 0;
             ctr->overflow = 0;
             ctr->n_work = 0;
-            ctr->n_edges = ctr->n_cand_total = ctr->n_edges_cap = 0;
+            ctr->n_edges = ctr->n_cand_total = ctr->n_edges_cap = ctr->n_connected = 0;
         }
     }
     const int r0 = blockIdx.x * rpw * 16 + wave * rpw;
@@ -1845,17 +1948,48 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
         return;
     }
     __shared__ int s_set[WAVES][SCAP];
-    __shared__ unsigned long long s_slots;
+    __shared__ int4 s_q[WAVES][64];  // fresh pairs {A, B, k_A, k_B} waiting for their queue slots (20 KiB of LDS in all: 8 blocks per CU)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     int *set = s_set[wave];
-    if (threadIdx.x == 0) s_slots = 0ull;
+    int4 *sq = s_q[wave];
     for (int i = lane; i < SCAP; i += 64) set[i] = -1;
     __syncthreads();
     int cshard = (blockIdx.x * WAVES + wave) & (CAND_SHARDS - 1);
     unsigned long long visits = 0;
     const int d = pa.d;
+    int nq = 0;  // pairs waiting in sq (wave-uniform)
+    // The wave's pairs go to the queue 64 at a time: one returning atomic per 64 pairs instead of one per chunk that found
+    // any (a round trip to the memory side each), and the queue records leave as full lines.
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cshard = (cshard + 1) & (CAND_SHARDS - 1);
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&pa.ctr->ncand[cshard], (unsigned)nq);
+        int4 e = make_int4(0, 0, 0, 0);
+        int ba = 0, bb = 0;
+        if (lane < nq) {
+            e = sq[lane];
+            ba = pa.indptr[e.x];
+            bb = pa.indptr[e.y];
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < nq) {
+            const int idx = base + lane;
+            if (idx < pa.cand_cap_shard) {
+                const size_t o = (size_t)cshard * pa.cand_cap_shard + idx;
+                pa.cand[o] = make_int4(e.x, e.y, ba, bb);
+                pa.candk[o] = make_int2(e.z, e.w);
+            } else {
+                pa.ctr->overflow = 1;  // dropped: the host re-runs the row range in smaller slices
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nq = 0;
+    };
     const int r_begin = t_begin * 64, r_end = min(n, (int)min((long long)t_end * 64, (long long)n));
     for (int A = r_begin + blockIdx.x * WAVES + wave; A < r_end; A += (int)gridDim.x * WAVES) {
         if (nshards > 1 && ((A >> 6) % nshards) != shard0) continue;  // another rank's block of rows
@@ -1867,19 +2001,44 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
             mykey = keys_s[mypos];
         }
         const int4 arec = srec[__builtin_amdgcn_readfirstlane(mypos)];  // {A, k_A, signature}
+        // the records to walk, as a mask over the STEPS (step 0 = the SHORT record in slot recs - 1, step i = slot i - 1)
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(lane < recs && (lane == recs - 1 ? mykey == 0ull : mykey < PG_SENTINEL));
+        unsigned om = (unsigned)((vm >> (recs - 1)) & 1ull) | ((unsigned)(vm & ((1ull << (recs - 1)) - 1ull)) << 1);
+        if (om == 0u) continue;
         int n_in = 0;         // entries of the set (wave-uniform)
         bool full = false;    // the set stopped taking entries
-        for (int step = 0; step < recs; step++) {
-            const int slot = step == 0 ? recs - 1 : step - 1;
-            const unsigned long long x = __shfl(mykey, slot);
-            if (step == 0 && x != 0ull) continue;           // no SHORT record
-            if (x >= PG_SENTINEL) continue;                  // no such prefix element
-            const int p = __shfl(mypos, slot);
+        // first chunk of the first record; while a record is worked on, the first chunk of the next one is already under way
+        // (most groups end inside their first chunk: the walk of a row is one dependent load deep instead of one per record)
+        int step = __builtin_ctz(om);
+        om &= om - 1u;
+        int slot = step == 0 ? recs - 1 : step - 1;
+        unsigned long long x = __shfl(mykey, slot);
+        int p = __shfl(mypos, slot);
+        unsigned long long kq = p + 1 + lane < total ? keys_s[p + 1 + lane] : ~0ull;
+        int4 rec = p + 1 + lane < total ? srec[p + 1 + lane] : make_int4(0, 0, 0, 0);
+        for (;;) {
+            const bool have_next = om != 0u;
+            int step_n = 0, p_n = 0;
+            unsigned long long x_n = 0ull, kq_n = ~0ull;
+            int4 rec_n = make_int4(0, 0, 0, 0);
+            if (have_next) {
+                step_n = __builtin_ctz(om);
+                om &= om - 1u;
+                const int slot_n = step_n - 1;  // (only the first step can be the SHORT record)
+                x_n = __shfl(mykey, slot_n);
+                p_n = __shfl(mypos, slot_n);
+                if (p_n + 1 + lane < total) {
+                    kq_n = keys_s[p_n + 1 + lane];
+                    rec_n = srec[p_n + 1 + lane];
+                }
+            }
             for (int q0 = p + 1;; q0 += 64) {
                 const int q = q0 + lane;
                 const bool inb = q < total;
-                const unsigned long long kq = inb ? keys_s[q] : ~0ull;
-                const int4 rec = inb ? srec[q] : make_int4(0, 0, 0, 0);
+                if (q0 != p + 1) {
+                    kq = inb ? keys_s[q] : ~0ull;
+                    rec = inb ? srec[q] : make_int4(0, 0, 0, 0);
+                }
                 const bool same = inb && kq == x;
                 const unsigned long long sm = __builtin_amdgcn_ballot_w64(same);
                 if (sm == 0ull) break;
@@ -1922,39 +2081,39 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
                 }
                 n_in += __popcll(__builtin_amdgcn_ballot_w64(fresh && !full));
                 if (n_in > SCAP * 3 / 4) full = true;  // (wave-uniform; entries made so far stay valid)
-                // queue the fresh pairs for k_verify
+                // the fresh pairs wait in LDS for their queue slots
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
                 if (fm != 0ull) {
-                    cshard = (cshard + 1) & (CAND_SHARDS - 1);
-                    int base = 0;
-                    if (lane == 0) base = (int)atomicAdd(&pa.ctr->ncand[cshard], (unsigned)__popcll(fm));
-                    int ba = 0, bb = 0;
-                    if (fresh) {
-                        ba = pa.indptr[A];
-                        bb = pa.indptr[B];
-                    }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (fresh) {
-                        const int idx = base + below(fm);
-                        if (idx < pa.cand_cap_shard) {
-                            const size_t o = (size_t)cshard * pa.cand_cap_shard + idx;
-                            pa.cand[o] = make_int4(A, B, ba, bb);
-                            pa.candk[o] = make_int2(arec.y, rec.y);
-                        } else {
-                            pa.ctr->overflow = 1;  // dropped: the host re-runs the row range in smaller slices
-                        }
-                    }
+                    const int nf = __popcll(fm);
+                    if (nq + nf > 64) flush();
+                    if (fresh) sq[nq + below(fm)] = make_int4(A, B, arec.y, rec.y);
+                    nq += nf;
                 }
                 if (__builtin_amdgcn_ballot_w64(inb && !same) != 0ull || !__builtin_amdgcn_ballot_w64(inb)) break;  // the group ended in this chunk
             }
+            if (!have_next) break;
+            step = step_n;
+            p = p_n;
+            x = x_n;
+            kq = kq_n;
+            rec = rec_n;
         }
         // clean the set for the next row
         if (n_in > 0 || full)
             for (int i = lane; i < SCAP; i += 64) set[i] = -1;
     }
-    if (lane == 0 && visits) atomicAdd(&s_slots, visits);
+    if (nq > 0) flush();
+    __syncthreads();  // every wave is done with its set: the first one's holds the block's visit counts now
+    if (lane == 0) {
+        s_set[0][2 * wave] = (int)(unsigned)visits;
+        s_set[0][2 * wave + 1] = (int)(unsigned)(visits >> 32);
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && s_slots) atomicAdd(&pa.ctr->pairs_filtered, s_slots);
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0ull;
+        for (int w = 0; w < WAVES; w++) sum += (unsigned long long)(unsigned)s_set[0][2 * w] | ((unsigned long long)(unsigned)s_set[0][2 * w + 1] << 32);
+        if (sum) atomicAdd(&pa.ctr->pairs_filtered, sum);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2059,6 +2218,7 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.part_lo = 0;
     pa.part_hi = pa.part_den = 1;
     pa.stats_off = 0;
+    pa.skip_connected = pl.skip_connected && !pl.edges;
     // measured, verify kernel in us (splicing / find + hook): 100k rows d = 2: 77 / 115-128, 1M rows d = 1: 75 / 111 —
     // nearly every edge joins two trees and one atomic does it; d = 3: 470 / 361, d = 5: 2640 / 840 — most edges are
     // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
@@ -2079,7 +2239,11 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
     const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
     auto one = [&](const PairArgs &pa) {
 #define VF_CASE(S)                                                                                                        \
-    if (pl.d <= pl.wave_table_d)                                                                                          \
+    if (pa.skip_connected && pl.d <= pl.wave_table_d)                                                                     \
+        hipLaunchKernelGGL((k_verify_connected<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.blk_stats);      \
+    else if (pa.skip_connected)                                                                                           \
+        hipLaunchKernelGGL((k_verify_connected<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.blk_stats);     \
+    else if (pl.d <= pl.wave_table_d)                                                                                     \
         hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
                            pl.blk_stats);                                                                                 \
     else                                                                                                                  \
@@ -2087,6 +2251,7 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
                            pl.blk_stats)
         if (steps <= 3) { VF_CASE(3); }
         else if (steps <= 4) { VF_CASE(4); }
+        else if (steps <= 5) { VF_CASE(5); }
         else if (steps <= 6) { VF_CASE(6); }
         else if (steps <= 8) { VF_CASE(8); }
         else { VF_CASE(12); }
@@ -2153,7 +2318,11 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 
     if (pl.pg) {  // prefix-group path: one wave per row walks the row's groups (work items = blocks of 64 rows)
         const int items = std::max(0, std::min(t_end, (n + 63) / 64) - t_begin);
-        const int blocks = std::max(1, std::min(pl.pf_blocks, (int)std::min<long long>((long long)items * 16, 1 << 20)));
+        // the waves stride over the rows; blocks per CU: large inputs want many (the rows' walks differ in length)
+        // (measured, k_pgjoin at 8 / 16 / 32 / 64 / 256 blocks per CU: 1M rows 3.26 / 2.80 / 2.60 / 2.46 / 2.38 ms, 100k rows 0.56 / 0.52 / 0.51 / 0.51 / 0.55)
+        static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
+        const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
+        const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
         hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_keys_s, pl.pg_srec, pl.pg_recpos, pl.pg_keys, n, pl.pg_recs,
                            n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
         LAUNCH_CHECK();

@@ -49,7 +49,7 @@ typedef struct bfk_stats {
     int64_t pairs_in_band;   /* unordered pairs with |k_i-k_j| <= max_dist (need a set comparison), all shards */
     int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded); variant join: table lookups */
     int64_t n_candidates;    /* pairs that passed both signature levels and were checked exactly */
-    int64_t n_edges;         /* candidates with exact distance <= max_dist */
+    int64_t n_edges;         /* candidates checked exactly with distance <= max_dist: every edge of the graph when n_connected == 0 */
     int64_t n_retry_slices;  /* >0: the candidate queue overflowed and the run was redone in this many slices */
     int32_t max_row_len;     /* largest multiset size k */
     int32_t sig_words;       /* 32-bit words of the first-level signature used (1, 2 or 4) */
@@ -62,6 +62,8 @@ typedef struct bfk_stats {
     float ms_total;          /* first launch to last launch completion */
     int32_t path;            /* candidate generator of the step: 0 band kernels, 1 variant join, 2 prefix groups (pairs_filtered = group members visited) */
     int32_t reserved_;
+    int64_t n_connected;     /* candidates dropped unchecked because their rows were in one component already (labels-only
+                              * steps at max_dist >= 3; 0 with bfk_ctx_set_exact_edges(ctx, 1), BFK_EXACT_EDGES=1 or edge capture) */
 } bfk_stats;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -154,6 +156,12 @@ int bfk_ctx_download(bfk_ctx *ctx, const void *d_src, void *h_dst, int64_t bytes
 int bfk_ctx_upload(bfk_ctx *ctx, const void *h_src, void *d_dst, int64_t bytes);
 int bfk_ctx_device_alloc(bfk_ctx *ctx, int64_t bytes, void **d_out);
 int bfk_ctx_device_free(bfk_ctx *ctx, void *d_ptr);
+
+/* Steps that only deliver labels may drop a candidate pair whose rows are already in one component without computing its
+ * distance (the reference computes every distance, breakfast.py:261-276, and then keeps only the components, :325-329;
+ * the labels are the same).  enable = 1: every candidate is checked and bfk_stats.n_edges is the number of edges of the
+ * graph (what the parity tests compare); 0: the default (pruning at max_dist >= 3). */
+int bfk_ctx_set_exact_edges(bfk_ctx *ctx, int32_t enable);
 
 /* edges of the last bfk_ctx_cluster run with edge capture enabled: (i<j) int32 pairs, library-allocated */
 int bfk_ctx_set_edge_capture(bfk_ctx *ctx, int32_t enable);

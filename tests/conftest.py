@@ -15,6 +15,17 @@ sys.path.insert(0, str(ROOT))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "exact_edges: the test compares bfk_stats.n_edges with the number of edges of the graph: "
+                            "every candidate is checked (BFK_EXACT_EDGES=1); unmarked tests run the library's default, which "
+                            "drops candidates of already connected rows at max_dist >= 3 (tests/test_gpu_pruned.py)")
+
+
+@pytest.fixture(autouse=True)
+def _exact_edges_mode(request, monkeypatch):
+    if request.node.get_closest_marker("exact_edges"):
+        monkeypatch.setenv("BFK_EXACT_EDGES", "1")
+    else:
+        monkeypatch.delenv("BFK_EXACT_EDGES", raising=False)
 
 
 def stage_names():

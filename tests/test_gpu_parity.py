@@ -26,6 +26,7 @@ def test_device_present():
     assert _lib.load().bfk_device_count() >= 1
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("name", stage_names())
 def test_labels_match_reference_golden(name):
     g = load_stage(name)
@@ -202,6 +203,7 @@ def test_very_long_rows_use_the_global_table():
         assert np.array_equal(got, want), d
 
 
+@pytest.mark.exact_edges
 def test_all_identical_rows_clique():
     """every pair is within distance 0: a dense candidate set (queue pressure) must still be exact"""
     n = 3000
@@ -418,6 +420,7 @@ def test_stats_pairs_in_band_matches_the_reference_band():
         assert st["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("n_shards,d", [(2, 1), (3, 2), (8, 1)])
 def test_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d):
     """the N-GPU path on one GPU: every shard of the tile list clustered into its own local forest
@@ -447,6 +450,7 @@ def test_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d):
     assert edges == st1["n_edges"]  # every edge found by exactly one shard
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("seed,d", [(1, 1), (2, 2), (3, 4), (4, 6)])
 def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
     """the verify kernel's certificate path: rows that keep a common token order (like real profiles), with
@@ -486,6 +490,7 @@ def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
         assert np.array_equal(idx[ptr[i]: ptr[i + 1]], np.flatnonzero(dist[i] <= d))
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("env", [{"BFK_PF_ROWS": "2"}, {"BFK_PF_ROWS": "4"}, {"BFK_PF_WAVES": "2"}, {"BFK_PF_WAVES": "4"},
                                  {"BFK_VERIFY_GRID": "32"}, {"BFK_VERIFY_GRID": "8192"}, {"BFK_KEY_H": "16"},
                                  {"BFK_KEY_H": "16", "BFK_PF_ROWS": "2"}, {"BFK_UNION_BATCH": "2"},
@@ -512,6 +517,7 @@ def test_kernel_configurations_of_large_inputs_give_the_same_labels(env, d, monk
     assert st["n_edges"] == st0["n_edges"] and st["n_candidates"] >= st["n_edges"]
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("cap,d", [(64, 2), (16, 3), (4, 1)])
 def test_candidate_queue_overflow_is_recovered(cap, d, monkeypatch):
     """a queue far too small for the input: dropped candidates raise the device flag, bfk_ctx_sync re-runs
@@ -573,6 +579,7 @@ def _join_cases():
     return cases
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("name", ["small_alphabet", "medium", "long_rows", "perms100", "perms400", "profiles30k",
                                   "tiny_rows"])
 def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
@@ -597,6 +604,7 @@ def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
     assert np.array_equal(ptr, ptr0) and np.array_equal(idx, idx0)
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "6"))))
 def test_variant_join_fuzz_vs_oracle(seed):
     """many small inputs of every shape the join special-cases: rows of 0 .. 700 tokens (single tokens, windows that
@@ -640,6 +648,36 @@ def test_variant_join_fuzz_vs_oracle(seed):
     assert by_join >= 15, by_join
 
 
+def fuzz_case(rng):
+    """one small input of the general-path fuzzers: a few base rows, every row a base row with up to d + 1 edits (front,
+    end, anywhere; repeats; now and then shuffled)"""
+    d = int(rng.integers(2, 6))
+    n_base = int(rng.integers(1, 20))
+    alphabet = int(rng.choice([4, 12, 100, 3000]))
+    kmax = int(rng.choice([3, 12, 40, 90, 250]))
+    base = [np.sort(rng.integers(0, alphabet, size=int(rng.integers(0, kmax + 1)))) for _ in range(n_base)]
+    rows = []
+    for _ in range(int(rng.integers(1, 500))):
+        r = list(base[int(rng.integers(0, n_base))])
+        for _ in range(int(rng.integers(0, d + 2))):
+            op = rng.random()
+            pos = int(rng.choice([0, len(r), int(rng.integers(0, len(r) + 1))]))
+            if op < 0.45 and r:
+                r.pop(min(pos, len(r) - 1))
+            elif op < 0.9:
+                r.insert(pos, int(rng.integers(0, alphabet)))
+            elif r:
+                r.insert(pos, r[int(rng.integers(0, len(r)))])
+        if rng.random() < 0.05:
+            rng.shuffle(r)
+        rows.append(np.array(r, dtype=np.int32))
+    indptr = np.zeros(len(rows) + 1, np.int32)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+    return rows, indptr, indices, d, alphabet
+
+
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("generator", ["band", "prefix"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
 def test_all_pairs_fuzz_vs_oracle(seed, generator, monkeypatch):
@@ -650,29 +688,7 @@ def test_all_pairs_fuzz_vs_oracle(seed, generator, monkeypatch):
     monkeypatch.setenv("BFK_PG", "1" if generator == "prefix" else "0")
     rng = np.random.default_rng(5000 + seed)
     for it in range(20):
-        d = int(rng.integers(2, 6))
-        n_base = int(rng.integers(1, 20))
-        alphabet = int(rng.choice([4, 12, 100, 3000]))
-        kmax = int(rng.choice([3, 12, 40, 90, 250]))
-        base = [np.sort(rng.integers(0, alphabet, size=int(rng.integers(0, kmax + 1)))) for _ in range(n_base)]
-        rows = []
-        for _ in range(int(rng.integers(1, 500))):
-            r = list(base[int(rng.integers(0, n_base))])
-            for _ in range(int(rng.integers(0, d + 2))):
-                op = rng.random()
-                pos = int(rng.choice([0, len(r), int(rng.integers(0, len(r) + 1))]))
-                if op < 0.45 and r:
-                    r.pop(min(pos, len(r) - 1))
-                elif op < 0.9:
-                    r.insert(pos, int(rng.integers(0, alphabet)))
-                elif r:
-                    r.insert(pos, r[int(rng.integers(0, len(r)))])
-            if rng.random() < 0.05:
-                rng.shuffle(r)
-            rows.append(np.array(r, dtype=np.int32))
-        indptr = np.zeros(len(rows) + 1, np.int32)
-        indptr[1:] = np.cumsum([len(r) for r in rows])
-        indices = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+        rows, indptr, indices, d, alphabet = fuzz_case(rng)
         want = orc.cluster_csr(indptr, indices, d, n_threads=4)["labels"]
         got, st = _lib.cluster_csr(indptr, indices, d)
         assert np.array_equal(got, want), (seed, it, d)
@@ -684,6 +700,7 @@ def test_all_pairs_fuzz_vs_oracle(seed, generator, monkeypatch):
             assert st["n_edges"] == int(np.triu(dist <= d, 1).sum()), (seed, it, d)
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("name,n_shards", [("perms100", 3), ("tiny_rows", 4), ("long_rows", 2)])
 def test_variant_join_sharded_equals_one_shard(name, n_shards):
     """the join's multi-GPU split on one GPU: blocks of tokens (their lookups) round-robin, a pair of equal multisets to
@@ -710,6 +727,7 @@ def test_variant_join_sharded_equals_one_shard(name, n_shards):
     assert edges == st1["n_edges"]
 
 
+@pytest.mark.exact_edges
 def test_variant_join_queue_overflow_falls_back(monkeypatch):
     """rows in no common order: the join cannot certify its matches itself and queues them for k_verify; a queue
     that is too small makes bfk_ctx_sync redo the step on the all-pairs path (which has the sliced recovery)"""
@@ -722,6 +740,7 @@ def test_variant_join_queue_overflow_falls_back(monkeypatch):
     assert np.array_equal(got, want) and st["n_edges"] == st0["n_edges"]
 
 
+@pytest.mark.exact_edges
 def test_variant_join_on_a_resident_context_alternates_its_tables():
     """steps on one context: the join clears the table set of the NEXT step; rebinding a smaller and a larger CSR
     in between must not leave stale entries"""
@@ -802,6 +821,7 @@ def test_allreduce_min_merge_reaches_the_fix_point():
 
 
 # ---- prefix groups (max-dist >= 4 on large inputs; any max-dist 2..7 when forced) against the band kernels and the oracle ----
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("n,d,indels", [(3000, 2, False), (20000, 3, True), (20000, 5, True), (60000, 4, True), (777, 7, True)])
 def test_prefix_groups_equal_the_band_path(n, d, indels):
     """bfk_ctx_set_candidate_path(3): candidates from the groups of the rows' prefix elements instead of (k,f,g)
@@ -846,6 +866,7 @@ def test_prefix_groups_on_random_multisets(seed, monkeypatch):
         assert np.array_equal(got, want["labels"]), (seed, d)
 
 
+@pytest.mark.exact_edges
 def test_prefix_groups_hub_row_overflows_the_lds_set(monkeypatch):
     """one row with 3000 neighbours at distance 1..2: the wave's LDS set (1024 slots) fills up and the rest of the row's
     members are de-duplicated by the slow exact test; every pair still counted once"""
@@ -869,6 +890,7 @@ def test_prefix_groups_hub_row_overflows_the_lds_set(monkeypatch):
         assert st["n_edges"] == st_band["n_edges"]
 
 
+@pytest.mark.exact_edges
 def test_prefix_groups_give_up_on_big_groups(monkeypatch):
     """random rows over a small alphabet: every token is in a quarter of the rows, so the 'rarest' tokens of a row still
     group thousands of rows and walking the groups would be quadratic.  The sampled counts say so before any walk:

@@ -1,0 +1,136 @@
+"""The library's default for labels-only steps at max-dist >= 3: a candidate pair whose rows are already in one component is
+dropped without its distance being computed (k_verify_connected).  The reference computes every distance
+(src/breakfast/breakfast.py:261-276) and then keeps only the connected components (:325-329), so the labels must be the
+same bit for bit; what changes is bfk_stats: n_edges counts the edges that went through the exact check, n_connected the
+candidates that were dropped.  The tests that compare n_edges with the number of edges of the graph carry the
+`exact_edges` marker (every candidate checked); here the default runs against the golden vectors, the oracle and the
+exact mode.  BFK_SKIP_CONNECTED=1 forces the pruning kernel at max-dist 1 and 2 as well."""
+
+import os
+
+import numpy as np
+import pytest
+from conftest import load_stage, stage_names
+from test_gpu_parity import fuzz_case
+
+from breakfast_amd import _lib
+from breakfast_amd.synth import generate_profiles
+from oracle import ref_port as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _invariants(st, labels):
+    n = len(labels)
+    comps = len(np.unique(labels))
+    assert st["n_edges"] + st["n_connected"] <= st["n_candidates"]
+    if st["n_retry_slices"] == 0:           # (after a queue overflow the counts are those of the recovery slices, which find
+        assert st["n_edges"] >= n - comps    #  the first pass's unions done) a spanning forest went through the exact check
+
+
+@pytest.mark.parametrize("force", [False, True])
+@pytest.mark.parametrize("name", stage_names())
+def test_golden_labels_with_pruning(name, force, monkeypatch):
+    g = load_stage(name)
+    if force:
+        monkeypatch.setenv("BFK_SKIP_CONNECTED", "1")
+    elif g["max_dist"] < 3:
+        pytest.skip("default: no pruning below max-dist 3 (covered by test_labels_match_reference_golden)")
+    labels, st = _lib.cluster_csr(g["indptr"], g["indices"], g["max_dist"])
+    assert np.array_equal(labels, g["labels"])
+    assert st["n_edges"] <= len(g["edges"])
+    _invariants(st, labels)
+
+
+@pytest.mark.parametrize("generator", ["band", "prefix"])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
+def test_fuzz_vs_oracle_with_pruning(seed, generator, monkeypatch):
+    """the inputs of test_all_pairs_fuzz_vs_oracle (max-dist 2 .. 5) with the pruning kernel at every max-dist"""
+    monkeypatch.setenv("BFK_PG", "1" if generator == "prefix" else "0")
+    monkeypatch.setenv("BFK_SKIP_CONNECTED", "1")
+    rng = np.random.default_rng(5000 + seed)
+    dropped = 0
+    for it in range(20):
+        rows, indptr, indices, d, alphabet = fuzz_case(rng)
+        want = orc.cluster_csr(indptr, indices, d, n_threads=4)["labels"]
+        got, st = _lib.cluster_csr(indptr, indices, d)
+        assert np.array_equal(got, want), (seed, it, d)
+        _invariants(st, got)
+        dropped += st["n_connected"]
+    assert dropped > 0
+
+
+@pytest.mark.parametrize("d,indels", [(3, False), (4, True), (5, True)])
+def test_100k_rows_pruned_equals_exact(d, indels):
+    """both kernels on one resident context, alternating (the counters of one mode must not leak into the other); the
+    prefix groups at max-dist 4, 5, the band kernels (two-phase verify) at 3"""
+    rows = generate_profiles(100_000, p_del=0.05, p_ins=0.01) if indels else generate_profiles(100_000)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n = len(uf)
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * n)
+    res = {}
+    for exact in (True, False, True, False):
+        ctx.set_exact_edges(exact)
+        ctx.cluster(d, d_out)
+        st = ctx.sync()
+        labels = ctx.download_i32(d_out, n).copy()
+        if exact in res:
+            assert np.array_equal(labels, res[exact][0]) and st["n_candidates"] == res[exact][1]["n_candidates"]
+            if exact:
+                assert st["n_edges"] == res[exact][1]["n_edges"]
+        res[exact] = (labels, st)
+    ctx.close()
+    (lx, sx), (lp, sp) = res[True], res[False]
+    assert np.array_equal(lx, lp)
+    assert sx["n_connected"] == 0 and sp["n_connected"] > 0
+    assert sp["n_candidates"] == sx["n_candidates"] and sp["n_edges"] <= sx["n_edges"]
+    _invariants(sp, lp)
+    assert sp["path"] == (2 if d >= 4 else 0)
+
+
+def test_pruned_sharded_runs_merge_to_the_one_shard_labels():
+    rows = generate_profiles(30_000, p_del=0.05, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n = len(uf)
+    for d in (3, 5):
+        want, st1 = _lib.cluster_csr(indptr, indices, d)
+        ctx = _lib.Context(0)
+        ctx.upload_csr(indptr, indices)
+        n_shards = 3
+        d_gath = ctx.alloc(4 * n * n_shards)
+        d_out = ctx.alloc(4 * n)
+        dropped = 0
+        for s in range(n_shards):
+            ctx.cluster(d, d_gath + 4 * n * s, s, n_shards)
+            dropped += ctx.sync()["n_connected"]
+        ctx.merge_labels(d_gath, n_shards, d_out)
+        ctx.sync()
+        assert np.array_equal(ctx.download_i32(d_out, n), want)
+        assert dropped > 0
+        ctx.close()
+
+
+def test_pruned_queue_overflow_is_recovered(monkeypatch):
+    """the recovery slices run the pruning kernel too: its counters add up over the slices"""
+    rows = generate_profiles(20_000, p_del=0.05, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want, st0 = _lib.cluster_csr(indptr, indices, 4)
+    monkeypatch.setenv("BFK_CAND_CAP_SHARD", "64")
+    got, st = _lib.cluster_csr(indptr, indices, 4)
+    assert st["n_retry_slices"] > 0
+    assert np.array_equal(got, want)
+    _invariants(st, got)
+
+
+def test_edge_capture_and_neighbour_lists_are_never_pruned():
+    """bfk_neighbours_csr (the cache path's lists) needs every edge: capture switches the pruning off"""
+    g = load_stage("indel200_d5")
+    ptr, idx = _lib.neighbours_csr(g["indptr"], g["indices"], g["max_dist"])
+    n = len(g["indptr"]) - 1
+    got = {(i, int(j)) for i in range(n) for j in idx[ptr[i]: ptr[i + 1]] if j > i}
+    assert got == {tuple(e) for e in g["edges"].tolist()}

@@ -102,6 +102,7 @@ def _sharded_labels(indptr, indices, d, n_shards):
     return got, edges
 
 
+@pytest.mark.exact_edges
 def test_config3_one_million_rows_max_dist_1(million):
     uf, indptr, indices = _csr(million)
     assert len(uf) > 990_000
@@ -130,24 +131,35 @@ def test_config3_one_million_rows_max_dist_1(million):
     ctx.close()
 
 
-def test_config4_one_million_rows_max_dist_5_indels(million_indels):
+def test_config4_one_million_rows_max_dist_5_indels(million_indels, monkeypatch):
     uf, indptr, indices = _csr(million_indels)
     d = 5
+    # the library's default for a labels-only step at max-dist >= 3: candidates of already connected rows are dropped
     l5, st5 = _lib.cluster_csr(indptr, indices, d)
     if st5["n_retry_slices"]:               # the first queue is sized for sparse graphs; sync grows it: run again clean
         l5b, st5 = _lib.cluster_csr(indptr, indices, d)
         assert np.array_equal(l5b, l5)
     _check_fix_point(l5)
+    assert st5["n_connected"] > st5["n_candidates"] // 2    # the dense graph the configuration is about
+    assert st5["n_edges"] + st5["n_connected"] <= st5["n_candidates"]
+    assert st5["n_edges"] >= len(uf) - len(np.unique(l5))    # at least a spanning forest went through the exact check
     l4, _ = _lib.cluster_csr(indptr, indices, 4)
     assert np.array_equal(l5[l4], l5)
-    assert st5["n_edges"] > 5 * len(uf)     # the dense graph the configuration is about
     assert _check_sampled_rows(indptr, indices, d, l5, 40, seed=21) > 40
     _check_permutation_invariance(uf, d, l5, seed=22)
+    got8, _ = _sharded_labels(indptr, indices, d, 8)
+    assert np.array_equal(got8, l5)
+    # every candidate checked: same labels, and every edge is found by exactly one shard
+    monkeypatch.setenv("BFK_EXACT_EDGES", "1")
+    l5x, st5x = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(l5x, l5) and st5x["n_connected"] == 0 and st5x["n_candidates"] == st5["n_candidates"]
+    assert st5x["n_edges"] > 5 * len(uf)
     got8, edges8 = _sharded_labels(indptr, indices, d, 8)
     assert np.array_equal(got8, l5)
-    assert edges8 == st5["n_edges"]
+    assert edges8 == st5x["n_edges"]
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("n_rows,join,third_key", [(590_000, True, False), (610_000, True, True), (790_000, True, True),
                                                    (815_000, False, True)])
 def test_size_switches_without_knobs(million, n_rows, join, third_key):
@@ -189,6 +201,7 @@ def _driver_case():
     return indptr, indices
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("d", [1, 2])
 def test_gpu_engine_world_1_matches_one_shot(d):
     import torch
@@ -233,6 +246,7 @@ def _nccl_worker(rank, world, port, d, merge, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("d,merge", [(1, "allgather"), (2, "allgather"), (2, "allreduce")])
 def test_gpu_engine_world_2_over_rccl(d, merge, tmp_path):
     """two ranks, two GPUs, RCCL label exchange: every rank ends with the 1-GPU labels (needs >= 2 devices)"""
@@ -255,6 +269,7 @@ def test_gpu_engine_world_2_over_rccl(d, merge, tmp_path):
     assert edges == st1["n_edges"]
 
 
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("d,world", [(1, 2), (2, 3)])
 def test_gpu_engine_sharded_steps_on_one_device(d, world):
     """GpuEngine.cluster_shard + GpuEngine.merge for every rank of a `world`-rank run, executed one after the other on
@@ -284,6 +299,7 @@ def test_gpu_engine_sharded_steps_on_one_device(d, world):
 
 
 # ---- n_gpus > 1 behind the one-shot C-ABI and the CLI (one process, one context per device) ------------------------------
+@pytest.mark.exact_edges
 @pytest.mark.parametrize("d,n_gpus", [(1, 2), (2, 3), (3, 8)])
 def test_cluster_csr_n_gpus_rehearsed_on_one_device(d, n_gpus, monkeypatch):
     """bfk_cluster_csr(n_gpus > 1): shards on their own contexts, label arrays gathered by peer copies, merged on the first
