@@ -26,7 +26,6 @@ constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefi
 constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
 constexpr int PG_GIVE_UP = 4096;        // group members behind a row's records, per row (sampled), beyond which the band path is used
 constexpr int PG_EST_STRIDE = 1024;     // every so many positions of the sorted records measure their walk (power of two)
-constexpr int PG_SORT_BITS = 50;        // key bits of a prefix record (12 count + 31 token + 6 occurrence, + 1, sentinel bit 49)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
 
@@ -96,20 +95,22 @@ struct Plan {
     // bands.  The sorted order has pg_recs * n positions (pg_recs = max_dist + 2 records per row).
     int pg, pg_recs;
     uint32_t *pg_cnt;                         // sampled token counts (2^PG_CNT_BITS hashed counters)
-    unsigned long long *pg_keys, *pg_keys_s;  // [n][recs] records, row-major; sorted
+    uint32_t *pg_keys, *pg_keys_s;            // [n][recs] record keys, row-major; sorted
+    int pg_tb;                                // key bits to sort: bits of (largest token id + 2)
     int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along
     void *pg_temp;
     size_t pg_temp_bytes;
     int4 *pg_srec;       // {row, length, second-level signature} in group order
-    int *pg_recpos;      // [n][recs]: position of every record in the group order
+    int2 *pg_recpos;     // [n][recs]: {position of the record in the group order, members of its group behind it}
     int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;
 };
 
-int sort_records(void *temp, size_t *temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const int *rows_in,
+int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st);  // bfk_sort.hip
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
+int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev);
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev);

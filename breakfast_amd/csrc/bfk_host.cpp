@@ -104,8 +104,10 @@ struct bfk_ctx {
     // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
     uint32_t *pg_cnt = nullptr;
     int64_t n_short = 0;  // rows of at most 2 * PG_MAX_DIST tokens (bind time): they all meet in one group
-    unsigned long long *pg_keys = nullptr, *pg_keys_s = nullptr;
-    int *pg_rows = nullptr, *pg_rows_s = nullptr, *pg_recpos = nullptr;
+    uint32_t *pg_keys = nullptr, *pg_keys_s = nullptr;
+    int max_tok = -1;  // largest token id of the bound CSR (found when the prefix groups are first considered for it)
+    int *pg_rows = nullptr, *pg_rows_s = nullptr;
+    int2 *pg_recpos = nullptr;
     void *pg_temp = nullptr;
     int4 *pg_srec = nullptr;
     int64_t pg_rec_cap = 0, pg_temp_cap = 0;
@@ -344,6 +346,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->nnz = nnz32;
     c->kcap = h[0];
     c->n_short = h[2];
+    c->max_tok = -1;
     c->ran = false;
     c->need_zero = true;  // bins are laid out by kcap
     c->join_clear = true;
@@ -425,10 +428,16 @@ static int ctx_size_join(bfk_ctx *c) {
 // thresholds the sort and the passes over (d + 2) N records cost more than the band scan they save (measured: DESIGN 6d).
 // Rows of at most 2 * max_dist tokens all meet in ONE group (prefix filtering says nothing about them): an input with
 // many of those stays on the band path.
-// measured, ms per step band / prefix groups: 1M rows d = 2: 1.45 / 3.4, d = 3: 4.8 / 5.1, d = 4: 14.5 / 6.7, d = 5: 24.9 / 10.5;
-// 400k rows d = 5: 6.2 / 5.2; 100k rows d = 3: 0.48 / 1.02, d = 5: 2.19 / 1.78 — the records, their sort and the row-by-row
-// walk are ~0.5 ms at 100k rows and ~2 ms at 1M whatever max_dist is, the band scan they replace grows steeply with it
-static int64_t PG_MIN_ROWS(int max_dist) { return max_dist >= 4 ? 80000 : ((int64_t)1 << 40); }
+// measured, ms per step band / prefix groups (tools/pg_matrix.sh, labels-only steps, indels kept):
+//   rows    d = 2          d = 3          d = 4          d = 5
+//   100k    0.18 / 0.55    0.46 / 0.69    0.81 / 0.78    2.11 / 1.37
+//   300k    0.49 / 0.74    1.28 / 1.00    2.14 / 1.18    3.62 / 2.29
+//   1M      1.50 / 2.03    4.83 / 2.49    13.5 / 3.12    21.4 / 4.60
+// the records, their sort and the row-by-row walk cost ~0.5 ms at 100k rows and ~2 ms at 1M whatever max_dist is, the band
+// scan they replace grows steeply with it
+static int64_t PG_MIN_ROWS(int max_dist) {
+    return max_dist >= 5 ? 80000 : (max_dist == 4 ? 90000 : (max_dist == 3 ? 200000 : ((int64_t)1 << 40)));
+}
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {
     if (max_dist < 2 || max_dist > PG_MAX_DIST || c->n < 2 || c->nnz <= 0 || c->pg_off) return false;
@@ -437,6 +446,24 @@ static bool pg_wanted(const bfk_ctx *c, int max_dist) {
     if (const char *e = getenv("BFK_PG")) return atoi(e) != 0;
     if (c->n_short > 4096) return false;
     return c->n >= PG_MIN_ROWS(max_dist);
+}
+
+// the 32-bit record keys hold token + 1 (0: SHORT record, all ones: none): the largest token id of the CSR — one pass over
+// the indices, once per bind — gives the number of key bits the sort has to look at
+static int pg_key_bits(bfk_ctx *c, int *tb_out) {
+    if (c->max_tok < 0) {
+        HIP_TRY(hipMemsetAsync(c->d_small, 0, 16, c->stream));
+        if (int e = launch_maxtok(c->d_indices, (int)c->nnz, c->d_small, c->stream))
+            return fail(BFK_EHIP, std::string("k_maxtok launch: ") + hipGetErrorString((hipError_t)e));
+        int m = 0;
+        HIP_TRY(hipMemcpyAsync(&m, c->d_small, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->max_tok = m;
+    }
+    int tb = 2;
+    while (tb < 31 && ((int64_t)1 << tb) - 3 < (int64_t)c->max_tok) tb++;  // token + 1 <= 2^tb - 2
+    *tb_out = tb;
+    return BFK_OK;
 }
 
 static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
@@ -455,7 +482,7 @@ static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
         c->pg_rec_cap = total;
     }
     size_t tb = 0;
-    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, PG_SORT_BITS, c->stream))
+    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, 32, c->stream))
         return fail(BFK_EHIP, std::string("radix sort set-up: ") + hipGetErrorString((hipError_t)e));
     if ((int64_t)tb > c->pg_temp_cap) {
         if (c->pg_temp) (void)hipFree(c->pg_temp);
@@ -617,6 +644,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     }
     pl.pg = 0;
     if (!pl.join && pg_wanted(c, max_dist)) {
+        if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
         size_t tb = 0;
         if (int rc = ctx_size_pg(c, max_dist + 2, &tb)) return rc;
         pl.pg = 1;

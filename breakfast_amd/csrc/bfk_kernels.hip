@@ -960,6 +960,13 @@ __device__ __forceinline__ int row16_allmin(int x) {
     x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));
     return x;
 }
+__device__ __forceinline__ uint32_t row16_allmin_u(uint32_t x) {
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false));
+    return x;
+}
 __device__ __forceinline__ int row16_allmax(int x) {
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));
@@ -1237,8 +1244,12 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     if (e_lo > j0) e_first = j0 + (e_lo - j0 + jstep - 1) / jstep * jstep;
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     unsigned n_edges = 0, n_conn = 0;  // wave-uniform
-    for (int e = e_first + l16 * jstep;; e += 16 * jstep) {
-        const bool have = e < e_hi;
+    // A round takes `width` queue records per group: 1, 2, 4, 8, then 16 — in the first rounds nothing is connected yet and
+    // everything a wave looks at has to be checked, so they are kept short until the first unions have gone in
+    int width = 1;
+    for (int e0 = e_first;; e0 += width * jstep, width = min(16, width * 2)) {
+        const int e = e0 + l16 * jstep;
+        const bool have = l16 < width && e < e_hi;
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
         int4 rec = make_int4(0, 0, 0, 0);
         int2 kk = make_int2(0, 0);
@@ -1832,115 +1843,183 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 //   the row's records and queues every member that passes the second level, once (see there).  Exact: sharing a prefix
 //   element is a necessary condition, so is the signature level, the verify is exact, and every pair is queued once.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned long long PG_SENTINEL = 1ull << 49;  // above every element key; + a unique number
+// Record keys are 32 bits: token + 1 for a prefix element, 0 for the SHORT record, PG_NONE for "no such record".
+// Elements are DISTINCT tokens: a repeated token counts once (capping multiplicities is a contraction of the distance —
+// |min(a,1) - min(b,1)| <= |a - b| per token — so rows within max_dist stay within max_dist and the filter stays valid; a
+// row's records then have distinct keys).  The radix sort is stable and the records are written row by row: a group lists
+// its rows ascending, a row looks at the members BEHIND it, and every unordered pair is seen from its smaller row.
+constexpr uint32_t PG_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - PG_CNT_BITS); }
 
+// bind-time helper of the path: the largest token id (sets the number of key bits to sort)
+__global__ __launch_bounds__(256) void k_maxtok(const uint32_t *__restrict__ indices, int nnz, int *out) {
+    int m = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nnz; i += gridDim.x * 256) m = max(m, (int)(indices[i] & 0x7FFFFFFFu));
+    for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+// Token counts over a sample of the rows (every stride-th row), 16 lanes per row, 64 rows per block.  A token that nearly every
+// row carries would take thousands of adds to one address, one after the other (96 us of this kernel with one global add per
+// occurrence): the block first counts in LDS — a direct-mapped table of counter slots, a slot that is taken by another counter
+// sends the add to memory — and then adds what it holds, once per counter.  The totals are exact whatever the order.
 __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int stride,
                                                 uint32_t *__restrict__ cnt, Counters *ctr) {
-    const int r = (blockIdx.x * 256 + threadIdx.x) * stride;
+    constexpr int LT = 2048, ROWS = 4;  // LDS slots; rows per 16-lane group
+    __shared__ int l_tag[LT];
+    __shared__ unsigned l_cnt[LT];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->pg_est = 0ull;
         ctr->pg_fail = 0;
     }
-    if (r >= n) return;
-    for (int j = indptr[r], e = indptr[r + 1]; j < e; j++) atomicAdd(&cnt[pg_cnt_slot(indices[j])], 1u);
+    for (int i = threadIdx.x; i < LT; i += 256) {
+        l_tag[i] = -1;
+        l_cnt[i] = 0u;
+    }
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    for (int q = 0; q < ROWS; q++) {
+        const long long r = (long long)((blockIdx.x * ROWS + q) * 16 + (threadIdx.x >> 4)) * stride;
+        if (r >= n) continue;
+        for (int j = indptr[r] + l16, e = indptr[r + 1]; j < e; j += 16) {
+            const int slot = (int)pg_cnt_slot(indices[j] & 0x7FFFFFFFu);
+            const int i = slot & (LT - 1);
+            const int old = atomicCAS(&l_tag[i], -1, slot);
+            if (old == -1 || old == slot) atomicAdd(&l_cnt[i], 1u);
+            else atomicAdd(&cnt[slot], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LT; i += 256)
+        if (l_tag[i] >= 0) atomicAdd(&cnt[l_tag[i]], l_cnt[i]);
 }
 
-// one lane per row: the row's `recs - 1` first elements in the global order (kept in a sorted register list), as keys
-//   (sampled count, saturated : 0x7FFFFFFF - token : occurrence, saturated) + 1   — smaller = earlier in the order
-__global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int nnz,
-                                                int recs, int max_dist, const uint32_t *__restrict__ cnt,
-                                                unsigned long long *__restrict__ keys, int *__restrict__ rows, Counters *ctr) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r == 0) {
+// 16 lanes per row: the row's max_dist + 1 first DISTINCT tokens in the global order (sampled count, then the higher token
+// id: vocabulary ids are handed out by first appearance, higher = newer = rarer), by repeated minimum over the group —
+// the tokens are read once, coalesced, 64 at a time; lane i of the group ends up with the i-th element.  The order value
+// of a token is 32 bits: (sampled count, saturated) above (2^tb - 2 - token), tb = bits of the largest token id + 2.
+__global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
+                                                int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
+                                                int *__restrict__ rows, Counters *ctr) {
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->n_work = (unsigned)((n + 63) >> 6);  // work items of k_pgjoin: blocks of 64 rows (k_cells left its tile count here)
         ctr->pairs_filtered = 0ull;
     }
-    if (r >= n) return;
-    const int b = indptr[r], e = indptr[r + 1];
-    constexpr int L = PG_MAX_DIST + 1;
-    unsigned long long lst[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) lst[i] = ~0ull;
-    for (int j = b; j < e; j++) {  // (rows are short, the CSR is L2-resident)
-        const uint32_t t = indices[j] & 0x7FFFFFFFu;
-        const unsigned long long base = ((unsigned long long)min(cnt[pg_cnt_slot(t)], 4094u) << 37) | ((unsigned long long)(0x7FFFFFFFu - t) << 6);
-        int m = 0;  // occurrences of this token already in the list
-#pragma unroll
-        for (int i = 0; i < L; i++) m += (lst[i] >> 6) == (base >> 6) ? 1 : 0;
-        if (m > 63) continue;  // (multiplicities are capped at 64: a contraction, the bound stays valid)
-        unsigned long long key = base | (unsigned long long)m;
-        if (key >= lst[L - 1]) continue;
-#pragma unroll
-        for (int i = 0; i < L; i++) {  // insert, keeping the list ascending
-            const unsigned long long lo = min(lst[i], key), hi = max(lst[i], key);
-            lst[i] = lo;
-            key = hi;
-        }
-    }
+    // (no early return: the groups of a wave run the DPP reductions together)
+    const bool live = r < n;
+    const int b = live ? indptr[r] : 0, e = live ? indptr[r + 1] : 0;
+    const uint32_t cmax = (1u << (32 - tb)) - 1u, tinv = (1u << tb) - 2u;
     const int pre = recs - 1;  // = max_dist + 1
+    uint32_t sel = 0xFFFFFFFFu;  // lane i < pre: the i-th element so far
+    for (int c0 = b;; c0 += 64) {
+        if (__builtin_amdgcn_ballot_w64(c0 < e) == 0ull) break;  // wave-uniform: until every group of the wave is through its row
+        uint32_t v[4];
 #pragma unroll
-    for (int i = 0; i < L; i++)
-        if (i < pre) {
-            keys[(size_t)r * recs + i] = lst[i] != ~0ull ? lst[i] + 1ull : (PG_SENTINEL | (unsigned long long)((size_t)r * recs + i));
-            rows[(size_t)r * recs + i] = r * recs + i;  // the sort carries (row, slot)
+        for (int st = 0; st < 4; st++) {
+            const int j = c0 + st * 16 + l16;
+            v[st] = 0xFFFFFFFFu;
+            if (j < e) {
+                const uint32_t t = indices[j] & 0x7FFFFFFFu;
+                v[st] = (min(cnt[pg_cnt_slot(t)], cmax) << tb) | (tinv - t);
+            }
         }
-    // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
-    // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
-    keys[(size_t)r * recs + pre] = (e - b) <= 2 * max_dist ? 0ull : (PG_SENTINEL | (unsigned long long)((size_t)r * recs + pre));
-    rows[(size_t)r * recs + pre] = r * recs + pre;
+        uint32_t carry = sel, nsel = 0xFFFFFFFFu;
+        for (int i = 0; i < pre; i++) {
+            const uint32_t m = row16_allmin_u(min(min(min(v[0], v[1]), min(v[2], v[3])), carry));
+#pragma unroll
+            for (int st = 0; st < 4; st++) v[st] = v[st] == m ? 0xFFFFFFFFu : v[st];  // every copy of the token leaves
+            carry = carry == m ? 0xFFFFFFFFu : carry;
+            if (l16 == i) nsel = m;
+        }
+        sel = nsel;
+    }
+    if (!live) return;
+    if (l16 < pre) {
+        keys[(size_t)r * recs + l16] = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
+        rows[(size_t)r * recs + l16] = r * recs + l16;  // the sort carries (row, slot)
+    } else if (l16 == pre) {
+        // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
+        // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
+        keys[(size_t)r * recs + pre] = (e - b) <= 2 * max_dist ? 0u : PG_NONE;
+        rows[(size_t)r * recs + pre] = r * recs + pre;
+    }
 }
 
 // one thread per position of the sorted records: {row, length, second-level signature} of the position's row in group
-// order (k_pgjoin reads the members of a group as one coalesced stream), and where each record of a row went
-__global__ __launch_bounds__(256) void k_pgplace(const unsigned long long *__restrict__ keys_s, const int *__restrict__ vals_s, int total,
+// order (k_pgjoin reads the members of a group as one coalesced stream), and for every record of a row where it went and
+// how many members its group has BEHIND it — the walk of a row is then a list of chunks known in advance, whose loads can
+// be in flight together.  The end of a position's group: the next position whose key differs, found by a suffix minimum
+// over the block, and from the block's last position by galloping over the sorted keys.
+__global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s, const int *__restrict__ vals_s, int total,
                                                  int recs, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu2,
-                                                 int4 *__restrict__ srec, int *__restrict__ recpos, Counters *ctr) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
-    const int v = vals_s[p];
-    const int row = v / recs;
-    srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
-    recpos[v] = p;
-    if ((p & (PG_EST_STRIDE - 1)) == 0) {
-        // every PG_EST_STRIDE-th position measures what k_pgjoin would walk from it — the members of its group behind it
-        // (gallop + bisect over the sorted keys) — so that the walk can be called off when the groups are too big
-        const unsigned long long key = keys_s[p];
-        int lo = p, hi = total;  // last position of the group in [lo, hi)
-        if (key < PG_SENTINEL) {
-            int step = 1;
+                                                 int4 *__restrict__ srec, int2 *__restrict__ recpos, Counters *ctr) {
+    __shared__ int s_nh[256];
+    const int t = threadIdx.x, p = blockIdx.x * 256 + t;
+    const bool inb = p < total;
+    const uint32_t key = inb ? keys_s[p] : PG_NONE;
+    int row = 0, v = 0;
+    if (inb) {
+        v = vals_s[p];
+        row = v / recs;
+        srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
+    }
+    // first position behind p that starts another group, if the block can tell
+    int nh = !inb ? total : ((p + 1 < total && keys_s[p + 1] == key) ? 0x7FFFFFFF : p + 1);
+    if (t == 255 && nh == 0x7FFFFFFF) {
+        if (key == PG_NONE) {
+            nh = total;
+        } else {  // the group goes on behind the block: gallop, then bisect
+            int lo = p + 1, step = 1;  // keys_s[lo] == key
             while (lo + step < total && keys_s[lo + step] == key) {
                 lo += step;
                 step <<= 1;
             }
-            hi = min(total, lo + step);
+            int hi = min(total, lo + step);
             while (hi - lo > 1) {
                 const int mid = lo + ((hi - lo) >> 1);
                 if (keys_s[mid] == key) lo = mid;
                 else hi = mid;
             }
-            if (lo > p) atomicAdd(&ctr->pg_est, (unsigned long long)(lo - p));
+            nh = lo + 1;
         }
     }
+    s_nh[t] = nh;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // suffix minimum
+        const int o = t + off < 256 ? s_nh[t + off] : 0x7FFFFFFF;
+        __syncthreads();
+        nh = min(nh, o);
+        s_nh[t] = nh;
+        __syncthreads();
+    }
+    if (!inb || key == PG_NONE) return;
+    const int behind = nh - p - 1;
+    recpos[v] = make_int2(p, behind);
+    // every PG_EST_STRIDE-th position reports what k_pgjoin will walk from it, so that the walk can be called off when the
+    // groups are too big
+    if ((p & (PG_EST_STRIDE - 1)) == 0 && behind > 0) atomicAdd(&ctr->pg_est, (unsigned long long)behind);
 }
 
 // k_pgjoin: candidates of the prefix-group path, row by row.  One wave per row A: its records in the global order (the SHORT
-// record first, then the prefix elements), and for each the members BEHIND A's record in that record's group — the radix
-// sort is stable and the records were written row by row, so a group lists its rows ascending and every unordered pair is
-// seen from its smaller row.  A member B passes the second level (length difference and 64-bit signature distance within
-// max_dist) or is dropped; a pair must be queued once although its rows share several prefix elements: the FIRST element
-// they share is the first of A's records in whose group B shows up, so "seen in an earlier group of A" is the whole test —
-// a hash set in the wave's LDS, holding only members that passed (a row has ~16 of those at max_dist 5).  A set that
-// fills up (a hub row with thousands of neighbours) stops taking entries; from then on a member that is not in it is
-// checked the slow, equally exact way: is one of A's earlier elements among B's records.
+// record first, then the prefix elements), and for each the members behind A's record in that record's group.  A member B
+// passes the second level (length difference and 64-bit signature distance within max_dist) or is dropped; a pair must be
+// queued once although its rows share several prefix elements: the FIRST element they share is the first of A's records in
+// whose group B shows up, so "seen in an earlier group of A" is the whole test — a hash set in the wave's LDS, holding only
+// members that passed (a row has ~16 of those at max_dist 5).  A set that fills up (a hub row with thousands of neighbours)
+// stops taking entries; from then on a member that is not in it is checked the slow, equally exact way: is one of A's
+// earlier elements among B's records.
+// The members behind the row's records are a list of chunks of up to 64 positions that is known before the first load
+// (k_pgplace counted them): two chunks are in flight while a third is worked on, and the head of the NEXT row (its records'
+// positions and counts, its length and signature) is requested before the current row is walked.
 // Work items are blocks of 64 rows (t_begin / t_end and the multi-GPU owner rule count in those).
-__global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__restrict__ keys_s, const int4 *__restrict__ srec,
-                                                const int *__restrict__ recpos, const unsigned long long *__restrict__ keys, int n,
-                                                int recs, int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
+__global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
+                                                const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sigu2, int n, int recs,
+                                                int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
     constexpr int SCAP = 1024, WAVES = 4;
     // A token that many rows carry can still be among a row's first d + 1 (small alphabets, random rows): the groups are then a
-    // large part of all rows and walking them is quadratic.  k_pgplace measured the walk from every PG_EST_STRIDE-th position
+    // large part of all rows and walking them is quadratic.  k_pgplace reported the walk from every PG_EST_STRIDE-th position
     // of the sorted records: beyond PG_GIVE_UP members per row the kernel does nothing and the host redoes the step on the
     // band kernels (and keeps this CSR there).
     if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
@@ -1991,64 +2070,90 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
         nq = 0;
     };
     const int r_begin = t_begin * 64, r_end = min(n, (int)min((long long)t_end * 64, (long long)n));
-    for (int A = r_begin + blockIdx.x * WAVES + wave; A < r_end; A += (int)gridDim.x * WAVES) {
-        if (nshards > 1 && ((A >> 6) % nshards) != shard0) continue;  // another rank's block of rows
-        // lane i < recs: record i of A (position, key); the order to walk them: SHORT record (key 0) first, then 0 .. recs - 2
-        int mypos = 0;
-        unsigned long long mykey = ~0ull;
+    const int stride = (int)gridDim.x * WAVES;
+    auto owned_from = [&](int A) {  // the first row at or behind A (in steps of the wave's stride) that is this rank's
+        while (nshards > 1 && A < r_end && ((A >> 6) % nshards) != shard0) A += stride;
+        return A;
+    };
+    struct RowHead {
+        uint32_t key;  // lane i < recs: record i of the row
+        int2 pos;      // ... where it is in the group order, members behind it (stale for a record that does not exist)
+        int len;
+        uint32_t s0, s1;
+    };
+    auto load_head = [&](int A) {
+        RowHead h;
+        h.key = PG_NONE;
+        h.pos = make_int2(0, 0);
         if (lane < recs) {
-            mypos = recpos[(size_t)A * recs + lane];
-            mykey = keys_s[mypos];
+            h.key = keys[(size_t)A * recs + lane];
+            h.pos = recpos[(size_t)A * recs + lane];
         }
-        const int4 arec = srec[__builtin_amdgcn_readfirstlane(mypos)];  // {A, k_A, signature}
-        // the records to walk, as a mask over the STEPS (step 0 = the SHORT record in slot recs - 1, step i = slot i - 1)
-        const unsigned long long vm = __builtin_amdgcn_ballot_w64(lane < recs && (lane == recs - 1 ? mykey == 0ull : mykey < PG_SENTINEL));
+        h.len = pa.indptr[A + 1] - pa.indptr[A];
+        h.s0 = sigu2[(size_t)A * 2];
+        h.s1 = sigu2[(size_t)A * 2 + 1];
+        return h;
+    };
+    int A = owned_from(r_begin + blockIdx.x * WAVES + wave);
+    RowHead cur{PG_NONE, make_int2(0, 0), 0, 0u, 0u};
+    if (A < r_end) cur = load_head(A);
+    for (; A < r_end;) {
+        const int A_next = owned_from(A + stride);
+        RowHead nxt{PG_NONE, make_int2(0, 0), 0, 0u, 0u};
+        if (A_next < r_end) nxt = load_head(A_next);
+        const int A_now = A;
+        const RowHead hd = cur;
+        cur = nxt;
+        A = A_next;
+        const int len_a = hd.len;
+        const uint32_t sa0 = hd.s0, sa1 = hd.s1;
+        // the records to walk (those with members behind them), as a mask over the STEPS: step 0 = the SHORT record in slot
+        // recs - 1, step i = slot i - 1
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(hd.key != PG_NONE && hd.pos.y > 0);
         unsigned om = (unsigned)((vm >> (recs - 1)) & 1ull) | ((unsigned)(vm & ((1ull << (recs - 1)) - 1ull)) << 1);
         if (om == 0u) continue;
         int n_in = 0;         // entries of the set (wave-uniform)
         bool full = false;    // the set stopped taking entries
-        // first chunk of the first record; while a record is worked on, the first chunk of the next one is already under way
-        // (most groups end inside their first chunk: the walk of a row is one dependent load deep instead of one per record)
-        int step = __builtin_ctz(om);
-        om &= om - 1u;
-        int slot = step == 0 ? recs - 1 : step - 1;
-        unsigned long long x = __shfl(mykey, slot);
-        int p = __shfl(mypos, slot);
-        unsigned long long kq = p + 1 + lane < total ? keys_s[p + 1 + lane] : ~0ull;
-        int4 rec = p + 1 + lane < total ? srec[p + 1 + lane] : make_int4(0, 0, 0, 0);
-        for (;;) {
-            const bool have_next = om != 0u;
-            int step_n = 0, p_n = 0;
-            unsigned long long x_n = 0ull, kq_n = ~0ull;
-            int4 rec_n = make_int4(0, 0, 0, 0);
-            if (have_next) {
-                step_n = __builtin_ctz(om);
+        // the chunk list: (first position, members, step) one after the other (wave-uniform scalars)
+        int g_p = 0, g_left = 0, g_step = 0;
+        auto next_chunk = [&](int &p, int &cnt, int &step) {
+            if (g_left == 0) {
+                if (om == 0u) return false;
+                g_step = __builtin_ctz(om);
                 om &= om - 1u;
-                const int slot_n = step_n - 1;  // (only the first step can be the SHORT record)
-                x_n = __shfl(mykey, slot_n);
-                p_n = __shfl(mypos, slot_n);
-                if (p_n + 1 + lane < total) {
-                    kq_n = keys_s[p_n + 1 + lane];
-                    rec_n = srec[p_n + 1 + lane];
-                }
+                const int slot = g_step == 0 ? recs - 1 : g_step - 1;
+                g_p = __shfl(hd.pos.x, slot) + 1;
+                g_left = __shfl(hd.pos.y, slot);
             }
-            for (int q0 = p + 1;; q0 += 64) {
-                const int q = q0 + lane;
-                const bool inb = q < total;
-                if (q0 != p + 1) {
-                    kq = inb ? keys_s[q] : ~0ull;
-                    rec = inb ? srec[q] : make_int4(0, 0, 0, 0);
-                }
-                const bool same = inb && kq == x;
-                const unsigned long long sm = __builtin_amdgcn_ballot_w64(same);
-                if (sm == 0ull) break;
-                visits += (unsigned long long)__popcll(sm);
-                const int B = rec.x;
-                bool pass = same && abs(rec.y - arec.y) <= d &&
-                            __popc((uint32_t)(rec.z ^ arec.z)) + __popc((uint32_t)(rec.w ^ arec.w)) <= d;
+            p = g_p;
+            cnt = min(64, g_left);
+            step = g_step;
+            g_p += cnt;
+            g_left -= cnt;
+            return true;
+        };
+        int p0 = 0, c0 = 0, st0 = 0, p1 = 0, c1 = 0, st1 = 0, p2 = 0, c2 = 0, st2 = 0;
+        bool h0 = next_chunk(p0, c0, st0);
+        int4 rec0 = h0 && lane < c0 ? srec[p0 + lane] : make_int4(0, 0, 0, 0);
+        bool h1 = next_chunk(p1, c1, st1);
+        int4 rec1 = h1 && lane < c1 ? srec[p1 + lane] : make_int4(0, 0, 0, 0);
+        while (h0) {
+            const bool h2 = next_chunk(p2, c2, st2);
+            const int4 rec2 = h2 && lane < c2 ? srec[p2 + lane] : make_int4(0, 0, 0, 0);
+            {
+                const int4 rec = rec0;
+                const int step = st0;
+                visits += (unsigned long long)c0;
+                const int B = rec.x, len_b = rec.y;
+                bool pass = lane < c0 && abs(len_b - len_a) <= d && __popc((uint32_t)rec.z ^ sa0) + __popc((uint32_t)rec.w ^ sa1) <= d;
+                if (pa.dbg & 64) pass = false;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
                 // seen in an earlier group of A?  (members of one group are distinct rows: no two lanes insert the same B)
                 bool fresh = false, unknown = false;
-                if (pass) {
+                if (pa.dbg & 256) {  // (BFK_PF_DEBUG=256: no set, every member that passes is queued; timing experiments)
+                    fresh = pass;
+                } else if (pass) {
+                    // (the set by plain LDS reads and writes — read, write if empty, read back — instead of the compare-and-swap
+                    // was 5.1 ms against 2.25 for this kernel at 1M rows, max_dist 5: three dependent LDS round trips per probe)
                     uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 22;  // SCAP = 1024 slots
                     for (;;) {
                         const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
@@ -2065,16 +2170,15 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
                     // the slow exact test: one of A's earlier elements among B's records
                     bool dup = false;
                     if (unknown) {
-                        const unsigned long long *kb = keys + (size_t)B * recs;
-                        unsigned long long kbv[PG_MAX_DIST + 2];
+                        const uint32_t *kb = keys + (size_t)B * recs;
+                        uint32_t gb[PG_MAX_DIST + 2];
 #pragma unroll
-                        for (int j = 0; j < PG_MAX_DIST + 2; j++) kbv[j] = j < recs ? kb[j] : ~0ull;
+                        for (int j = 0; j < PG_MAX_DIST + 2; j++) gb[j] = j < recs ? kb[j] : PG_NONE;
                         for (int e2 = 0; e2 < step; e2++) {
-                            const int sl2 = e2 == 0 ? recs - 1 : e2 - 1;
-                            const unsigned long long y = keys[(size_t)A * recs + sl2];
-                            if (y >= PG_SENTINEL || (e2 == 0 && y != 0ull)) continue;
+                            const uint32_t y = keys[(size_t)A_now * recs + (e2 == 0 ? recs - 1 : e2 - 1)];
+                            if (y == PG_NONE) continue;
 #pragma unroll
-                            for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || kbv[j] == y;
+                            for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || gb[j] == y;
                         }
                     }
                     fresh = fresh || (unknown && !dup);
@@ -2086,17 +2190,13 @@ __global__ __launch_bounds__(256) void k_pgjoin(const unsigned long long *__rest
                 if (fm != 0ull) {
                     const int nf = __popcll(fm);
                     if (nq + nf > 64) flush();
-                    if (fresh) sq[nq + below(fm)] = make_int4(A, B, arec.y, rec.y);
+                    if (fresh) sq[nq + below(fm)] = make_int4(A_now, B, len_a, len_b);
                     nq += nf;
+                    if (pa.dbg & 128) nq = 0;  // (BFK_PF_DEBUG=128: nothing is queued; timing experiments, results invalid)
                 }
-                if (__builtin_amdgcn_ballot_w64(inb && !same) != 0ull || !__builtin_amdgcn_ballot_w64(inb)) break;  // the group ended in this chunk
             }
-            if (!have_next) break;
-            step = step_n;
-            p = p_n;
-            x = x_n;
-            kq = kq_n;
-            rec = rec_n;
+            h0 = h1; p0 = p1; c0 = c1; st0 = st1; rec0 = rec1;
+            h1 = h2; p1 = p2; c1 = c2; st1 = st2; rec1 = rec2;
         }
         // clean the set for the next row
         if (n_in > 0 || full)
@@ -2201,6 +2301,13 @@ __global__ void k_changed(const int *__restrict__ labels, const int *__restrict_
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_maxlen, dim3((n + 255) / 256), dim3(256), 0, st, indptr, n, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st) {
+    if (nnz <= 0) return 0;
+    hipLaunchKernelGGL(k_maxtok, dim3(std::min(4096, (nnz + 255) / 256)), dim3(256), 0, st, indices, nnz, out);
     LAUNCH_CHECK();
     return 0;
 }
@@ -2323,7 +2430,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
         const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
-        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_keys_s, pl.pg_srec, pl.pg_recpos, pl.pg_keys, n, pl.pg_recs,
+        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.sigu2, n, pl.pg_recs,
                            n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
@@ -2452,13 +2559,13 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
         const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
         const int sampled = (n + stride - 1) / stride;
-        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
+        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pgkeys, dim3((n + 255) / 256), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.nnz, pl.pg_recs, pl.d, pl.pg_cnt,
+        hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
                            pl.pg_keys, pl.pg_rows, pl.ctr);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, PG_SORT_BITS, st))
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
             return e;
         hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.indptr,
                            pl.sigu2, pl.pg_srec, pl.pg_recpos, pl.ctr);

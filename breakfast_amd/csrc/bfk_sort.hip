@@ -1,6 +1,7 @@
-// bfk_sort.hip — the one library primitive of the prefix-group path: a device radix sort of (64-bit key, row) records
+// bfk_sort.hip — the one library primitive of the prefix-group path: a device radix sort of (32-bit key, row) records
 // (rocPRIM, header-only).  In a translation unit of its own: the rocPRIM templates take longer to compile than all
 // of bfk_kernels.hip.
+#include <cstdint>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -9,7 +10,7 @@
 namespace bfk {
 
 // temp == nullptr: only *temp_bytes is set.  Sorts by key bits [0, bits); keys_in / rows_in stay intact.
-int sort_records(void *temp, size_t *temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const int *rows_in,
+int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st) {
     return (int)rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, rows_in, rows_out, n, 0u, (unsigned)bits, st);
 }
