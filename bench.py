@@ -464,20 +464,30 @@ def main():
             comp_what = "4*nnz tokens + 4*N_u extents + 8*N_u row hashes, read once"
             step_bytes = (8 * nnz + 44 * n_u) / world
         elif prefix:
-            # prefix groups: the exact verify is the longest kernel; it must read both rows of every candidate
-            # (4 B per token) and the 24-byte queue record
+            # prefix groups.  What the two long kernels must move:
+            #   k_pgjoin: 16 B (row record) per group member visited, the row heads (recs * (4 B key + 8 B position/count) +
+            #   16 B length/signature per row), 24 B written + 8 B of row extents read per queued pair
+            #   verify: the 24-byte queue record + the two parent words of every candidate, both rows' tokens (4 B each) of
+            #   the candidates that are checked (all of them, or those not dropped as connected: counters.n_connected)
             recs = d + 2
+            R = recs * n_u / world
+            checked = st["n_candidates"] - st.get("n_connected", 0)
+            b_verify = st["n_candidates"] * 32 + checked * 8 * k_mean
+            b_pgjoin = st["pairs_filtered"] * 16 + 12 * R + 16 * n_u / world + st["n_candidates"] * 32
             if st["ms_verify"] >= st["ms_prefilter"]:
-                dom = "k_verify"
+                dom = "k_verify_connected" if st.get("n_connected", 0) else "k_verify"
                 t_dom = st["ms_verify"] * 1e-3
-                comp = st["n_candidates"] * (8 * k_mean + 24)
-                comp_what = "per candidate: both rows' tokens (8*k_mean B) + its 24-byte queue record"
+                comp = b_verify
+                comp_what = ("per candidate: 24-byte queue record + 2 parent words; per candidate checked exactly (n_candidates - "
+                             "n_connected): both rows' tokens (8*k_mean B)")
             else:
                 dom = "k_pgjoin"
-                comp = st["pairs_filtered"] * 24 + 12 * recs * n_u / world
-                comp_what = "24 B per group member visited (8-byte key + 16-byte row record) + the row's record positions and keys"
-            step_bytes = (2 * 4 * nnz + (84 + 16 * w) * n_u + 2 * 12 * recs * n_u * 8 + 36 * recs * n_u) / world + \
-                st["pairs_filtered"] * 24 + st["n_candidates"] * (8 * k_mean + 48)
+                comp = b_pgjoin
+                comp_what = ("16 B per group member visited + per row 12 B per record (key, position, count) and 16 B of length / "
+                             "signature + 32 B per queued pair (record written, row extents read)")
+            # + band prep that still runs (k_sig .. k_place: tokens once, signatures / keys), k_pgkeys (tokens once, 8 B per
+            # record out), three radix passes (8 B per record in and out each), k_pgplace (8 B in, 16 B gathered, 24 B out)
+            step_bytes = (2 * 4 * nnz + (84 + 16 * w) * n_u) / world + 8 * R + 3 * 16 * R + 48 * R + b_pgjoin + b_verify
         else:
             dom = f"k_prefilter<W={w}>"
             comp = (4 * w * n_u + 16 * n_u) / world
@@ -485,7 +495,7 @@ def main():
             step_bytes = (4 * nnz + (84 + 16 * w) * n_u) / world
         achieved = comp / t_dom / 1e9 if t_dom > 0 else None
         wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'prefix' if prefix else 'allpairs'}"
-        tr = measured_traffic("bfk::k_join" if join else "void bfk::k_verify" if (prefix and dom == "k_verify") else
+        tr = measured_traffic("bfk::k_join" if join else ("void bfk::" + dom) if (prefix and dom.startswith("k_verify")) else
                               "bfk::k_pgjoin" if prefix else "void bfk::k_prefilter", wl_key) if world == 1 else None
         roof = {
             "bound": "hbm", "kernel": dom,
@@ -519,7 +529,8 @@ def main():
         elif join:
             roof["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
         else:
-            roof["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges": st["n_edges"],
+            roof["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges_checked": st["n_edges"],
+                              "dropped_as_connected": st.get("n_connected", 0),
                               "note": "prefix groups: candidates come from the groups of the rows' rarest tokens (no band scan); the "
                                       "step is bound by the exact verify of the candidates and by round trips, not by VALU or HBM"}
         out = {
@@ -542,7 +553,7 @@ def main():
                 "workload_key": wl_key, "kernel_source_digest": kernel_source_digest(),
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
                 "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else
-                                   "prefix groups (k_pgkeys .. radix sort .. k_pgjoin .. k_verify, DESIGN 6d)" if prefix else
+                                   "prefix groups (k_pgkeys .. radix sort .. k_pgplace .. k_pgjoin .. k_verify_connected, DESIGN 6d/6e)" if prefix else
                                    "all-pairs band kernels (k_sig .. k_prefilter .. k_verify)"),
                 "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
                              f"blocks of 64 rows (the walks of their groups) round-robin over {world} rank(s)" if prefix else

@@ -101,6 +101,7 @@ struct Plan {
     void *pg_temp;
     size_t pg_temp_bytes;
     int4 *pg_srec;       // {row, length, second-level signature} in group order
+    int4 *pg_rowinfo;    // [n]: {length, second-level signature, first token}
     int2 *pg_recpos;     // [n][recs]: {position of the record in the group order, members of its group behind it}
     int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter

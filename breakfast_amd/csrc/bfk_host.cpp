@@ -109,8 +109,8 @@ struct bfk_ctx {
     int *pg_rows = nullptr, *pg_rows_s = nullptr;
     int2 *pg_recpos = nullptr;
     void *pg_temp = nullptr;
-    int4 *pg_srec = nullptr;
-    int64_t pg_rec_cap = 0, pg_temp_cap = 0;
+    int4 *pg_srec = nullptr, *pg_rowinfo = nullptr;
+    int64_t pg_rec_cap = 0, pg_temp_cap = 0, pg_rowinfo_cap = 0;
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
     int join_empty_shard = -1, join_empty_shards = 0;
@@ -179,7 +179,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt};
+                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -469,6 +469,7 @@ static int pg_key_bits(bfk_ctx *c, int *tb_out) {
 static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
     const int64_t total = c->n * recs;
     if (!c->pg_cnt && hipMalloc((void **)&c->pg_cnt, sizeof(uint32_t) << PG_CNT_BITS) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc(token counts) failed");
+    if (int rc = dev_realloc(&c->pg_rowinfo, &c->pg_rowinfo_cap, c->n + SIG_PAD_ROWS)) return rc;
     if (total > c->pg_rec_cap) {
         int64_t cap;
         int rc = 0;
@@ -658,6 +659,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.pg_temp_bytes = tb;
         pl.pg_srec = c->pg_srec;
         pl.pg_recpos = c->pg_recpos;
+        pl.pg_rowinfo = c->pg_rowinfo;
     }
     c->plan = pl;
     if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step

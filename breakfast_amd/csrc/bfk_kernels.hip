@@ -1901,7 +1901,8 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
 // of a token is 32 bits: (sampled count, saturated) above (2^tb - 2 - token), tb = bits of the largest token id + 2.
 __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
-                                                int *__restrict__ rows, Counters *ctr) {
+                                                int *__restrict__ rows, const uint32_t *__restrict__ sigu2, int4 *__restrict__ rowinfo,
+                                                Counters *ctr) {
     const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->n_work = (unsigned)((n + 63) >> 6);  // work items of k_pgjoin: blocks of 64 rows (k_cells left its tile count here)
@@ -1936,6 +1937,9 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
         sel = nsel;
     }
     if (!live) return;
+    // {length, second-level signature, first token} of the row in one 16-byte record: what k_pgplace gathers per position and
+    // k_pgjoin per row
+    if (l16 == 15) rowinfo[r] = make_int4(e - b, (int)sigu2[(size_t)r * 2], (int)sigu2[(size_t)r * 2 + 1], b);
     if (l16 < pre) {
         keys[(size_t)r * recs + l16] = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
         rows[(size_t)r * recs + l16] = r * recs + l16;  // the sort carries (row, slot)
@@ -1953,8 +1957,8 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
 // be in flight together.  The end of a position's group: the next position whose key differs, found by a suffix minimum
 // over the block, and from the block's last position by galloping over the sorted keys.
 __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s, const int *__restrict__ vals_s, int total,
-                                                 int recs, const int *__restrict__ indptr, const uint32_t *__restrict__ sigu2,
-                                                 int4 *__restrict__ srec, int2 *__restrict__ recpos, Counters *ctr) {
+                                                 int recs, const int4 *__restrict__ rowinfo, int4 *__restrict__ srec,
+                                                 int2 *__restrict__ recpos, Counters *ctr) {
     __shared__ int s_nh[256];
     const int t = threadIdx.x, p = blockIdx.x * 256 + t;
     const bool inb = p < total;
@@ -1963,7 +1967,8 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
     if (inb) {
         v = vals_s[p];
         row = v / recs;
-        srec[p] = make_int4(row, indptr[row + 1] - indptr[row], (int)sigu2[(size_t)row * 2], (int)sigu2[(size_t)row * 2 + 1]);
+        const int4 ri = rowinfo[row];
+        srec[p] = make_int4(row, ri.x, ri.y, ri.z);
     }
     // first position behind p that starts another group, if the block can tell
     int nh = !inb ? total : ((p + 1 < total && keys_s[p + 1] == key) ? 0x7FFFFFFF : p + 1);
@@ -2015,7 +2020,7 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
 // positions and counts, its length and signature) is requested before the current row is walked.
 // Work items are blocks of 64 rows (t_begin / t_end and the multi-GPU owner rule count in those).
 __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
-                                                const uint32_t *__restrict__ keys, const uint32_t *__restrict__ sigu2, int n, int recs,
+                                                const uint32_t *__restrict__ keys, const int4 *__restrict__ rowinfo, int n, int recs,
                                                 int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
     constexpr int SCAP = 1024, WAVES = 4;
     // A token that many rows carry can still be among a row's first d + 1 (small alphabets, random rows): the groups are then a
@@ -2089,9 +2094,10 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
             h.key = keys[(size_t)A * recs + lane];
             h.pos = recpos[(size_t)A * recs + lane];
         }
-        h.len = pa.indptr[A + 1] - pa.indptr[A];
-        h.s0 = sigu2[(size_t)A * 2];
-        h.s1 = sigu2[(size_t)A * 2 + 1];
+        const int4 ri = rowinfo[A];
+        h.len = ri.x;
+        h.s0 = (uint32_t)ri.y;
+        h.s1 = (uint32_t)ri.z;
         return h;
     };
     int A = owned_from(r_begin + blockIdx.x * WAVES + wave);
@@ -2430,7 +2436,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
         const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
-        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.sigu2, n, pl.pg_recs,
+        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
                            n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
@@ -2562,13 +2568,13 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
-                           pl.pg_keys, pl.pg_rows, pl.ctr);
+                           pl.pg_keys, pl.pg_rows, pl.sigu2, pl.pg_rowinfo, pl.ctr);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
         if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
             return e;
-        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.indptr,
-                           pl.sigu2, pl.pg_srec, pl.pg_recpos, pl.ctr);
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
+                           pl.pg_srec, pl.pg_recpos, pl.ctr);
         LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[1], st);
