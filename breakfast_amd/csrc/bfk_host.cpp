@@ -854,7 +854,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             const int planes = c->kcap + 2;
             const size_t pitch = (size_t)c->fb * c->gb * c->hb * sizeof(int);
             std::vector<int> sk((size_t)planes);
-            if (c->plan.join) {  // no sorted order on the join path: count the row lengths from indptr
+            if (c->plan.join || c->plan.pg) {  // no cell histogram on the join / prefix-group paths: count the row lengths from indptr
                 std::vector<int> ip((size_t)n + 1);
                 HIP_TRY(hipMemcpy(ip.data(), c->d_indptr, ip.size() * 4, hipMemcpyDeviceToHost));
                 std::fill(sk.begin(), sk.end(), 0);

@@ -967,6 +967,13 @@ __device__ __forceinline__ uint32_t row16_allmin_u(uint32_t x) {
     x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false));
     return x;
 }
+__device__ __forceinline__ uint32_t row16_allxor(uint32_t x) {
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xF, 0xF, false);
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xF, 0xF, false);
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xF, 0xF, false);
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false);
+    return x;
+}
 __device__ __forceinline__ int row16_allmax(int x) {
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xF, 0xF, false));
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xF, 0xF, false));
@@ -1869,9 +1876,16 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
     constexpr int LT = 2048, ROWS = 4;  // LDS slots; rows per 16-lane group
     __shared__ int l_tag[LT];
     __shared__ unsigned l_cnt[LT];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctr->pg_est = 0ull;
-        ctr->pg_fail = 0;
+    if (blockIdx.x == 0) {  // the step's counters (the band kernels' k_cells does this on their path)
+        for (int i = threadIdx.x; i < CAND_SHARDS; i += 256) ctr->ncand[i] = 0;
+        if (threadIdx.x == 0) {
+            ctr->pg_est = 0ull;
+            ctr->pg_fail = 0;
+            ctr->err = 0;
+            ctr->overflow = 0;
+            ctr->n_edges = ctr->n_cand_total = ctr->n_edges_cap = ctr->n_connected = 0;
+            ctr->pairs_in_band = 0ull;
+        }
     }
     for (int i = threadIdx.x; i < LT; i += 256) {
         l_tag[i] = -1;
@@ -1901,7 +1915,7 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
 // of a token is 32 bits: (sampled count, saturated) above (2^tb - 2 - token), tb = bits of the largest token id + 2.
 __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
-                                                int *__restrict__ rows, const uint32_t *__restrict__ sigu2, int4 *__restrict__ rowinfo,
+                                                int *__restrict__ rows, int kcap, int *__restrict__ parent, int4 *__restrict__ rowinfo,
                                                 Counters *ctr) {
     const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1914,6 +1928,7 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
     const uint32_t cmax = (1u << (32 - tb)) - 1u, tinv = (1u << tb) - 2u;
     const int pre = recs - 1;  // = max_dist + 1
     uint32_t sel = 0xFFFFFFFFu;  // lane i < pre: the i-th element so far
+    uint32_t s2all = 0u, s2hi = 0u;  // the row's second-level signature (XOR parity of one of 64 bits per token, as k_sig's)
     for (int c0 = b;; c0 += 64) {
         if (__builtin_amdgcn_ballot_w64(c0 < e) == 0ull) break;  // wave-uniform: until every group of the wave is through its row
         uint32_t v[4];
@@ -1922,8 +1937,13 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
             const int j = c0 + st * 16 + l16;
             v[st] = 0xFFFFFFFFu;
             if (j < e) {
-                const uint32_t t = indices[j] & 0x7FFFFFFFu;
+                const uint32_t x = indices[j];
+                const uint32_t t = x & 0x7FFFFFFFu;
                 v[st] = (min(cnt[pg_cnt_slot(t)], cmax) << tb) | (tinv - t);
+                const uint32_t h2 = sig_h2(sig_h1(x));
+                const uint32_t bit2 = 1u << ((h2 >> 24) & 31);
+                s2all ^= bit2;
+                s2hi ^= (uint32_t)((int)(h2 << 2) >> 31) & bit2;  // bit 29 selects the word
             }
         }
         uint32_t carry = sel, nsel = 0xFFFFFFFFu;
@@ -1939,7 +1959,13 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
     if (!live) return;
     // {length, second-level signature, first token} of the row in one 16-byte record: what k_pgplace gathers per position and
     // k_pgjoin per row
-    if (l16 == 15) rowinfo[r] = make_int4(e - b, (int)sigu2[(size_t)r * 2], (int)sigu2[(size_t)r * 2 + 1], b);
+    s2all = row16_allxor(s2all);
+    s2hi = row16_allxor(s2hi);
+    if (l16 == 15) {
+        rowinfo[r] = make_int4(e - b, (int)(s2all ^ s2hi), (int)s2hi, b);
+        parent[r] = r;
+        if (e - b < 0 || e - b > kcap) atomicOr(&ctr->err_rows, ERR_ROWLEN);  // the CSR changed after the bind
+    }
     if (l16 < pre) {
         keys[(size_t)r * recs + l16] = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
         rows[(size_t)r * recs + l16] = r * recs + l16;  // the sort carries (row, slot)
@@ -2511,6 +2537,26 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         }
         return launch_flatten(pl, st, ev);
     }
+    if (pl.pg) {  // prefix-group path: sampled token counts, records (+ signatures, forest, counters), sort, group order — none of the band kernels' prep
+        const int total = n * pl.pg_recs;
+        if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
+        const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
+        const int sampled = (n + stride - 1) / stride;
+        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
+                           pl.pg_keys, pl.pg_rows, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr);
+        LAUNCH_CHECK();
+        size_t tb = pl.pg_temp_bytes;
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
+            return e;
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
+                           pl.pg_srec, pl.pg_recpos, pl.ctr);
+        LAUNCH_CHECK();
+            if (ev) (void)hipEventRecord(ev[1], st);
+        if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
+        return launch_flatten(pl, st, ev);
+    }
     KeyCfg key;
     key.fb = pl.fb;
     key.gb = pl.gb;
@@ -2560,23 +2606,6 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
             return -1;
     }
     LAUNCH_CHECK();
-    if (pl.pg) {  // prefix-group path: sampled token counts, records, sort, group order + tiles (the prep above supplied the signatures)
-        const int total = n * pl.pg_recs;
-        if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
-        const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
-        const int sampled = (n + stride - 1) / stride;
-        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
-                           pl.pg_keys, pl.pg_rows, pl.sigu2, pl.pg_rowinfo, pl.ctr);
-        LAUNCH_CHECK();
-        size_t tb = pl.pg_temp_bytes;
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
-            return e;
-        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
-                           pl.pg_srec, pl.pg_recpos, pl.ctr);
-        LAUNCH_CHECK();
-    }
     if (ev) (void)hipEventRecord(ev[1], st);
     if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
     return launch_flatten(pl, st, ev);
