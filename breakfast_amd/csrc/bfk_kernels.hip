@@ -1139,13 +1139,11 @@ __device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int l
 // separate insertions fail the single-shift certificate).
 template <int STEPS, bool WAVE_TABLE>
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap, int *blk_stats) {
-    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}
-    __shared__ unsigned int blk_edges, blk_cands;
+    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}: exactly 32 KiB per block with group tables,
+                                                              // five blocks per CU (the block's two counters live in it at the end)
     const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;  // 0..15 in the block
     uint2 *mt = tab[WAVE_TABLE ? (threadIdx.x >> 6) : grp];
-    if (threadIdx.x == 0) blk_edges = blk_cands = 0;
-    __syncthreads();
     // Group u of U (a multiple of CAND_SHARDS) works on queue shard u % CAND_SHARDS, entries j0, j0 + jstep, ..:
     // the slot is computed, not searched, and the shards fill evenly (the prefilter rotates over them).
     const int u = blockIdx.x * 16 + grp, U = gridDim.x * 16;
@@ -1167,7 +1165,6 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     int my_a = -1, my_b = -1;
     int nkept = 0;
     const int ubm = pa.union_batch - 1;
-    if (j0 == 0 && l16 == 0 && cnt && pa.part_lo == 0) atomicAdd(&blk_cands, (unsigned)cnt);
     // the part of the shard this launch works on (the whole shard unless the kernel runs in two phases)
     const int e_lo = (int)((long long)cnt * pa.part_lo / pa.part_den), e_hi = (int)((long long)cnt * pa.part_hi / pa.part_den);
     int e_first = j0;
@@ -1212,11 +1209,16 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
         if (pa.use_link == 1) uf_link(pa.parent, my_a, my_b); else if (pa.use_link == 2) uf_link_checked(pa.parent, my_a, my_b); else uf_union(pa.parent, my_a, my_b);
         if (edges) record_edge(pa, edges, edge_cap, my_a, my_b);
     }
-    if (l16 == 0 && nkept) atomicAdd(&blk_edges, (unsigned)nkept);
+    __syncthreads();  // every group is done with its table
+    unsigned *blk = reinterpret_cast<unsigned *>(&tab[0][0]);  // [0] edges, [1] candidates of the block
+    if (threadIdx.x == 0) blk[0] = blk[1] = 0u;
+    __syncthreads();
+    if (l16 == 0 && nkept) atomicAdd(&blk[0], (unsigned)nkept);
+    if (j0 == 0 && l16 == 0 && cnt && pa.part_lo == 0) atomicAdd(&blk[1], (unsigned)cnt);
     __syncthreads();
     if (threadIdx.x == 0) {  // plain stores, summed by the host (no same-word global atomics)
-        blk_stats[pa.stats_off + 2 * blockIdx.x] = (int)blk_edges;
-        blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = (int)blk_cands;
+        blk_stats[pa.stats_off + 2 * blockIdx.x] = (int)blk[0];
+        blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = (int)blk[1];
     }
 }
 

@@ -855,6 +855,24 @@ def test_prefix_groups_equal_the_band_path(n, d, indels):
         assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
 
 
+@pytest.mark.exact_edges
+@pytest.mark.parametrize("top", [2**31 - 1, 2**24 + 5, 70_000])
+def test_prefix_groups_with_sparse_token_ids(top, monkeypatch):
+    """the record keys are token + 1 and the sort looks at as many bits as the largest id needs (up to 31): the same rows
+    with their token ids spread over [0, top] — and the largest possible id present — must give the same labels and edges"""
+    uf = list(dict.fromkeys(generate_profiles(4000, p_del=0.05, p_ins=0.01)))
+    indptr, indices, nv = _lib.build_csr(uf, " ")
+    rng = np.random.default_rng(top % 1000)
+    ids = np.unique(rng.integers(0, top, size=4 * nv))[: nv - 1]           # ascending, distinct, below top
+    remap = np.concatenate([ids, [top]]).astype(np.int32)       # monotone: "higher id = newer" keeps its meaning
+    spread = remap[indices]
+    monkeypatch.setenv("BFK_PG", "0")
+    want, st_band = _lib.cluster_csr(indptr, indices, 4)
+    monkeypatch.setenv("BFK_PG", "1")
+    got, st = _lib.cluster_csr(indptr, spread, 4)
+    assert st["path"] == 2 and np.array_equal(got, want) and st["n_edges"] == st_band["n_edges"]
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_prefix_groups_on_random_multisets(seed, monkeypatch):
     """shuffled rows, repeated tokens, empty rows, rows shorter than the prefix (they meet in the SHORT group)"""
