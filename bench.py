@@ -463,6 +463,9 @@ def main():
             comp = (4 * nnz + 12 * n_u) / world
             comp_what = "4*nnz tokens + 4*N_u extents + 8*N_u row hashes, read once"
             step_bytes = (8 * nnz + 44 * n_u) / world
+            # the exact certificate of a match compares the row with its PARTNER row, which another wave — on another XCD's
+            # L2 seven times out of eight — streamed: those tokens cross the fabric a second time whatever the layout
+            join_partner_bytes = st["n_candidates"] * (4 * k_mean + 8)
         elif prefix:
             # prefix groups.  What the two long kernels must move:
             #   k_pgjoin: 16 B (row record) per group member visited, the row heads (recs * (4 B key + 8 B position/count) +
@@ -528,6 +531,16 @@ def main():
                                     "word per pair slot), its working set lives in L2; this is the binding roofline"}
         elif join:
             roof["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
+            roof["traffic_breakdown"] = {
+                "matches": st["n_candidates"], "partner_row_bytes": join_partner_bytes,
+                "algorithmic_bytes_incl_partner_rows": comp + join_partner_bytes,
+                "frac_incl_partner_rows": (comp + join_partner_bytes) / t_dom / 1e9 / HBM_PEAK_GBS if t_dom > 0 else None,
+                "measured": "FETCH_SIZE of k_join, separate --pmc passes with parts of the kernel switched off (BFK_JOIN_DEBUG, "
+                            "100k rows, builder-run, DESIGN 6c): 34.8 MB as shipped; 19.2 MB without the certificate (its reads: "
+                            "15.6 MB = the partner rows of ~1e5 matches); 10.8 MB without certificate and table probes (probes: "
+                            "8.4 MB of 64-byte lines for 16-byte slot pairs)",
+                "note": "`frac` above prices the kernel against the bytes read ONCE (tokens, extents, hashes); the partner rows "
+                        "are a second trip of bytes already counted there, served by the Infinity Cache (the counter includes its hits)"}
         else:
             roof["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges_checked": st["n_edges"],
                               "dropped_as_connected": st.get("n_connected", 0),
