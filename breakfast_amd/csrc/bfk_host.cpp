@@ -428,15 +428,15 @@ static int ctx_size_join(bfk_ctx *c) {
 // thresholds the sort and the passes over (d + 2) N records cost more than the band scan they save (measured: DESIGN 6d).
 // Rows of at most 2 * max_dist tokens all meet in ONE group (prefix filtering says nothing about them): an input with
 // many of those stays on the band path.
-// measured, ms per step band / prefix groups (tools/pg_matrix.sh, labels-only steps, indels kept):
+// measured, ms per step band / prefix groups (tools/pg_matrix.sh -> profiles/r02_pg_matrix.txt; labels-only steps, indels kept):
 //   rows    d = 2          d = 3          d = 4          d = 5
-//   100k    0.18 / 0.55    0.46 / 0.69    0.81 / 0.78    2.11 / 1.37
-//   300k    0.49 / 0.74    1.28 / 1.00    2.14 / 1.18    3.62 / 2.29
-//   1M      1.50 / 2.03    4.83 / 2.49    13.5 / 3.12    21.4 / 4.60
-// the records, their sort and the row-by-row walk cost ~0.5 ms at 100k rows and ~2 ms at 1M whatever max_dist is, the band
-// scan they replace grows steeply with it
+//   100k    0.18 / 0.42    0.49 / 0.61    0.82 / 0.73    1.58 / 0.84
+//   300k    0.48 / 0.59    1.37 / 0.85    2.14 / 0.96    3.20 / 1.62
+//   1M      1.50 / 1.73    4.48 / 1.94    13.2 / 2.35    21.0 / 3.81
+// the records, their sort and the group order cost 0.15 ms at 100k rows and 0.4 - 0.6 ms at 1M whatever max_dist is, the
+// band scan they replace grows steeply with it
 static int64_t PG_MIN_ROWS(int max_dist) {
-    return max_dist >= 5 ? 80000 : (max_dist == 4 ? 90000 : (max_dist == 3 ? 200000 : ((int64_t)1 << 40)));
+    return max_dist >= 4 ? 80000 : (max_dist == 3 ? 150000 : ((int64_t)1 << 40));
 }
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {
