@@ -555,7 +555,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         // was 0.93 ms against 1.05 (2048 blocks) / 1.09 (8192) at 1M rows, max_dist 5
         if (pl.skip_connected && !getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, c->n_cus * 4);
     }
-    pl.verify_phases = ((max_dist == 3 || max_dist == 4) && c->n < 400000) ? 8 : 1;
+    // (with the pruning kernel one phase is better: 100k rows d = 3: 0.217 / 0.241 ms, d = 4: 0.262 / 0.271, 300k d = 4: 0.431 / 0.479)
+    pl.verify_phases = ((max_dist == 3 || max_dist == 4) && c->n < 400000 && !pl.skip_connected) ? 8 : 1;
     pl.verify_phase2_union = 0;
     if (const char *e = getenv("BFK_VERIFY_PHASES")) pl.verify_phases = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("BFK_VERIFY_PHASE2")) pl.verify_phase2_union = std::max(0, std::min(2, atoi(e)));
