@@ -138,20 +138,33 @@ __device__ __forceinline__ uint32_t hash3(uint32_t x) {
 // ------------------------------------------------------------------------------------------------
 // k_maxlen: validate indptr, find the longest row (bind time only)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens*/) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int k = 0;
-    if (i < n) {
-        k = indptr[i + 1] - indptr[i];
+__global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens*/) {
+    __shared__ int s_k[4], s_short[4];
+    int kmax = 0, n_short = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // (grid-stride: one set of atomics per block)
+        int k = indptr[i + 1] - indptr[i];
         if (k < 0) {
             atomicOr(out + 1, 1);
             k = 0;
         }
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(k <= 2 * PG_MAX_DIST);
-        if (sm != 0ull && (threadIdx.x & 63) == (int)__builtin_ctzll(sm)) atomicAdd(out + 2, (int)__popcll(sm));
+        n_short += k <= 2 * PG_MAX_DIST ? 1 : 0;
+        kmax = max(kmax, k);
     }
-    for (int s = 32; s > 0; s >>= 1) k = max(k, __shfl_xor(k, s));
-    if ((threadIdx.x & 63) == 0 && k > 0) atomicMax(out, k);
+    for (int s = 32; s > 0; s >>= 1) {
+        kmax = max(kmax, __shfl_xor(kmax, s));
+        n_short += __shfl_xor(n_short, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_k[threadIdx.x >> 6] = kmax;
+        s_short[threadIdx.x >> 6] = n_short;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kmax = max(max(s_k[0], s_k[1]), max(s_k[2], s_k[3]));
+        n_short = s_short[0] + s_short[1] + s_short[2] + s_short[3];
+        if (kmax > 0) atomicMax(out, kmax);
+        if (n_short > 0) atomicAdd(out + 2, n_short);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1863,10 +1876,17 @@ __device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t) { return (t * 0x9E37
 
 // bind-time helper of the path: the largest token id (sets the number of key bits to sort)
 __global__ __launch_bounds__(256) void k_maxtok(const uint32_t *__restrict__ indices, int nnz, int *out) {
+    __shared__ int s_m[4];
     int m = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nnz; i += gridDim.x * 256) m = max(m, (int)(indices[i] & 0x7FFFFFFFu));
     for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per block (one per wave of 4096 blocks was 190 us of same-address atomics, whatever the input size)
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m > 0) atomicMax(out, m);
+    }
 }
 
 // Token counts over a sample of the rows (every stride-th row), 16 lanes per row, 64 rows per block.  A token that nearly every
@@ -2141,53 +2161,65 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
         A = A_next;
         const int len_a = hd.len;
         const uint32_t sa0 = hd.s0, sa1 = hd.s1;
-        // the records to walk (those with members behind them), as a mask over the STEPS: step 0 = the SHORT record in slot
-        // recs - 1, step i = slot i - 1
-        const unsigned long long vm = __builtin_amdgcn_ballot_w64(hd.key != PG_NONE && hd.pos.y > 0);
-        unsigned om = (unsigned)((vm >> (recs - 1)) & 1ull) | ((unsigned)(vm & ((1ull << (recs - 1)) - 1ull)) << 1);
-        if (om == 0u) continue;
+        // The members behind the row's records, group after group in the order of the STEPS (step 0 = the SHORT record in slot
+        // recs - 1, step i = slot i - 1), are ONE list: lane l of chunk c takes entry 64 c + l of it, whichever group that
+        // falls into.  Half of the records have 8 members or fewer behind them — a chunk per group was a third full — and
+        // nothing below depends on the groups being worked off one after the other: of the lanes that find one row B in
+        // several groups, in one chunk or not, exactly one gets its insert into the set through (and with a full set, exactly
+        // the lane of the first group they share passes the test on the records).
+        const int slot_j = lane == 0 ? recs - 1 : lane - 1;
+        const uint32_t key_j = __shfl(hd.key, slot_j);
+        const int pos_j = __shfl(hd.pos.x, slot_j);
+        const int beh_all = __shfl(hd.pos.y, slot_j);  // (unconditional: a lane that sits this out cannot be read from)
+        const int beh_j = (lane < recs && key_j != PG_NONE) ? beh_all : 0;
+        const int incl_j = wave_incl_scan_add(beh_j);
+        const int T = __builtin_amdgcn_readlane(incl_j, 63);
+        if (T == 0) continue;
+        const int base_j = pos_j + 1 - (incl_j - beh_j);  // entry f of the list, in group j, is position base_j + f
+        int I[PG_MAX_DIST + 1];  // (scalars; lanes at and beyond recs repeat the total)
+#pragma unroll
+        for (int j = 0; j < PG_MAX_DIST + 1; j++) I[j] = __builtin_amdgcn_readlane(incl_j, j);
+        auto entry = [&](int f, int &step) {  // position of entry f of the list, and the step of its group
+            int st = 0;
+#pragma unroll
+            for (int j = 0; j < PG_MAX_DIST + 1; j++) st += f >= I[j] ? 1 : 0;
+            st = min(st, recs - 1);
+            step = st;
+            return __shfl(base_j, st) + f;  // (ds_bpermute: the base of group st sits in lane st)
+        };
         int n_in = 0;         // entries of the set (wave-uniform)
         bool full = false;    // the set stopped taking entries
-        // the chunk list: (first position, members, step) one after the other (wave-uniform scalars)
-        int g_p = 0, g_left = 0, g_step = 0;
-        auto next_chunk = [&](int &p, int &cnt, int &step) {
-            if (g_left == 0) {
-                if (om == 0u) return false;
-                g_step = __builtin_ctz(om);
-                om &= om - 1u;
-                const int slot = g_step == 0 ? recs - 1 : g_step - 1;
-                g_p = __shfl(hd.pos.x, slot) + 1;
-                g_left = __shfl(hd.pos.y, slot);
+        const int nch = (T + 63) >> 6;
+        int st0 = 0, st1 = 0, st2 = 0;
+        int4 rec0 = make_int4(0, 0, 0, 0), rec1 = rec0;
+        {
+            const int q0 = entry(lane, st0), q1 = entry(64 + lane, st1);
+            if (lane < T) rec0 = srec[q0];
+            if (64 + lane < T) rec1 = srec[q1];
+        }
+        for (int c = 0; c < nch; c++) {
+            int4 rec2 = make_int4(0, 0, 0, 0);
+            {
+                const int f2 = (c + 2) * 64 + lane;
+                const int q2 = entry(f2, st2);
+                if (f2 < T) rec2 = srec[q2];
             }
-            p = g_p;
-            cnt = min(64, g_left);
-            step = g_step;
-            g_p += cnt;
-            g_left -= cnt;
-            return true;
-        };
-        int p0 = 0, c0 = 0, st0 = 0, p1 = 0, c1 = 0, st1 = 0, p2 = 0, c2 = 0, st2 = 0;
-        bool h0 = next_chunk(p0, c0, st0);
-        int4 rec0 = h0 && lane < c0 ? srec[p0 + lane] : make_int4(0, 0, 0, 0);
-        bool h1 = next_chunk(p1, c1, st1);
-        int4 rec1 = h1 && lane < c1 ? srec[p1 + lane] : make_int4(0, 0, 0, 0);
-        while (h0) {
-            const bool h2 = next_chunk(p2, c2, st2);
-            const int4 rec2 = h2 && lane < c2 ? srec[p2 + lane] : make_int4(0, 0, 0, 0);
             {
                 const int4 rec = rec0;
                 const int step = st0;
-                visits += (unsigned long long)c0;
+                const bool inb = c * 64 + lane < T;
+                visits += (unsigned long long)min(64, T - c * 64);
                 const int B = rec.x, len_b = rec.y;
-                bool pass = lane < c0 && abs(len_b - len_a) <= d && __popc((uint32_t)rec.z ^ sa0) + __popc((uint32_t)rec.w ^ sa1) <= d;
+                bool pass = inb && abs(len_b - len_a) <= d && __popc((uint32_t)rec.z ^ sa0) + __popc((uint32_t)rec.w ^ sa1) <= d;
                 if (pa.dbg & 64) pass = false;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
-                // seen in an earlier group of A?  (members of one group are distinct rows: no two lanes insert the same B)
+                // seen in another group of A?
                 bool fresh = false, unknown = false;
                 if (pa.dbg & 256) {  // (BFK_PF_DEBUG=256: no set, every member that passes is queued; timing experiments)
                     fresh = pass;
                 } else if (pass) {
-                    // (the set by plain LDS reads and writes — read, write if empty, read back — instead of the compare-and-swap
-                    // was 5.1 ms against 2.25 for this kernel at 1M rows, max_dist 5: three dependent LDS round trips per probe)
+                    // (the set by plain LDS reads and writes of {row : lane} slots — read, write if empty, read back: in order per
+                    // wave, the last writer stays — instead of the compare-and-swap: 2.81 ms against 2.33 for this kernel at 1M
+                    // rows, max_dist 5, 1.30 against 0.53 at 100k rows: three dependent LDS round trips per probe instead of one)
                     uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 22;  // SCAP = 1024 slots
                     for (;;) {
                         const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
@@ -2229,8 +2261,10 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
                     if (pa.dbg & 128) nq = 0;  // (BFK_PF_DEBUG=128: nothing is queued; timing experiments, results invalid)
                 }
             }
-            h0 = h1; p0 = p1; c0 = c1; st0 = st1; rec0 = rec1;
-            h1 = h2; p1 = p2; c1 = c2; st1 = st2; rec1 = rec2;
+            rec0 = rec1;
+            st0 = st1;
+            rec1 = rec2;
+            st1 = st2;
         }
         // clean the set for the next row
         if (n_in > 0 || full)
@@ -2334,14 +2368,14 @@ __global__ void k_changed(const int *__restrict__ labels, const int *__restrict_
 
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_maxlen, dim3((n + 255) / 256), dim3(256), 0, st, indptr, n, out);
+    hipLaunchKernelGGL(k_maxlen, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, st, indptr, n, out);
     LAUNCH_CHECK();
     return 0;
 }
 
 int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st) {
     if (nnz <= 0) return 0;
-    hipLaunchKernelGGL(k_maxtok, dim3(std::min(4096, (nnz + 255) / 256)), dim3(256), 0, st, indices, nnz, out);
+    hipLaunchKernelGGL(k_maxtok, dim3(std::min(1024, (nnz + 255) / 256)), dim3(256), 0, st, indices, nnz, out);
     LAUNCH_CHECK();
     return 0;
 }
