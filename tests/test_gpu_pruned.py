@@ -134,3 +134,18 @@ def test_edge_capture_and_neighbour_lists_are_never_pruned():
     n = len(g["indptr"]) - 1
     got = {(i, int(j)) for i in range(n) for j in idx[ptr[i]: ptr[i + 1]] if j > i}
     assert got == {tuple(e) for e in g["edges"].tolist()}
+
+
+def test_pruned_prefix_groups_behind_n_gpus(monkeypatch):
+    """bfk_cluster_csr(n_gpus = 4) — one context per device, every one with its own forest and its own pruning — on the
+    prefix groups: the merged labels are those of one device"""
+    rows = generate_profiles(30_000, p_del=0.05, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want, _ = _lib.cluster_csr(indptr, indices, 5)
+    monkeypatch.setenv("BFK_PG", "1")
+    if _lib.load().bfk_device_count() < 4:
+        monkeypatch.setenv("BFK_MULTI_ONE_DEVICE", "1")
+    got, st = _lib.cluster_csr(indptr, indices, 5, n_gpus=4)
+    assert np.array_equal(got, want)
+    assert st["path"] == 2 and st["n_connected"] > 0
