@@ -430,13 +430,15 @@ static int ctx_size_join(bfk_ctx *c) {
 // many of those stays on the band path.
 // measured, ms per step band / prefix groups (tools/pg_matrix.sh -> profiles/r02_pg_matrix.txt; labels-only steps, indels kept):
 //   rows    d = 2          d = 3          d = 4          d = 5
-//   100k    0.18 / 0.42    0.49 / 0.61    0.82 / 0.73    1.58 / 0.84
-//   300k    0.48 / 0.59    1.37 / 0.85    2.14 / 0.96    3.20 / 1.62
-//   1M      1.50 / 1.73    4.48 / 1.94    13.2 / 2.35    21.0 / 3.81
-// the records, their sort and the group order cost 0.15 ms at 100k rows and 0.4 - 0.6 ms at 1M whatever max_dist is, the
-// band scan they replace grows steeply with it
+//   30k                    0.30 / 0.27    0.54 / 0.38    0.99 / 0.40
+//   70k                    0.39 / 0.42    0.74 / 0.53    1.46 / 0.50
+//   100k    0.18 / 0.42    0.45 / 0.50    0.84 / 0.57    1.63 / 0.58
+//   300k    0.48 / 0.58    1.28 / 0.67    2.07 / 0.72    3.22 / 0.92
+//   1M      1.49 / 1.72    4.54 / 1.91    13.2 / 2.16    21.0 / 2.99
+// the records, their sort and the group order cost 0.1 ms at 30k rows, 0.15 at 100k and 0.4 - 0.6 ms at 1M whatever max_dist
+// is, the band scan they replace grows steeply with it
 static int64_t PG_MIN_ROWS(int max_dist) {
-    return max_dist >= 4 ? 80000 : (max_dist == 3 ? 150000 : ((int64_t)1 << 40));
+    return max_dist >= 4 ? 25000 : (max_dist == 3 ? 150000 : ((int64_t)1 << 40));
 }
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {

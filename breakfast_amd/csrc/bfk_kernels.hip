@@ -2225,8 +2225,10 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
                         const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
                         if (old == B) break;                     // seen: a duplicate
                         if (old == -1) {
-                            fresh = !full;                       // (just inserted)
-                            unknown = full;                      // not in the set, and the set is incomplete
+                            // (just inserted; or the set takes no more entries: a labels-only step lets the pair through — the
+                            // verify drops a second copy as connected — the others decide it the slow way)
+                            fresh = !full || pa.skip_connected;
+                            unknown = full && !pa.skip_connected;
                             break;
                         }
                         h = (h + 1) & (SCAP - 1);
@@ -2250,7 +2252,11 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
                     fresh = fresh || (unknown && !dup);
                 }
                 n_in += __popcll(__builtin_amdgcn_ballot_w64(fresh && !full));
-                if (n_in > SCAP * 3 / 4) full = true;  // (wave-uniform; entries made so far stay valid)
+                // (wave-uniform; entries made so far stay valid.)  Half full, not three quarters: the rows that get there are the
+                // hubs — an early profile with hundreds of descendants within max_dist — and at 75% load the linear probe
+                // chains of those rows were most of this kernel: 2.27 -> 1.44 ms at 1M rows, max_dist 5, 0.49 -> 0.23 at 100k
+                // (a set of 2048 slots at 3/4: 1.92 / 0.24 — the LDS it takes costs more waves than the shorter chains give)
+                if (n_in > SCAP / 2) full = true;
                 // the fresh pairs wait in LDS for their queue slots
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
                 if (fm != 0ull) {

@@ -49,7 +49,8 @@ typedef struct bfk_stats {
     int64_t pairs_in_band;   /* unordered pairs with |k_i-k_j| <= max_dist (need a set comparison), all shards */
     int64_t pairs_filtered;  /* pair slots the signature kernel evaluated in this shard (tile-padded); variant join: table lookups;
                               * prefix groups: group members visited */
-    int64_t n_candidates;    /* pairs that passed both signature levels and were queued for the exact check */
+    int64_t n_candidates;    /* pairs that passed both signature levels and were queued for the exact check (prefix groups,
+                              * labels-only steps: a row with hundreds of neighbours may queue a pair more than once) */
     int64_t n_edges;         /* candidates checked exactly with distance <= max_dist: every edge of the graph when n_connected == 0 */
     int64_t n_retry_slices;  /* >0: the candidate queue overflowed and the run was redone in this many slices */
     int32_t max_row_len;     /* largest multiset size k */

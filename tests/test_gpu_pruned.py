@@ -86,7 +86,10 @@ def test_100k_rows_pruned_equals_exact(d, indels):
     (lx, sx), (lp, sp) = res[True], res[False]
     assert np.array_equal(lx, lp)
     assert sx["n_connected"] == 0 and sp["n_connected"] > 0
-    assert sp["n_candidates"] == sx["n_candidates"] and sp["n_edges"] <= sx["n_edges"]
+    # (prefix groups, labels-only: a hub row whose de-duplication set is half full lets its further pairs through, so a pair
+    # can be queued — and dropped as connected — more than once)
+    assert sp["n_candidates"] >= sx["n_candidates"] if sp["path"] == 2 else sp["n_candidates"] == sx["n_candidates"]
+    assert sp["n_edges"] <= sx["n_edges"]
     _invariants(sp, lp)
     assert sp["path"] == (2 if d >= 4 else 0)
 
