@@ -152,3 +152,29 @@ def test_pruned_prefix_groups_behind_n_gpus(monkeypatch):
     got, st = _lib.cluster_csr(indptr, indices, 5, n_gpus=4)
     assert np.array_equal(got, want)
     assert st["path"] == 2 and st["n_connected"] > 0
+
+
+def test_cli_bytes_at_max_dist_5_do_not_depend_on_the_generator_or_the_pruning(tmp_path, monkeypatch):
+    """clusters.tsv of the CLI (native front end -> bfk_cluster_csr -> writer) at max-dist 5, indels kept: the default
+    (prefix groups + pruning verify at this size), every candidate checked, and the band kernels give the same bytes"""
+    import hashlib
+
+    import click.testing
+
+    from breakfast_amd import console
+    from breakfast_amd.synth import generate_tsv
+
+    inp = tmp_path / "in.tsv"
+    generate_tsv(inp, 40_000, p_del=0.05, p_ins=0.01)
+    digests = []
+    for name, env in (("default", {}), ("exact", {"BFK_EXACT_EDGES": "1"}), ("band", {"BFK_PG": "0"})):
+        for k in ("BFK_EXACT_EDGES", "BFK_PG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = tmp_path / name
+        res = click.testing.CliRunner().invoke(console.main, ["--input-file", str(inp), "--outdir", str(out), "--max-dist", "5",
+                                                              "--var-type", "raw"])   # raw: every token counts, indels too
+        assert res.exit_code == 0, (res.output, res.exception)
+        digests.append(hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest())
+    assert digests[0] == digests[1] == digests[2]
