@@ -4,12 +4,14 @@ import sys
 def _early_preload():
     """Before click is even imported: if this is a plain clustering run, start loading the HIP library on a native thread
     (fastpath.run would do it a few tens of milliseconds later; a second start is a no-op)."""
-    argv = sys.argv[1:]
+    argv = []
+    for a in sys.argv[1:]:  # "--opt=value" and "--opt value" are the same to click
+        argv.extend(a.split("=", 1) if a.startswith("--") and "=" in a else [a])
     if "--input-file" not in argv or "--input-cache" in argv or "--output-cache" in argv or "--help" in argv:
         return
     try:
         i = argv.index("--max-dist") if "--max-dist" in argv else -1
-        if i >= 0 and argv[i + 1] == "0":
+        if i >= 0 and argv[i + 1].strip() == "0":
             return
         from . import _front
 

@@ -12,8 +12,10 @@ _HERE = Path(__file__).resolve().parent
 FRONT_PATH = _HERE / "libbfk_front.so"
 LIB_PATH = Path(os.environ["BFK_LIB"]) if os.environ.get("BFK_LIB") else _HERE / "libbfk.so"
 EUNSUPPORTED = -7
+ABI_VERSION = 2  # BFK_ABI_VERSION of include/bfk.h (same number as _lib.ABI_VERSION)
 VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
 _lib = None
+_preloading = False
 
 
 class FilterOpts(C.Structure):
@@ -45,6 +47,10 @@ def load():
                                "__graft_entry__.build()); there is no CPU fallback")
         lib = C.CDLL(str(FRONT_PATH))
         lib.bfk_last_error.restype = C.c_char_p
+        if lib.bfk_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{FRONT_PATH} has ABI version {lib.bfk_abi_version()}, this binding expects {ABI_VERSION}: "
+                               "rebuild it (make -C breakfast_amd/csrc)")
+        lib.bfk_preload_join.restype = None
         lib.bfk_preload_start.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64]
         lib.bfk_table_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         lib.bfk_table_close.argtypes = [C.c_void_p]
@@ -63,7 +69,15 @@ def _err(lib):
 def preload(input_file=None, device: int = 0):
     """Start loading libbfk.so (HIP runtime, device context, code object, workspace sized from the input file's size) on a
     native thread.  Idempotent; errors surface at cluster time."""
+    global _preloading
     lib = load()
+    if not _preloading:
+        # every exit path that never reaches bfk_table_cluster_write (max-dist 0, a declined input, an exception, --help)
+        # joins the thread here — before interpreter teardown and the HIP runtime's own exit handlers
+        import atexit
+
+        atexit.register(lib.bfk_preload_join)
+        _preloading = True
     rows = nnz = 0
     if input_file is not None:
         try:

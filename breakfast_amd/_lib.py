@@ -37,6 +37,16 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class TextStats(C.Structure):
+    _fields_ = [("text_bytes", C.c_int64), ("n_rows", C.c_int64), ("nnz", C.c_int64), ("table_slots", C.c_int64),
+                ("n_vocab", C.c_int32), ("table_growths", C.c_int32), ("host_fallback", C.c_int32), ("reserved_", C.c_int32),
+                ("ms_h2d", C.c_float), ("ms_scan", C.c_float), ("ms_hash", C.c_float), ("ms_ids", C.c_float),
+                ("ms_total", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved_"}
+
+
 class FilterOpts(C.Structure):
     _fields_ = [("var_type", C.c_int32), ("skip_ins", C.c_int32), ("skip_del", C.c_int32),
                 ("trim_start", C.c_int64), ("trim_end", C.c_int64), ("reference_length", C.c_int64)]
@@ -49,6 +59,7 @@ class PrepInfo(C.Structure):
 
 VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
 EUNSUPPORTED = -7
+ABI_VERSION = 2  # BFK_ABI_VERSION of include/bfk.h this binding (struct layouts, EXPORTS) was written against
 
 EXPORTS = {
     "bfk_abi_version": (C.c_int, []),
@@ -57,6 +68,13 @@ EXPORTS = {
     "bfk_free": (None, [C.c_void_p]),
     "bfk_build_csr": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, C.POINTER(c_i32p),
                                 c_i64p, c_i32p]),
+    "bfk_build_csr_device": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, C.POINTER(c_i32p),
+                                       c_i64p, c_i32p]),
+    "bfk_cluster_text": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, C.c_int32, c_i32p, C.POINTER(Stats),
+                                   c_i64p, c_i32p]),
+    "bfk_ctx_build_csr": (C.c_int, [C.c_void_p, C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i64p, c_i32p]),
+    "bfk_ctx_download_csr": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
+    "bfk_ctx_text_stats": (C.c_int, [C.c_void_p, C.POINTER(TextStats)]),
     "bfk_cluster_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_i32p, C.POINTER(Stats)]),
     "bfk_neighbours_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, C.POINTER(c_i64p),
                                      C.POINTER(c_i32p)]),
@@ -97,6 +115,7 @@ EXPORTS = {
     "bfk_warmup": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
     "bfk_preload_start": (C.c_int, [C.c_char_p, C.c_int, C.c_int64, C.c_int64]),
     "bfk_preload_wait": (C.c_int, []),
+    "bfk_preload_join": (None, []),
 }
 
 
@@ -113,8 +132,9 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.bfk_abi_version() != 1:
-            raise RuntimeError("libbfk ABI version mismatch")
+        if lib.bfk_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {lib.bfk_abi_version()}, this binding expects {ABI_VERSION}: "
+                               "rebuild it (make -C breakfast_amd/csrc)")
         _lib = lib
     return _lib
 
@@ -156,8 +176,18 @@ def build_csr(features, sep: str):
     return indptr, indices, int(nv.value)
 
 
-def build_csr_bytes(buf: bytes, row_off, sep: str):
-    """bfk_build_csr on the C-ABI's own input: one byte buffer + int64 offsets[N+1] (no Python strings touched)."""
+def pack_rows(features):
+    """sequence of str (floats/NaN = empty rows, breakfast.py:200-201) -> (one byte buffer, int64 offsets[N+1])"""
+    rows = [b"" if isinstance(f, float) else f.encode() for f in features]
+    off = np.zeros(len(rows) + 1, dtype=np.int64)
+    if rows:
+        np.cumsum(np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows)), out=off[1:])
+    return b"".join(rows), off
+
+
+def build_csr_bytes(buf: bytes, row_off, sep: str, device: bool = False):
+    """bfk_build_csr on the C-ABI's own input: one byte buffer + int64 offsets[N+1] (no Python strings touched).
+    device=True: bfk_build_csr_device — the same contract computed by the HIP tokeniser."""
     lib = load()
     off = np.ascontiguousarray(row_off, dtype=np.int64)
     n = len(off) - 1
@@ -166,10 +196,39 @@ def build_csr_bytes(buf: bytes, row_off, sep: str):
     out = c_i32p()
     nnz = C.c_int64()
     nv = C.c_int32()
-    _check(lib.bfk_build_csr(buf, _p64(off), n, sepb, len(sepb), _p32(indptr), C.byref(out), C.byref(nnz), C.byref(nv)))
+    fn = lib.bfk_build_csr_device if device else lib.bfk_build_csr
+    rc = fn(buf, _p64(off), n, sepb, len(sepb), _p32(indptr), C.byref(out), C.byref(nnz), C.byref(nv))
+    if rc == -1 and len(sepb) == 0:
+        raise ValueError("empty separator")
+    if rc == EUNSUPPORTED:
+        raise Unsupported(lib.bfk_last_error().decode(errors="replace"))
+    _check(rc)
     indices = np.ctypeslib.as_array(out, shape=(max(nnz.value, 1),))[: nnz.value].copy()
     lib.bfk_free(out)
     return indptr, indices, int(nv.value)
+
+
+def build_csr_device(features, sep: str):
+    """bfk_build_csr_device on a sequence of str: the CSR of sparse_feature_matrix, computed on the GPU."""
+    buf, off = pack_rows(features)
+    return build_csr_bytes(buf, off, sep, device=True)
+
+
+def cluster_text(buf: bytes, row_off, sep: str, max_dist: int):
+    """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device."""
+    lib = load()
+    off = np.ascontiguousarray(row_off, dtype=np.int64)
+    n = len(off) - 1
+    sepb = sep.encode()
+    labels = np.empty(max(n, 1), dtype=np.int32)
+    st = Stats()
+    nnz, nv = C.c_int64(), C.c_int32()
+    rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels), C.byref(st), C.byref(nnz),
+                              C.byref(nv))
+    if rc == -1 and len(sepb) == 0:
+        raise ValueError("empty separator")
+    _check(rc)
+    return labels[:n], st.as_dict(), int(nnz.value), int(nv.value)
 
 
 def cluster_csr(indptr, indices, max_dist: int, n_gpus: int = 1):
@@ -405,6 +464,30 @@ class Context:
     def bind_csr_device(self, d_indptr: int, d_indices: int, n_rows: int):
         self.n_rows = int(n_rows)
         _check(self.lib.bfk_ctx_bind_csr_device(self.h, C.c_void_p(d_indptr), C.c_void_p(d_indices), self.n_rows))
+
+    def build_csr(self, buf: bytes, row_off, sep: str):
+        """bfk_ctx_build_csr: tokenise on the device, leave the CSR resident and bound -> (nnz, n_vocab)"""
+        off = np.ascontiguousarray(row_off, dtype=np.int64)
+        sepb = sep.encode()
+        nnz, nv = C.c_int64(), C.c_int32()
+        rc = self.lib.bfk_ctx_build_csr(self.h, buf, _p64(off), len(off) - 1, sepb, len(sepb), C.byref(nnz), C.byref(nv))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        self.n_rows = len(off) - 1
+        self.nnz = int(nnz.value)
+        return int(nnz.value), int(nv.value)
+
+    def download_csr(self):
+        indptr = np.empty(self.n_rows + 1, dtype=np.int32)
+        indices = np.empty(max(self.nnz, 1), dtype=np.int32)
+        _check(self.lib.bfk_ctx_download_csr(self.h, _p32(indptr), _p32(indices)))
+        return indptr, indices[: self.nnz]
+
+    def text_stats(self) -> dict:
+        st = TextStats()
+        _check(self.lib.bfk_ctx_text_stats(self.h, C.byref(st)))
+        return st.as_dict()
 
     def alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -28,7 +28,17 @@ extern "C" void bfk_free(void *p) { free(p); }
 
 namespace {
 std::mutex g_mu;
-std::thread g_thread;
+// The thread is never left joinable at static destruction (std::terminate): the holder's destructor joins it, and every
+// caller that started it joins earlier — bfk_preload_wait on the clustering path, bfk_preload_join from the Python shell's
+// atexit hook on every other exit (max-dist 0, declined inputs, exceptions), i.e. before the HIP runtime's own exit
+// handlers run.
+struct ThreadHolder {
+    std::thread th;
+    ~ThreadHolder() {
+        if (th.joinable()) th.join();
+    }
+};
+ThreadHolder g_thread;
 bool g_started = false, g_joined = false;
 void *g_handle = nullptr;
 std::string g_path, g_load_err;
@@ -60,15 +70,24 @@ extern "C" int bfk_preload_start(const char *libbfk_path, int device, int64_t ro
     if (g_started) return BFK_OK;
     g_path = libbfk_path;
     g_started = true;
-    g_thread = std::thread(preload_body, device, rows_hint, nnz_hint);
+    g_thread.th = std::thread(preload_body, device, rows_hint, nnz_hint);
     return BFK_OK;
+}
+
+// wait for the preload thread whatever it achieved (no error is reported): for exit paths that never cluster
+extern "C" void bfk_preload_join(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_started && !g_joined) {
+        if (g_thread.th.joinable()) g_thread.th.join();
+        g_joined = true;
+    }
 }
 
 extern "C" int bfk_preload_wait(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_started) return bfk_fail(BFK_ESTATE, "bfk_preload_wait: bfk_preload_start was not called");
     if (!g_joined) {
-        g_thread.join();
+        if (g_thread.th.joinable()) g_thread.th.join();
         g_joined = true;
     }
     if (!g_handle) return bfk_fail(BFK_ENODEV, "cannot load " + g_path + ": " + g_load_err);

@@ -114,6 +114,19 @@ struct bfk_ctx {
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
     int join_empty_shard = -1, join_empty_shards = 0;
+    // device tokeniser (bfk_ctx_build_csr, bfk_text.hip): text, bit arrays, vocabulary table, per-token scratch
+    uint8_t *tk_text = nullptr;
+    long long *tk_rowoff = nullptr;
+    char *tk_zero = nullptr;  // [TokCounters | chain_scan | chain_first | rowbits]: zeroed by ONE memset per build
+    uint32_t *tk_bits = nullptr, *tk_winbase = nullptr, *tk_tokoff = nullptr;
+    unsigned long long *tk_table = nullptr;
+    int *tk_tabid = nullptr;
+    int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_tokoff_cap = 0,
+            tk_table_cap = 0, tk_tabid_cap = 0;
+    int tk_grow = 0;  // how often the table was enlarged 8x for this context's inputs (kept: the next input is likely alike)
+    hipEvent_t tk_ev[6] = {};
+    bool tk_ev_ready = false;
+    bfk_text_stats tk_stats{};
     // last run
     bool ran = false;
     int last_d = 0, last_w1 = 0, last_shards = 1;
@@ -179,12 +192,15 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo};
+                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->tk_text, c->tk_rowoff,
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_tokoff, c->tk_table, c->tk_tabid};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
         for (auto &e : slot)
             if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->tk_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BFK_OK;
@@ -381,6 +397,153 @@ extern "C" int bfk_ctx_upload_csr(bfk_ctx *c, const int32_t *indptr, const int32
     c->d_indices = c->own_indices;
     c->n = n_rows;
     return ctx_after_bind(c);
+}
+
+// ================================================================================================
+// a1 on the device: text -> first-appearance vocabulary -> CSR (bfk_text.hip), left bound in the context
+// ================================================================================================
+static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                          int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off || n_rows < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: null argument");
+    if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
+    if (n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
+    if (sep_len != 1) return fail(BFK_EUNSUPPORTED, "device tokeniser: one-byte separators only (the host tokeniser takes the rest)");
+    const int64_t base = row_off[0], T = row_off[n_rows] - base;
+    if (T < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
+    if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
+    if (T > (int64_t)0xFFF00000ll) return fail(BFK_EUNSUPPORTED, "device tokeniser: 32-bit byte offsets (text of 4 GiB or more)");
+    const int64_t T_pad = round_up(T + 1, TOK_BLOCK_BYTES);
+    // every token but the last of a row is followed by a separator: at most T/2 + n_rows + 1 tokens
+    const int64_t nnz_cap = T / 2 + n_rows + 1;
+    if (nnz_cap > (int64_t)INT32_MAX - 4 * TOK_FIRST_PER_BLOCK) return fail(BFK_EUNSUPPORTED, "device tokeniser: more than 2^31 possible tokens");
+    const int64_t nnz_alloc = round_up(nnz_cap, TOK_FIRST_PER_BLOCK) + 16;
+    const int64_t n_win = T_pad / TOK_WIN, scan_blocks = T_pad / TOK_BLOCK_BYTES, first_blocks = nnz_alloc / TOK_FIRST_PER_BLOCK + 1;
+    // zeroed region: counters | chain_scan | chain_first | rowbits
+    const int64_t z_chain1 = 64, z_chain2 = z_chain1 + round_up((scan_blocks + 1) * 8, 64),
+                  z_rowbits = z_chain2 + round_up((first_blocks + 1) * 8, 64), z_bytes = z_rowbits + T_pad / 8 + 64;
+    const int64_t bit_words = T_pad / 32 + 16;
+    if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n_rows + 1, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_zero, &c->tk_zero_cap, z_bytes, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 2 * bit_words, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, n_win + 2, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_tokoff, &c->tk_tokoff_cap, nnz_alloc, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
+    if (c->profiling && !c->tk_ev_ready) {
+        for (auto &e : c->tk_ev)
+            if (hipEventCreate(&e) != hipSuccess) return fail(BFK_EHIP, "hipEventCreate failed");
+        c->tk_ev_ready = true;
+    }
+    hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
+    // the text and the row offsets: the caller's (pageable) buffers, borrowed until the copies are done
+    if (ev) HIP_TRY(hipEventRecord(ev[4], c->stream));
+    if (T > 0) HIP_TRY(hipMemcpyAsync(c->tk_text, buf + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->tk_text + T, (unsigned char)sep[0], (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
+    TokCounters tc{};
+    int rc_bind = BFK_OK;
+    for (int attempt = 0;; attempt++) {
+        // vocabulary table: 1/8 slot per possible token (real inputs: ~8 bytes per token, a vocabulary of a few % of the
+        // tokens -> load of a few %); an input with more distinct tokens than that overflows the probe limit, the table
+        // grows 8x (twice at most: 8 slots per possible token) and the kernels run again on the resident text
+        int64_t slots = 1 << 16;
+        while (slots < nnz_cap / 8) slots <<= 1;
+        slots <<= 3 * c->tk_grow;
+        if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
+        if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
+        if (int rc = dev_realloc(&c->tk_tabid, &c->tk_tabid_cap, slots)) return rc;
+        HIP_TRY(hipMemsetAsync(c->tk_zero, 0, (size_t)z_bytes, c->stream));
+        HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * 8, c->stream));
+        TokArgs a{};
+        a.text = c->tk_text;
+        a.row_off = c->tk_rowoff;
+        a.base = base;
+        a.T = (uint32_t)T;
+        a.T_pad = (uint32_t)T_pad;
+        a.n_rows = (int)n_rows;
+        a.sep = (uint8_t)sep[0];
+        a.tc = (TokCounters *)c->tk_zero;
+        a.chain_scan = (unsigned long long *)(c->tk_zero + z_chain1);
+        a.chain_first = (unsigned long long *)(c->tk_zero + z_chain2);
+        a.rowbits = (uint32_t *)(c->tk_zero + z_rowbits);
+        a.startbits = c->tk_bits;
+        a.boundbits = c->tk_bits + bit_words;
+        a.winbase = c->tk_winbase;
+        a.table = c->tk_table;
+        a.tmask = (uint32_t)(slots - 1);
+        a.tabid = c->tk_tabid;
+        a.tokslot = c->own_indices;
+        a.tokoff = c->tk_tokoff;
+        a.indices = c->own_indices;
+        a.indptr = c->own_indptr;
+        a.nnz_cap = nnz_cap;
+        if (int e = launch_tokenize(a, c->stream, ev)) return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
+        HIP_TRY(hipMemcpyAsync(&tc, c->tk_zero, sizeof tc, hipMemcpyDeviceToHost, c->stream));
+        // bind: the sync inside (longest row, nnz) also lands the counters above
+        c->d_indptr = c->own_indptr;
+        c->d_indices = c->own_indices;
+        c->n = n_rows;
+        rc_bind = ctx_after_bind(c);
+        if (rc_bind == BFK_EHIP) return rc_bind;
+        if (n_rows == 0) HIP_TRY(hipStreamSynchronize(c->stream));  // (ctx_after_bind has nothing to wait for then)
+        if (!(tc.fail & TOK_FAIL_TABLE) || (tc.fail & (TOK_FAIL_ROWOFF | TOK_FAIL_LONG | TOK_FAIL_SPIN))) break;
+        if (attempt >= 2 || slots >= ((int64_t)1 << 31)) break;
+        c->tk_grow++;
+    }
+    c->tk_stats = bfk_text_stats{};
+    c->tk_stats.text_bytes = T;
+    c->tk_stats.n_rows = n_rows;
+    c->tk_stats.table_slots = (int64_t)c->tk_table_cap;
+    c->tk_stats.table_growths = c->tk_grow;
+    if (tc.fail) {
+        c->n = -1;  // nothing usable is bound
+        if (tc.fail & TOK_FAIL_ROWOFF) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
+        if (tc.fail & TOK_FAIL_SPIN) return fail(BFK_EHIP, "device tokeniser: look-back did not complete");
+        if (tc.fail & TOK_FAIL_LONG) return fail(BFK_EUNSUPPORTED, "device tokeniser: a token of 64 KiB or more (the host tokeniser takes it)");
+        return fail(BFK_EUNSUPPORTED, "device tokeniser: vocabulary table overflow (the host tokeniser takes it)");
+    }
+    if (rc_bind) return rc_bind;
+    if ((int64_t)tc.nnz != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
+    c->max_tok = (int)tc.n_vocab - 1;  // ids are 0 .. n_vocab - 1: the prefix-group path needs no k_maxtok pass
+    c->tk_stats.nnz = tc.nnz;
+    c->tk_stats.n_vocab = (int32_t)tc.n_vocab;
+    if (ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->tk_stats.ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
+        if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->tk_stats.ms_hash = ms;
+        if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->tk_stats.ms_ids = ms;
+        if (hipEventElapsedTime(&ms, ev[4], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
+    }
+    if (nnz_out) *nnz_out = tc.nnz;
+    if (n_vocab_out) *n_vocab_out = (int32_t)tc.n_vocab;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_build_csr(bfk_ctx *c, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep,
+                                 int64_t sep_len, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    return ctx_build_text(c, buf, row_off, n_rows, sep, sep_len, nnz_out, n_vocab_out);
+}
+
+extern "C" int bfk_ctx_text_stats(bfk_ctx *c, bfk_text_stats *out) {
+    if (!c || !out) return fail(BFK_EARG, "null argument");
+    *out = c->tk_stats;
+    return BFK_OK;
+}
+
+extern "C" int bfk_ctx_download_csr(bfk_ctx *c, int32_t *indptr_out, int32_t *indices_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (c->n < 0) return fail(BFK_ESTATE, "no CSR bound");
+    if (!indptr_out || (c->nnz > 0 && !indices_out)) return fail(BFK_EARG, "null output");
+    HIP_TRY(hipMemcpyAsync(indptr_out, c->d_indptr, (size_t)(c->n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->nnz > 0) HIP_TRY(hipMemcpyAsync(indices_out, c->d_indices, (size_t)c->nnz * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BFK_OK;
 }
 
 static int sig_words_for(int d) {
@@ -1098,6 +1261,61 @@ extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, in
     if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
     if (int rc = ctx_own_labels(c, n_rows)) return rc;
     int rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
+    if (!rc) rc = bfk_ctx_sync(c, stats_out);
+    if (!rc) rc = bfk_ctx_download(c, c->own_labels, labels_out, n_rows * 4);
+    return rc;
+}
+
+// a1 with host outputs, computed on the device: bfk_build_csr's contract (include/bfk.h) — what the parity tests compare
+// with the reference's CSR.  BFK_EUNSUPPORTED inputs (multi-byte separator, 4 GiB of text, 64 KiB tokens) are the
+// host tokeniser's (bfk_build_csr).
+extern "C" int bfk_build_csr_device(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                                    int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off || !indptr_out || !indices_out || !nnz_out || !n_vocab_out || n_rows < 0) return fail(BFK_EARG, "bfk_build_csr_device: null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;
+    int64_t nnz = 0;
+    int32_t nv = 0;
+    if (int rc = ctx_build_text(c, buf, row_off, n_rows, sep, sep_len, &nnz, &nv)) return rc;
+    int32_t *out = (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(1, nnz));
+    if (!out) return fail(BFK_ENOMEM, "bfk_build_csr_device: out of memory");
+    if (int rc = bfk_ctx_download_csr(c, indptr_out, out)) {
+        free(out);
+        return rc;
+    }
+    *indices_out = out;
+    *nnz_out = nnz;
+    *n_vocab_out = nv;
+    return BFK_OK;
+}
+
+// a1 .. a8 in one call: profile text in host memory -> canonical labels in host memory.  The text goes to the device once
+// (56 GB/s from the caller's buffer), the CSR is built there (bfk_text.hip) and never visits the host.
+extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                                int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off || n_rows < 0 || (n_rows > 0 && !labels_out)) return fail(BFK_EARG, "bfk_cluster_text: bad arguments");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;
+    int rc = ctx_build_text(c, buf, row_off, n_rows, sep, sep_len, nnz_out, n_vocab_out);
+    if (rc == BFK_EUNSUPPORTED) {  // the host tokeniser (same contract) and an upload of its CSR
+        std::vector<int32_t> indptr((size_t)n_rows + 1);
+        int32_t *indices = nullptr, nv = 0;
+        int64_t nnz = 0;
+        if (int r2 = bfk_build_csr(buf, row_off, n_rows, sep, sep_len, indptr.data(), &indices, &nnz, &nv)) return r2;
+        rc = bfk_ctx_upload_csr(c, indptr.data(), indices, n_rows);
+        free(indices);
+        if (nnz_out) *nnz_out = nnz;
+        if (n_vocab_out) *n_vocab_out = nv;
+        c->tk_stats = bfk_text_stats{};
+        c->tk_stats.host_fallback = 1;
+    }
+    if (rc) return rc;
+    if (int r2 = ctx_own_labels(c, n_rows)) return r2;
+    rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
     if (!rc) rc = bfk_ctx_sync(c, stats_out);
     if (!rc) rc = bfk_ctx_download(c, c->own_labels, labels_out, n_rows * 4);
     return rc;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BFK_ABI_VERSION 1
+#define BFK_ABI_VERSION 2 /* 2: bfk_stats grew (path, n_connected); bfk_preload_join, device tokeniser entries */
 
 #define BFK_OK 0
 #define BFK_EARG -1      /* bad argument (NULL pointer, negative size, malformed indptr, ...) */
@@ -88,6 +88,20 @@ int bfk_warmup(int device, int64_t rows_hint, int64_t nnz_hint);
 int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
                   int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out);
 
+/* The same contract computed ON THE DEVICE (bfk_text.hip: separator scan, vocabulary table keyed by hash + length + bytes
+ * with atomicMin on the first byte offset, first-appearance ids by a prefix sum over the first occurrences), host outputs:
+ * indptr / indices / n_vocab identical to bfk_build_csr's and to the reference's CSR.  One-byte separators, text below
+ * 4 GiB, tokens below 64 KiB; anything else -> BFK_EUNSUPPORTED and nothing done (bfk_build_csr takes those).           */
+int bfk_build_csr_device(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                         int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out);
+
+/* ---- a1..a8 one-shot: profile text in host memory -> labels in host memory -------------------------------------------
+ * sparse_feature_matrix (:193-215) + the body of cluster_features (:287-326) in one call: the text is copied to the device
+ * once, tokenised there (bfk_build_csr_device's kernels; the host tokeniser + an upload when they decline the input),
+ * the CSR stays in HBM and is clustered like bfk_cluster_csr.  nnz_out / n_vocab_out / stats_out may be NULL.            */
+int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                     int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out);
+
 /* ---- a2..a8 one-shot, host buffers ------------------------------------------------------------
  * Replaces the body of cluster_features between the CSR and the components:
  *   n_features / band loop (:287-319) -> get_neighbours_batch (:223-276) -> sklearn _sparse_manhattan
@@ -136,6 +150,28 @@ int bfk_ctx_upload_csr(bfk_ctx *ctx, const int32_t *indptr, const int32_t *indic
 /* borrow a CSR that already lives in device memory (int32 indptr[n_rows+1], int32 indices[nnz]);
  * sizes the workspace (synchronous: reads indptr[n_rows] and the longest row back) */
 int bfk_ctx_bind_csr_device(bfk_ctx *ctx, const void *d_indptr, const void *d_indices, int64_t n_rows);
+
+/* a1 on the device, CSR left resident and bound (bfk_build_csr_device without the download): buf / row_off are host
+ * buffers, borrowed until the call returns (synchronous: the longest row and nnz come back for the workspace). */
+int bfk_ctx_build_csr(bfk_ctx *ctx, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                      int64_t *nnz_out, int32_t *n_vocab_out);
+/* copy the bound CSR to the host: indptr_out int32[n_rows + 1], indices_out int32[nnz] (synchronous) */
+int bfk_ctx_download_csr(bfk_ctx *ctx, int32_t *indptr_out, int32_t *indices_out);
+/* counters / phase times (with bfk_ctx_set_profiling) of the last bfk_ctx_build_csr / bfk_cluster_text */
+typedef struct bfk_text_stats {
+    int64_t text_bytes, n_rows, nnz;
+    int64_t table_slots;     /* slots of the vocabulary table */
+    int32_t n_vocab;
+    int32_t table_growths;   /* times the table was enlarged 8x (kept with the context) */
+    int32_t host_fallback;   /* 1: the device tokeniser declined the input (BFK_EUNSUPPORTED), the host tokeniser built the CSR */
+    int32_t reserved_;
+    float ms_h2d;            /* text + row offsets, host -> device */
+    float ms_scan;           /* k_tok_rowbits + k_tok_scan */
+    float ms_hash;           /* k_tok_hash */
+    float ms_ids;            /* k_tok_rows + k_tok_first + k_tok_ids */
+    float ms_total;          /* first copy to last kernel */
+} bfk_text_stats;
+int bfk_ctx_text_stats(bfk_ctx *ctx, bfk_text_stats *out);
 
 /* enqueue CSR -> labels for shard `shard` of `n_shards` (the cells of the sorted order are dealt round-robin; 0,1 = all).
  * d_labels_out: device int32[n_rows]; with n_shards > 1 these are the labels of the LOCAL forest.
@@ -244,6 +280,9 @@ int bfk_table_ids(const bfk_table *t, char **buf_out, int64_t **off_out);
  * weights against min_cluster_size (:329-339), then bfk_table_write.  Replaces cluster + write_output (console.py:166-170). */
 int bfk_preload_start(const char *libbfk_path, int device, int64_t rows_hint, int64_t nnz_hint);
 int bfk_preload_wait(void);
+/* joins the preload thread without reporting its result: every exit path that does not cluster (max-dist 0, a declined
+ * input, an exception) calls it — the Python shell from an atexit hook — so the thread never outlives the HIP runtime */
+void bfk_preload_join(void);
 int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cluster_size, int32_t n_gpus, const char *path,
                             int64_t *n_clusters_out);
 

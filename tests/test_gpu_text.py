@@ -1,0 +1,174 @@
+"""GPU parity of the DEVICE tokeniser (bfk_text.hip behind bfk_build_csr_device / bfk_ctx_build_csr / bfk_cluster_text):
+text -> first-appearance vocabulary -> CSR must equal the reference's sparse_feature_matrix (breakfast.py:193-215) entry
+for entry — golden stage vectors and KATs produced by the imported reference, the oracle's restatement on seeded inputs,
+and the host tokeniser (bfk_build_csr) at BASELINE's sizes.  Integer / byte work: bit-exact."""
+
+import numpy as np
+import pytest
+from conftest import load_stage, stage_names
+
+from breakfast_amd import _lib
+from breakfast_amd.synth import generate_profiles
+from oracle import ref_port as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want):
+    assert np.array_equal(got[0], want[0]), "indptr differs"
+    assert np.array_equal(got[1], want[1]), "indices differ"
+    assert int(got[2]) == int(want[2]), "n_vocab differs"
+
+
+@pytest.mark.parametrize("name", stage_names())
+def test_device_csr_matches_reference_golden(name):
+    g = load_stage(name)
+    if len(g["sep"]) != 1:
+        pytest.skip("multi-byte separator: host tokeniser")
+    _same(_lib.build_csr_device(g["ufeatures"], g["sep"]), (g["indptr"], g["indices"], g["n_vocab"]))
+    # the raw (uncollapsed) feature column too: duplicates rows, other first appearances
+    want = orc.sparse_feature_matrix(g["features"], g["sep"])
+    _same(_lib.build_csr_device(g["features"], g["sep"]), want)
+
+
+def test_device_csr_kats(kats):
+    for c in kats["cluster"]:
+        if "error" in c or len(c["sep"]) != 1:
+            continue
+        uf = list(dict.fromkeys(c["features"]))
+        indptr, indices, _ = _lib.build_csr_device(uf, c["sep"])
+        assert indptr.tolist() == c["indptr"] and indices.tolist() == c["indices"], c
+
+
+def test_device_csr_edge_cases():
+    """the inputs of tests/test_abi.py::test_build_csr_edge_cases, through the device path"""
+    indptr, indices, nv = _lib.build_csr_device(["", "C241T"], " ")  # reference tests/test_filtering.py:94-99
+    assert indptr.tolist() == [0, 0, 1] and indices.tolist() == [0] and nv == 1
+    indptr, indices, nv = _lib.build_csr_device([], " ")
+    assert indptr.tolist() == [0] and len(indices) == 0 and nv == 0
+    indptr, indices, nv = _lib.build_csr_device(["", "", ""], " ")
+    assert indptr.tolist() == [0, 0, 0, 0] and len(indices) == 0 and nv == 0
+    indptr, indices, nv = _lib.build_csr_device(["a|b||||a", float("nan"), "||", "|a"], "|")
+    assert indptr.tolist() == [0, 3, 3, 3, 4] and indices.tolist() == [0, 1, 0, 0] and nv == 2
+    with pytest.raises(_lib.Unsupported):  # multi-byte separators are the host tokeniser's
+        _lib.build_csr_device(["a||b"], "||")
+    with pytest.raises(ValueError):
+        _lib.build_csr_device(["a b"], "")
+    # rows that abut without a separator: the row boundary ends a token ("ab" + "cd" are two tokens, not "abcd")
+    indptr, indices, nv = _lib.build_csr_device(["ab", "cd", "ab cd", "abcd"], " ")
+    assert indptr.tolist() == [0, 1, 2, 4, 5] and indices.tolist() == [0, 1, 0, 1, 2] and nv == 3
+    # one-byte rows: a token per byte
+    rows = [chr(65 + (i * 7) % 26) for i in range(5000)]
+    _same(_lib.build_csr_device(rows, " "), orc.sparse_feature_matrix(rows, " "))
+    big = " ".join(f"T{i}" for i in range(200000))  # 200k distinct tokens in one row: the table grows
+    indptr, indices, nv = _lib.build_csr_device([big, big], " ")
+    assert nv == 200000 and np.array_equal(indices[:200000], np.arange(200000)) and indptr.tolist() == [0, 200000, 400000]
+    assert np.array_equal(indices[200000:], np.arange(200000))
+
+
+def test_device_csr_long_tokens_and_window_borders():
+    """tokens across the 16-byte lane, 1 KiB window and 16 KiB block borders; tokens of 1 .. 5000 bytes; runs of separators"""
+    rng = np.random.default_rng(11)
+    rows = []
+    for r in range(400):
+        toks = []
+        for _ in range(int(rng.integers(0, 40))):
+            ln = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100, 1023, 1024, 1025, 5000], p=[.1] * 7 + [.03] * 10))
+            pool = int(rng.integers(1, 60))  # few distinct tokens per length: repeats, first appearances matter
+            toks.append((chr(97 + pool % 26) * ln)[: ln - 1] + chr(65 + pool // 26) if ln > 1 else chr(97 + pool % 26))
+        seps = [" " * int(rng.integers(1, 4)) for _ in toks]
+        rows.append(" " * int(rng.integers(0, 3)) + "".join(t + s for t, s in zip(toks, seps)))
+    want = orc.sparse_feature_matrix(rows, " ")
+    _same(_lib.build_csr_device(rows, " "), want)
+    with pytest.raises(_lib.Unsupported):  # a token of 64 KiB: declined, nothing done
+        _lib.build_csr_device(["x" * 70000 + " y"], " ")
+    indptr, indices, nv = _lib.build_csr_device(["x" * 65534 + " y " + "x" * 65534], " ")
+    assert indices.tolist() == [0, 1, 0] and nv == 2
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_csr_fuzz_vs_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    sep = [" ", ",", ";", "\t", "|", "-"][seed]
+    alphabet = [f"{chr(65 + int(a))}{int(p)}{chr(65 + int(b))}" for a, p, b in
+                zip(rng.integers(0, 26, 500), rng.integers(1, 30000, 500), rng.integers(0, 26, 500))]
+    rows = []
+    for _ in range(int(rng.integers(1, 3000))):
+        k = int(rng.integers(0, 60))
+        toks = [alphabet[int(i)] for i in rng.integers(0, len(alphabet), k)]
+        if rng.random() < 0.2:
+            toks += [""] * int(rng.integers(1, 3))  # empty tokens (double separators)
+            rng.shuffle(toks)
+        rows.append(sep.join(toks))
+    _same(_lib.build_csr_device(rows, sep), orc.sparse_feature_matrix(rows, sep))
+
+
+def test_device_csr_row_off_with_a_base_and_malformed_offsets():
+    rows = ["A1C G5T", "", "G5T", "Q9R A1C"]
+    buf, off = _lib.pack_rows(rows)
+    want = orc.sparse_feature_matrix(rows, " ")
+    shifted = b"junk " + buf + b" tail"
+    _same(_lib.build_csr_bytes(shifted, off + 5, " ", device=True), want)
+    bad = off.copy()
+    bad[2] = bad[1] - 1
+    with pytest.raises(_lib.BfkError) as ei:
+        _lib.build_csr_bytes(buf, bad, " ", device=True)
+    assert ei.value.code == -1
+
+
+@pytest.mark.parametrize("n,indels", [(10000, False), (100000, False), (100000, True)])
+def test_device_csr_equals_host_tokeniser_at_scale(n, indels):
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    rows = list(dict.fromkeys(generate_profiles(n, **kw)))
+    buf, off = _lib.pack_rows(rows)
+    host = _lib.build_csr_bytes(buf, off, " ")
+    _same(_lib.build_csr_bytes(buf, off, " ", device=True), host)
+    if n == 10000:
+        _same(host, orc.sparse_feature_matrix(rows, " "))
+
+
+def test_ctx_build_csr_binds_what_it_built_and_cluster_text_agrees():
+    rows = list(dict.fromkeys(generate_profiles(20000)))
+    buf, off = _lib.pack_rows(rows)
+    ip, ix, nv = _lib.build_csr_bytes(buf, off, " ")
+    ctx = _lib.Context(0)
+    ctx.set_profiling(True)
+    nnz, nv2 = ctx.build_csr(buf, off, " ")
+    assert (nnz, nv2) == (len(ix), nv)
+    d_ip, d_ix = ctx.download_csr()
+    assert np.array_equal(d_ip, ip) and np.array_equal(d_ix, ix)
+    ts = ctx.text_stats()
+    assert ts["nnz"] == nnz and ts["n_vocab"] == nv and ts["host_fallback"] == 0 and ts["ms_total"] > 0
+    d_out = ctx.alloc(4 * len(rows))
+    for d in (1, 2):
+        ctx.cluster(d, d_out)
+        ctx.sync()
+        lab = ctx.download_i32(d_out, len(rows)).copy()
+        want, _ = _lib.cluster_csr(ip, ix, d)
+        assert np.array_equal(lab, want)
+        lab2, st, nnz3, nv3 = _lib.cluster_text(buf, off, " ", d)
+        assert np.array_equal(lab2, want) and (nnz3, nv3) == (nnz, nv)
+    # a second, smaller input on the same context: nothing of the first build may leak
+    rows2 = rows[:777]
+    buf2, off2 = _lib.pack_rows(rows2)
+    ctx.build_csr(buf2, off2, " ")
+    d_ip, d_ix = ctx.download_csr()
+    ip2, ix2, _ = _lib.build_csr_bytes(buf2, off2, " ")
+    assert np.array_equal(d_ip, ip2) and np.array_equal(d_ix, ix2)
+    ctx.close()
+
+
+def test_cluster_text_falls_back_to_the_host_tokeniser_for_inputs_the_device_declines():
+    rows = ["A||B", "A||B||C", "Q", "A||B"]
+    buf, off = _lib.pack_rows(rows)
+    lab, st, nnz, nv = _lib.cluster_text(buf, off, "||", 1)
+    assert lab.tolist() == [0, 0, 2, 0] and nnz == 8 and nv == 4
+
+
+def test_cluster_text_matches_oracle_labels():
+    rows = list(dict.fromkeys(generate_profiles(3000, p_del=0.05, p_ins=0.01)))
+    buf, off = _lib.pack_rows(rows)
+    ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
+    for d in (1, 3):
+        lab, st, _, _ = _lib.cluster_text(buf, off, " ", d)
+        assert np.array_equal(lab, orc.cluster_csr(ip, ix, d, n_threads=8)["labels"])
