@@ -3,7 +3,9 @@
 
   python bench.py [--gpus N --steps K --warmup W] [--rows R --max-dist D --indels --merge allgather|allreduce]
 
-`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes of
+`--gpus N` with N > 1 runs BASELINE configs[3] by default — 1M profiles, max-dist 1, the SAME input on every N (strong
+scaling; --rows / --max-dist / --indels choose another, e.g. configs[4]) — and, with no WORLD_SIZE in the environment,
+starts the N ranks itself (child processes of
 `python -m torch.distributed.run`, before this process has touched the GPU), relays rank 0's JSON line and exits
 with the children's status; under a launcher (WORLD_SIZE set) it is one rank.
 
@@ -13,10 +15,14 @@ What the ONE JSON line holds (every number is measured in this r
                          HBM -> canonical labels in HBM (+ RCCL label merge for N > 1); EXACTLY --steps steps timed
                          between barrier + synchronize; value = N_u(N_u-1)/2 pairs resolved per step / time.
   sustained              the same steps for >= 0.3 s (so that an outside sampler sees the GPU busy)
-  ms_per_step_cold       first step after a bind (k_verify launched, nothing memoised), median of 5 re-binds
-  t_cluster_host_ms      metric (1) as SURVEY 8(d) defines it: list of N_u strings in host memory -> labels in host
-                         memory through the C-ABI (bfk_build_csr + H2D + kernels + D2H): first call and steady state,
-                         and value_host_inclusive = pairs / steady time (PCIe-inclusive; never `value`)
+  ms_per_step_cold       first step after a bind, host-timed single step incl. its launch (median of 5 re-binds); the same
+                         kernels as a timed step (no step depends on an earlier one)
+  t_cluster_host_ms      metric (1) as SURVEY 8(d) defines it: N_u profile strings in host memory -> labels in host
+                         memory through ONE C-ABI call (bfk_cluster_text: text H2D, device tokeniser + vocabulary + CSR,
+                         kernels, labels D2H): first call, steady state, and with a text buffer the driver has never
+                         seen; value_host_inclusive = pairs / steady time (PCIe-inclusive; never `value`).
+                         `tokeniser`: phase times and the text-bytes-once roofline of the tokenising kernels;
+                         `host_tokeniser_path`: round 2's route (bfk_build_csr on the host cores + bfk_cluster_csr)
   clusters_tsv_wall_s    metric (2): a fresh subprocess of the CLI, input file -> clusters.tsv, sha256 of the output
                          checked against tests/golden/sha256.json (the digest of the reference's own output)
   all_pairs              the same step with the all-pairs kernels forced (k_sig .. k_prefilter .. k_verify): the
@@ -137,7 +143,7 @@ def kernel_source_digest():
     """sha256 over the device + host sources a libbfk.so is built from: a PMC file is only quoted as `traffic` when
     it was taken on exactly these sources (tools/profile_gpu.sh stamps it)."""
     h = hashlib.sha256()
-    for f in ("bfk_kernels.hip", "bfk_host.cpp", "bfk_device.h"):
+    for f in ("bfk_kernels.hip", "bfk_host.cpp", "bfk_device.h", "bfk_text.hip", "bfk_sort.hip"):
         h.update((ROOT / "breakfast_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -224,7 +230,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--rows", type=int, default=0, help="input sequences (default 100000*sqrt(gpus))")
+    ap.add_argument("--rows", type=int, default=0, help="input sequences (default: 100000 on one GPU, 1000000 on several)")
     ap.add_argument("--max-dist", type=int, default=1)
     ap.add_argument("--indels", action="store_true", help="config 5 generator: p_del=0.05 p_ins=0.01, indels kept")
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
@@ -244,7 +250,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
 
-    n_rows = a.rows or int(round(100000 * math.sqrt(world)))
+    # N = 1: BASELINE's metric workload (configs[2]: 100k profiles, max-dist 1).  N > 1: configs[3] — 1M profiles, max-dist 1,
+    # row-sharded across the ranks — the same input for every N (strong scaling)
+    n_rows = a.rows or (100000 if world == 1 else 1000000)
     d = a.max_dist
     full = world == 1 and not a.quick and a.pipeline == 1
 
@@ -279,34 +287,71 @@ def main():
     rows = list(dict.fromkeys(generate_profiles(n_rows, **kw)))  # collapse_duplicates: unique profiles
     n_u = len(rows)
 
-    # ---- metric (1), host-inclusive: strings in host memory -> labels in host memory through the one-shot C-ABI
+    # ---- metric (1), host-inclusive: strings in host memory -> labels in host memory through ONE C-ABI call
     host = None
     if full:
         raw = [r.encode() for r in rows]
         off = np.zeros(n_u + 1, dtype=np.int64)
         np.cumsum(np.fromiter((len(r) for r in raw), dtype=np.int64, count=n_u), out=off[1:])
         buf = b"".join(raw)
-
-        def one_shot():
-            t0 = time.perf_counter()
-            ip, ix, nv = _lib.build_csr_bytes(buf, off, " ")
-            t1 = time.perf_counter()
-            lab, st_ = _lib.cluster_csr(ip, ix, d)
-            t2 = time.perf_counter()
-            return (t1 - t0) * 1e3, (t2 - t1) * 1e3, lab
-
-        b0, c0, lab_first = one_shot()
-        reps = [one_shot()[:2] for _ in range(7)]
-        bs, cs = sorted(x[0] for x in reps), sorted(x[1] for x in reps)
-        steady = bs[len(bs) // 2] + cs[len(cs) // 2]
-        host = {"first_call": round(b0 + c0, 3), "steady": round(steady, 3),
-                "steady_build_csr": round(bs[len(bs) // 2], 3), "steady_cluster_csr": round(cs[len(cs) // 2], 3),
-                "first_build_csr": round(b0, 3), "first_cluster_csr": round(c0, 3),
-                "what": "N_u profile strings as one byte buffer + offsets (the C-ABI's input) -> bfk_build_csr (tokeniser + "
-                        "first-appearance vocabulary, host) -> bfk_cluster_csr (H2D of the CSR, kernels, D2H of the labels); "
-                        "first_call includes context creation, code-object load and allocations; steady = median of 7 "
-                        "further calls", "text_bytes": len(buf)}
         del raw
+
+        def one_shot(b=buf):
+            t0 = time.perf_counter()
+            lab, _, nnz_, nv_ = _lib.cluster_text(b, off, " ", d, want_stats=False)
+            return (time.perf_counter() - t0) * 1e3, lab, nnz_, nv_
+
+        t_first, lab_first, nnz_t, nv_t = one_shot()
+        reps = sorted(one_shot()[0] for _ in range(9))
+        fresh = []
+        for _ in range(3):  # a buffer the driver has never seen: its pages are pinned on the fly during the copy
+            b2 = bytes(bytearray(buf))
+            fresh.append(one_shot(b2)[0])
+
+        def old_route():
+            t0 = time.perf_counter()
+            ip, ix, _ = _lib.build_csr_bytes(buf, off, " ")
+            t1 = time.perf_counter()
+            _lib.cluster_csr(ip, ix, d)
+            return (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+
+        old = [old_route() for _ in range(3)]
+        # the tokeniser by itself: phase times (HIP events) of bfk_ctx_build_csr on a context of its own
+        tctx = _lib.Context(0)
+        tctx.set_profiling(True)
+        tph = []
+        for _ in range(7):
+            tctx.build_csr(buf, off, " ")
+            tph.append(tctx.text_stats())
+        tctx.close()
+        tmed = {kk: sorted(x[kk] for x in tph)[len(tph) // 2] for kk in ("ms_h2d", "ms_scan", "ms_hash", "ms_ids", "ms_total")}
+        t_kern = tmed["ms_scan"] + tmed["ms_hash"] + tmed["ms_ids"]
+        host = {"first_call": round(t_first, 3), "steady": round(reps[len(reps) // 2], 3), "steady_min": round(reps[0], 3),
+                "fresh_text_buffer": [round(x, 3) for x in fresh],
+                "what": "N_u profile strings as one byte buffer + offsets (the C-ABI's input) -> bfk_cluster_text: text + offsets "
+                        "H2D from the caller's pageable buffer, device tokeniser + first-appearance vocabulary + CSR "
+                        "(bfk_text.hip), clustering kernels, labels D2H; first_call includes context creation, code-object "
+                        "load and allocations; steady = median of 9 further calls on the same buffer (the driver keeps its "
+                        "pages pinned); fresh_text_buffer = calls on a new copy of the text each",
+                "text_bytes": len(buf), "nnz": nnz_t, "n_vocab": nv_t,
+                "tokeniser": {
+                    "phases_ms": tmed, "kernels_ms": t_kern,
+                    "roofline": {"bound": "hbm", "kernel": "k_tok_hash (dominant of the tokenising kernels)",
+                                 "algorithmic_bytes_per_launch": len(buf) + 4 * nnz_t,
+                                 "algorithmic_bytes_what": "every text byte once + one 4-byte slot per token written",
+                                 "kernel_ms": tmed["ms_hash"],
+                                 "achieved": (len(buf) + 4 * nnz_t) / (tmed["ms_hash"] * 1e-3) / 1e9 if tmed["ms_hash"] > 0 else None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (len(buf) + 4 * nnz_t) / (tmed["ms_hash"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tmed["ms_hash"] > 0 else None,
+                                 "all_tokenising_kernels": {
+                                     "bytes": 2 * len(buf) + 12 * nnz_t + 4 * n_u,
+                                     "what": "text twice (scan, hash) + slot written, read, id written per token + indptr",
+                                     "GBps": (2 * len(buf) + 12 * nnz_t + 4 * n_u) / (t_kern * 1e-3) / 1e9 if t_kern > 0 else None},
+                                 "pcie": {"GBps": len(buf) / (tmed["ms_h2d"] * 1e-3) / 1e9 if tmed["ms_h2d"] > 0 else None,
+                                          "note": "the text crosses PCIe once; that copy, not a kernel, is most of the call"}}},
+                "host_tokeniser_path": {"build_csr_ms": round(sorted(x[0] for x in old)[1], 3),
+                                        "cluster_csr_ms": round(sorted(x[1] for x in old)[1], 3),
+                                        "what": "round 2's route: bfk_build_csr on the host cores, then bfk_cluster_csr (CSR H2D)"}}
 
     indptr, indices, n_vocab = _lib.build_csr(rows, " ")
     nnz = int(indptr[-1])
@@ -405,6 +450,57 @@ def main():
         dist.all_gather(allne, ne)
         edges_per_rank = [int(x.item()) for x in allne]
 
+    # ---- N > 1: where a step's time goes on this rank (torch events on the launch stream, a separate pass of 16 steps:
+    # the rank's shard of the kernels, the label exchange, the merge) and — rank 0 alone, the others idle — the SAME
+    # workload on one GPU in the same run
+    exchange = one_gpu = None
+    if world > 1 and a.merge == "allgather" and pipe == 1:
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(16)]
+        for e4 in evs:
+            e4[0].record()
+            sc.e.cluster_shard(d, rank, world, sc.local)
+            e4[1].record()
+            dist.all_gather_into_tensor(sc.gathered.view(-1), sc.local.view(-1))
+            e4[2].record()
+            sc.e.merge(sc.gathered, world, sc.labels)
+            e4[3].record()
+        torch.cuda.synchronize()
+        eng.sync()
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        mine = [med([e4[i].elapsed_time(e4[i + 1]) for e4 in evs]) for i in range(3)]
+        tt = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        exchange = {"per_rank_ms": [{"shard_kernels": round(float(x[0]), 4), "all_gather": round(float(x[1]), 4),
+                                     "merge_flatten": round(float(x[2]), 4)} for x in allt],
+                    "payload_bytes_per_rank": 4 * n_u,
+                    "what": "median of 16 steps, events on the launch stream of each rank; all_gather includes waiting for the "
+                            "slowest rank's shard"}
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            sc1 = ShardedClusterer(eng, 0, 1, a.merge)
+            sc1.bind(indptr, indices)
+            for _ in range(3):
+                for _ in range(max(5, min(a.warmup, 20))):
+                    sc1.step(d)
+                if eng.sync()["n_retry_slices"] == 0:
+                    break
+            k1 = max(20, min(a.steps, 200))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                sc1.step(d)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t0
+            st1 = eng.sync()
+            lab1 = sc1.labels[0][:n_u].cpu().numpy()
+            one_gpu = {"ms_per_step": e1 / k1 * 1e3, "steps": k1, "value": n_u * (n_u - 1) / 2 * k1 / e1,
+                       "labels_equal_n_gpu_run": bool(np.array_equal(lab1, labels)), "path": st1["path"],
+                       "what": "the same input clustered by rank 0's GPU alone (world 1), timed after the N-rank steps while "
+                               "the other ranks wait: ms_per_step of this line / this = the speed-up the N GPUs gave"}
+        dist.barrier()
+
     # ---- first step after a bind: k_verify launched, nothing memoised about this CSR
     cold = None
     if world == 1 and pipe == 1:
@@ -475,22 +571,31 @@ def main():
             recs = d + 2
             R = recs * n_u / world
             checked = st["n_candidates"] - st.get("n_connected", 0)
-            b_verify = st["n_candidates"] * 32 + checked * 8 * k_mean
-            b_pgjoin = st["pairs_filtered"] * 16 + 12 * R + 16 * n_u / world + st["n_candidates"] * 32
+            # bytes each kernel must move when everything is read / written ONCE (what `frac` prices), and — labelled
+            # apart, never part of `frac` — the bytes of its repeated visits (a group member is visited by every row in
+            # front of it in the group; a row is read by every candidate it is part of)
+            once_pgjoin = 24 * R + 16 * n_u / world + 32 * st["n_candidates"]
+            once_verify = 32 * st["n_candidates"] + 8 * n_u + min(checked * 8 * k_mean, 4 * nnz + 4 * n_u)
+            visits_pgjoin = st["pairs_filtered"] * 16
+            visits_verify = checked * 8 * k_mean
             if st["ms_verify"] >= st["ms_prefilter"]:
                 dom = "k_verify_connected" if st.get("n_connected", 0) else "k_verify"
                 t_dom = st["ms_verify"] * 1e-3
-                comp = b_verify
-                comp_what = ("per candidate: 24-byte queue record + 2 parent words; per candidate checked exactly (n_candidates - "
-                             "n_connected): both rows' tokens (8*k_mean B)")
+                comp = once_verify
+                visits = visits_verify
+                comp_what = ("read / written once: 24-byte queue record + 8 B of row extents per candidate, the forest (4 B read + "
+                             "4 B written per row), the tokens of the rows that are checked (at most the CSR once)")
+                visits_what = "both rows' tokens (8*k_mean B) per candidate checked exactly (n_candidates - n_connected)"
             else:
                 dom = "k_pgjoin"
-                comp = b_pgjoin
-                comp_what = ("16 B per group member visited + per row 12 B per record (key, position, count) and 16 B of length / "
-                             "signature + 32 B per queued pair (record written, row extents read)")
-            # + band prep that still runs (k_sig .. k_place: tokens once, signatures / keys), k_pgkeys (tokens once, 8 B per
-            # record out), three radix passes (8 B per record in and out each), k_pgplace (8 B in, 16 B gathered, 24 B out)
-            step_bytes = (2 * 4 * nnz + (84 + 16 * w) * n_u) / world + 8 * R + 3 * 16 * R + 48 * R + b_pgjoin + b_verify
+                comp = once_pgjoin
+                visits = visits_pgjoin
+                comp_what = ("read / written once: the group order (16 B record + 8 B position/count per record, (d+2) records "
+                             "per row), 16 B of length / signature per row, 32 B per queued pair (record written, extents read)")
+                visits_what = "16 B per group member visited (a member is visited once by every row in front of it in its group)"
+            # whole step: tokens twice (k_pgfreq sample + k_pgkeys), 8 B per record out, three radix passes (8 B in and
+            # out each), k_pgplace (8 B in, 16 B gathered, 24 B out), then the two kernels above, flatten
+            step_bytes = (4 * nnz + 20 * n_u) / world + 8 * R + 3 * 16 * R + 48 * R + once_pgjoin + once_verify + 8 * n_u
         else:
             dom = f"k_prefilter<W={w}>"
             comp = (4 * w * n_u + 16 * n_u) / world
@@ -507,6 +612,10 @@ def main():
             "traffic": tr["bytes"] if tr else None,
             "traffic_detail": tr,
             "algorithmic_bytes_per_launch": comp, "algorithmic_bytes_what": comp_what,
+            **({"algorithmic_visits": {"bytes": visits, "what": visits_what,
+                                       "GBps": visits / t_dom / 1e9 if t_dom > 0 else None,
+                                       "note": "re-reads served by L2 / Infinity Cache: work the kernel does, not bytes it must "
+                                               "move once; never part of `frac`"}} if prefix else {}),
             "kernel_ms": t_dom * 1e3,
             "kernel_ms_source": "HIP events on the launch stream around the kernel, mean of 64 steps (includes the "
                                 "launch gap, ~3 us more than rocprofv3's kernel time: profiles/)",
@@ -555,7 +664,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -573,10 +682,8 @@ def main():
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 "input": "CSR resident in HBM (host-inclusive figures: t_cluster_host_ms)",
-                "steady_state_memo": ("k_verify is not launched in the timed steps: the previous synced step on this CSR queued "
-                                      "nothing for it (the queued set is a function of the CSR only; k_flatten re-checks). The "
-                                      "first step after a bind launches it: ms_per_step_cold" if join else None),
-                **({"collective_backend": backend, "world_size": world, "n_edges_per_rank": edges_per_rank} if world > 1 else {}),
+                **({"collective_backend": backend, "world_size": world, "n_edges_per_rank": edges_per_rank,
+                    "step_phases": exchange, "one_gpu_same_workload": one_gpu} if world > 1 else {}),
                 **({"pipeline": f"{pipe} contexts on {pipe} streams, steps round-robin (opt-in experiment)"} if pipe > 1 else {}),
             },
             "roofline": roof,
@@ -596,6 +703,7 @@ def main():
             out["value_host_inclusive"] = resolved / (host["steady"] * 1e-3)
         if cli:
             out["clusters_tsv_wall_s"] = cli.get("seconds")
+            out["clusters_tsv_wall_median_s"] = cli.get("median_s")
             out["clusters_tsv"] = cli
         if allpairs:
             out["all_pairs"] = allpairs

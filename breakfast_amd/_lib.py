@@ -214,8 +214,9 @@ def build_csr_device(features, sep: str):
     return build_csr_bytes(buf, off, sep, device=True)
 
 
-def cluster_text(buf: bytes, row_off, sep: str, max_dist: int):
-    """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device."""
+def cluster_text(buf: bytes, row_off, sep: str, max_dist: int, want_stats: bool = True):
+    """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device.
+    want_stats=False passes stats_out = NULL (the counters that need host-side sums are then not gathered)."""
     lib = load()
     off = np.ascontiguousarray(row_off, dtype=np.int64)
     n = len(off) - 1
@@ -223,12 +224,12 @@ def cluster_text(buf: bytes, row_off, sep: str, max_dist: int):
     labels = np.empty(max(n, 1), dtype=np.int32)
     st = Stats()
     nnz, nv = C.c_int64(), C.c_int32()
-    rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels), C.byref(st), C.byref(nnz),
-                              C.byref(nv))
+    rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels),
+                              C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv))
     if rc == -1 and len(sepb) == 0:
         raise ValueError("empty separator")
     _check(rc)
-    return labels[:n], st.as_dict(), int(nnz.value), int(nv.value)
+    return labels[:n], (st.as_dict() if want_stats else None), int(nnz.value), int(nv.value)
 
 
 def cluster_csr(indptr, indices, max_dist: int, n_gpus: int = 1):

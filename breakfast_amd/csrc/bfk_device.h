@@ -111,19 +111,19 @@ struct Plan {
 // ---- device tokeniser (bfk_text.hip): profile text -> first-appearance vocabulary -> CSR --------------------------
 constexpr int TOK_WIN = 1024;                          // bytes per wave step: 16 per lane
 constexpr int TOK_WPW = 4;                             // windows per wave
-constexpr int TOK_BLOCK_BYTES = 4 * TOK_WPW * TOK_WIN; // 16 KiB of text per block of 4 waves
-constexpr int TOK_FIRST_PER_BLOCK = 2048;              // tokens per block of k_tok_first (8 per thread)
+constexpr int TOK_BLOCK_BYTES = 4 * TOK_WPW * TOK_WIN; // 16 KiB of text per block of 4 waves (k_tok_hash)
+constexpr int TOK_SCAN_WINS = 64;                      // windows per block of k_tok_scan / k_voc_count (16 waves): 64 KiB of text
+constexpr int TOK_PAD_BYTES = TOK_SCAN_WINS * TOK_WIN; // the text is padded to a multiple of this
 constexpr int TOK_TEXT_SLACK = 64;                     // separator bytes behind T_pad (unaligned 8-byte reads of a token's tail)
 constexpr uint32_t TOK_MAX_LEN = 65534;                // longest token the table word can describe (16-bit length)
 constexpr int TOK_MAX_PROBE = 512;                     // probe chain at which the table counts as too full
 constexpr unsigned long long TOK_EMPTY = ~0ull;        // free slot of the vocabulary table {tag16 : len16 : offset32}
-enum : int { TOK_FAIL_ROWOFF = 1, TOK_FAIL_LONG = 2, TOK_FAIL_TABLE = 4, TOK_FAIL_SPIN = 8 };
+enum : int { TOK_FAIL_ROWOFF = 1, TOK_FAIL_LONG = 2, TOK_FAIL_TABLE = 4 };
 
 struct TokCounters {
-    unsigned int ticket_scan, ticket_first;  // arrival order of the blocks of k_tok_scan / k_tok_first
     unsigned int nnz, n_vocab;
     int fail;  // TOK_FAIL_*
-    int pad_[3];
+    int pad_[5];
 };
 
 struct TokArgs {
@@ -134,16 +134,18 @@ struct TokArgs {
     int n_rows;
     uint8_t sep;
     uint32_t *rowbits, *startbits, *boundbits;  // one bit per byte position: row start / token start / separator or row start
-    uint32_t *winbase;         // [T_pad / TOK_WIN + 1]: tokens in front of every window
+    uint32_t *firstbits;       // ... / a token's first occurrence starts here
+    uint32_t *winbase, *vocwin; // [T_pad / TOK_WIN]: tokens / vocabulary entries in front of every window inside its scan block
+    uint32_t *blkbase, *vocblk; // [T_pad / TOK_PAD_BYTES + 1]: ... in front of every scan block (k_scan_single)
     unsigned long long *table; // tmask + 1 slots
     uint32_t tmask;
     int *tabid;                // vocabulary id per slot
-    uint32_t *tokslot, *tokoff; // per token: its slot, its byte offset (tokslot aliases `indices`)
+    uint32_t *tokslot;         // per token: its slot (aliases `indices`)
     uint32_t *indices;
     int *indptr;
-    unsigned long long *chain_scan, *chain_first;
     TokCounters *tc;
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
+    int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 2 no table loads, 4 no byte compares
 };
 int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev);  // bfk_text.hip
 

@@ -117,16 +117,18 @@ struct bfk_ctx {
     // device tokeniser (bfk_ctx_build_csr, bfk_text.hip): text, bit arrays, vocabulary table, per-token scratch
     uint8_t *tk_text = nullptr;
     long long *tk_rowoff = nullptr;
-    char *tk_zero = nullptr;  // [TokCounters | chain_scan | chain_first | rowbits]: zeroed by ONE memset per build
-    uint32_t *tk_bits = nullptr, *tk_winbase = nullptr, *tk_tokoff = nullptr;
+    char *tk_zero = nullptr;  // [TokCounters | rowbits | firstbits]: zeroed by ONE memset per build
+    uint32_t *tk_bits = nullptr, *tk_winbase = nullptr;
     unsigned long long *tk_table = nullptr;
     int *tk_tabid = nullptr;
-    int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_tokoff_cap = 0,
-            tk_table_cap = 0, tk_tabid_cap = 0;
+    int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_table_cap = 0,
+            tk_tabid_cap = 0;
     int tk_grow = 0;  // how often the table was enlarged 8x for this context's inputs (kept: the next input is likely alike)
     hipEvent_t tk_ev[6] = {};
     bool tk_ev_ready = false;
     bfk_text_stats tk_stats{};
+    bool tok_pending = false;  // the tokeniser's counters (d_small[8..15]) are to come back with the next bind's copy
+    int tok_host[8] = {0};
     // last run
     bool ran = false;
     int last_d = 0, last_w1 = 0, last_shards = 1;
@@ -193,7 +195,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->tk_text, c->tk_rowoff,
-                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_tokoff, c->tk_table, c->tk_tabid};
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -345,21 +347,22 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
 
 static int ctx_after_bind(bfk_ctx *c) {
     c->last_tiles = 0;  // another CSR: no tile count known yet
-    // nnz and the longest row come back once per bind (set-up, not part of a timed step)
-    int h[3] = {0, 0, 0};
-    HIP_TRY(hipMemsetAsync(c->d_small, 0, 16, c->stream));
-    int nnz32 = 0;
+    // nnz, the longest row — and the tokeniser's counters, when it built this CSR (d_small[8..15]) — come back in ONE
+    // small copy per bind (every small device-to-host copy costs ~20 us of driver time; set-up, not part of a timed step)
+    int h[16] = {0};
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 32, c->stream));
     if (c->n > 0) {
         if (int e = launch_maxlen(c->d_indptr, (int)c->n, c->d_small, c->stream))
             return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
-        HIP_TRY(hipMemcpyAsync(h, c->d_small, 12, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&nnz32, c->d_indptr + c->n, 4, hipMemcpyDeviceToHost, c->stream));
-        int first = 0;
-        HIP_TRY(hipMemcpyAsync(&first, c->d_indptr, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (h[1] || first != 0 || nnz32 < 0) return fail(BFK_EARG, "malformed CSR: indptr must start at 0 and be non-decreasing");
     }
-    c->nnz = nnz32;
+    if (c->n > 0 || c->tok_pending) {
+        HIP_TRY(hipMemcpyAsync(h, c->d_small, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    memcpy(c->tok_host, h + 8, sizeof c->tok_host);
+    c->tok_pending = false;
+    if (c->n > 0 && (h[1] || h[4] != 0 || h[3] < 0)) return fail(BFK_EARG, "malformed CSR: indptr must start at 0 and be non-decreasing");
+    c->nnz = c->n > 0 ? h[3] : 0;
     c->kcap = h[0];
     c->n_short = h[2];
     c->max_tok = -1;
@@ -414,22 +417,21 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     if (T < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
     if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
     if (T > (int64_t)0xFFF00000ll) return fail(BFK_EUNSUPPORTED, "device tokeniser: 32-bit byte offsets (text of 4 GiB or more)");
-    const int64_t T_pad = round_up(T + 1, TOK_BLOCK_BYTES);
+    const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     // every token but the last of a row is followed by a separator: at most T/2 + n_rows + 1 tokens
     const int64_t nnz_cap = T / 2 + n_rows + 1;
-    if (nnz_cap > (int64_t)INT32_MAX - 4 * TOK_FIRST_PER_BLOCK) return fail(BFK_EUNSUPPORTED, "device tokeniser: more than 2^31 possible tokens");
-    const int64_t nnz_alloc = round_up(nnz_cap, TOK_FIRST_PER_BLOCK) + 16;
-    const int64_t n_win = T_pad / TOK_WIN, scan_blocks = T_pad / TOK_BLOCK_BYTES, first_blocks = nnz_alloc / TOK_FIRST_PER_BLOCK + 1;
-    // zeroed region: counters | chain_scan | chain_first | rowbits
-    const int64_t z_chain1 = 64, z_chain2 = z_chain1 + round_up((scan_blocks + 1) * 8, 64),
-                  z_rowbits = z_chain2 + round_up((first_blocks + 1) * 8, 64), z_bytes = z_rowbits + T_pad / 8 + 64;
+    if (nnz_cap > (int64_t)INT32_MAX - 4096) return fail(BFK_EUNSUPPORTED, "device tokeniser: more than 2^31 possible tokens");
+    const int64_t nnz_alloc = round_up(nnz_cap, 1024) + 16;
+    const int64_t n_win = T_pad / TOK_WIN;
+    // zeroed region: rowbits | firstbits (the counters live in d_small[8..15] and travel with the bind's copy)
     const int64_t bit_words = T_pad / 32 + 16;
+    const int64_t z_rowbits = 0, z_firstbits = z_rowbits + bit_words * 4, z_bytes = z_firstbits + bit_words * 4;
     if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n_rows + 1, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_zero, &c->tk_zero_cap, z_bytes, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 2 * bit_words, 1.05)) return rc;
-    if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, n_win + 2, 1.05)) return rc;
-    if (int rc = dev_realloc(&c->tk_tokoff, &c->tk_tokoff_cap, nnz_alloc, 1.05)) return rc;
+    const int64_t n_blk = round_up(T_pad / TOK_PAD_BYTES + 1, 4) + 4;  // (+ the total behind the last block; 16-byte pieces)
+    if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, 2 * (n_win + n_blk), 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
     if (c->profiling && !c->tk_ev_ready) {
@@ -447,16 +449,18 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     TokCounters tc{};
     int rc_bind = BFK_OK;
     for (int attempt = 0;; attempt++) {
-        // vocabulary table: 1/8 slot per possible token (real inputs: ~8 bytes per token, a vocabulary of a few % of the
-        // tokens -> load of a few %); an input with more distinct tokens than that overflows the probe limit, the table
-        // grows 8x (twice at most: 8 slots per possible token) and the kernels run again on the resident text
+        // vocabulary table: 1/32 slot per possible token (real inputs: ~8 bytes per token — a quarter of the bound — and a
+        // vocabulary of a few % of the tokens: load below 20%); an input with more distinct tokens overflows the probe
+        // limit, the table grows 8x (twice at most: 2 slots per possible token) and the kernels run again on the
+        // resident text
         int64_t slots = 1 << 16;
-        while (slots < nnz_cap / 8) slots <<= 1;
+        while (slots < nnz_cap / 32) slots <<= 1;
         slots <<= 3 * c->tk_grow;
         if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
         if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
         if (int rc = dev_realloc(&c->tk_tabid, &c->tk_tabid_cap, slots)) return rc;
         HIP_TRY(hipMemsetAsync(c->tk_zero, 0, (size_t)z_bytes, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_small + 8, 0, 32, c->stream));
         HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * 8, c->stream));
         TokArgs a{};
         a.text = c->tk_text;
@@ -466,31 +470,34 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         a.T_pad = (uint32_t)T_pad;
         a.n_rows = (int)n_rows;
         a.sep = (uint8_t)sep[0];
-        a.tc = (TokCounters *)c->tk_zero;
-        a.chain_scan = (unsigned long long *)(c->tk_zero + z_chain1);
-        a.chain_first = (unsigned long long *)(c->tk_zero + z_chain2);
+        a.tc = (TokCounters *)(c->d_small + 8);
         a.rowbits = (uint32_t *)(c->tk_zero + z_rowbits);
+        a.firstbits = (uint32_t *)(c->tk_zero + z_firstbits);
         a.startbits = c->tk_bits;
         a.boundbits = c->tk_bits + bit_words;
         a.winbase = c->tk_winbase;
+        a.vocwin = c->tk_winbase + n_win;
+        a.blkbase = c->tk_winbase + 2 * n_win;
+        a.vocblk = c->tk_winbase + 2 * n_win + n_blk;
         a.table = c->tk_table;
         a.tmask = (uint32_t)(slots - 1);
         a.tabid = c->tk_tabid;
         a.tokslot = c->own_indices;
-        a.tokoff = c->tk_tokoff;
         a.indices = c->own_indices;
         a.indptr = c->own_indptr;
         a.nnz_cap = nnz_cap;
+        a.dbg = getenv("BFK_TOK_DEBUG") ? atoi(getenv("BFK_TOK_DEBUG")) : 0;
         if (int e = launch_tokenize(a, c->stream, ev)) return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
-        HIP_TRY(hipMemcpyAsync(&tc, c->tk_zero, sizeof tc, hipMemcpyDeviceToHost, c->stream));
-        // bind: the sync inside (longest row, nnz) also lands the counters above
+        // bind: its one copy + sync (longest row, nnz) also lands the tokeniser's counters
         c->d_indptr = c->own_indptr;
         c->d_indices = c->own_indices;
         c->n = n_rows;
+        c->tok_pending = true;
         rc_bind = ctx_after_bind(c);
         if (rc_bind == BFK_EHIP) return rc_bind;
-        if (n_rows == 0) HIP_TRY(hipStreamSynchronize(c->stream));  // (ctx_after_bind has nothing to wait for then)
-        if (!(tc.fail & TOK_FAIL_TABLE) || (tc.fail & (TOK_FAIL_ROWOFF | TOK_FAIL_LONG | TOK_FAIL_SPIN))) break;
+        static_assert(sizeof(TokCounters) == sizeof c->tok_host, "TokCounters = d_small[8..15]");
+        memcpy(&tc, c->tok_host, sizeof tc);
+        if (!(tc.fail & TOK_FAIL_TABLE) || (tc.fail & (TOK_FAIL_ROWOFF | TOK_FAIL_LONG))) break;
         if (attempt >= 2 || slots >= ((int64_t)1 << 31)) break;
         c->tk_grow++;
     }
@@ -502,7 +509,6 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     if (tc.fail) {
         c->n = -1;  // nothing usable is bound
         if (tc.fail & TOK_FAIL_ROWOFF) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
-        if (tc.fail & TOK_FAIL_SPIN) return fail(BFK_EHIP, "device tokeniser: look-back did not complete");
         if (tc.fail & TOK_FAIL_LONG) return fail(BFK_EUNSUPPORTED, "device tokeniser: a token of 64 KiB or more (the host tokeniser takes it)");
         return fail(BFK_EUNSUPPORTED, "device tokeniser: vocabulary table overflow (the host tokeniser takes it)");
     }
@@ -631,7 +637,7 @@ static int pg_key_bits(bfk_ctx *c, int *tb_out) {
     return BFK_OK;
 }
 
-static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
+static int ctx_size_pg(bfk_ctx *c, int recs, int key_bits, size_t *temp_bytes) {
     const int64_t total = c->n * recs;
     if (!c->pg_cnt && hipMalloc((void **)&c->pg_cnt, sizeof(uint32_t) << PG_CNT_BITS) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc(token counts) failed");
     if (int rc = dev_realloc(&c->pg_rowinfo, &c->pg_rowinfo_cap, c->n + SIG_PAD_ROWS)) return rc;
@@ -648,7 +654,7 @@ static int ctx_size_pg(bfk_ctx *c, int recs, size_t *temp_bytes) {
         c->pg_rec_cap = total;
     }
     size_t tb = 0;
-    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, 32, c->stream))
+    if (int e = sort_records(nullptr, &tb, c->pg_keys, c->pg_keys_s, c->pg_rows, c->pg_rows_s, (size_t)total, key_bits, c->stream))  // (the bits that will be sorted: the size is asked for exactly that call)
         return fail(BFK_EHIP, std::string("radix sort set-up: ") + hipGetErrorString((hipError_t)e));
     if ((int64_t)tb > c->pg_temp_cap) {
         if (c->pg_temp) (void)hipFree(c->pg_temp);
@@ -800,8 +806,10 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.bits = (uint32_t *)(cur ? bits1 : bits0);
         pl.ja.bits_next = (uint32_t *)(cur ? bits0 : bits1);
         pl.ja.rowhash = (uint2 *)(bits1 + c->join_bits / 8);
-        pl.join_skip_verify = (c->join_empty_shard == shard && c->join_empty_shards == n_shards && !c->edge_capture &&
-                               2 * c->kcap <= VERIFY_MAX_TOKENS && !getenv("BFK_CAND_CAP_SHARD")) ? 1 : 0;
+        // k_verify is launched in every step, also when the queue will turn out empty (ordered profiles): a step never
+        // relies on what an earlier step on this CSR found (round 2 skipped the launch after a synced step with an empty
+        // queue: ~5 us per step that only a second step on the same CSR ever saw)
+        pl.join_skip_verify = 0;
         // k_verify only sees what k_join could not certify itself (rows in no common order, rows over 64 tokens)
         if (!getenv("BFK_VERIFY_GRID")) pl.verify_grid = 256;
         pl.ja.dups = (int2 *)((char *)pl.ja.rowhash + (c->n + 16) * 8);
@@ -816,7 +824,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     if (!pl.join && pg_wanted(c, max_dist)) {
         if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
         size_t tb = 0;
-        if (int rc = ctx_size_pg(c, max_dist + 2, &tb)) return rc;
+        if (int rc = ctx_size_pg(c, max_dist + 2, pl.pg_tb, &tb)) return rc;
         pl.pg = 1;
         pl.pg_recs = max_dist + 2;
         pl.pg_cnt = c->pg_cnt;
@@ -1043,8 +1051,8 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             }
             s.pairs_in_band = (int64_t)acc;
         }
-        {   // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
-            std::vector<int> ts(c->plan.pg ? (size_t)0 : (size_t)h.n_work * c->plan.pf_waves);
+        if (out) {  // pair slots the prefilter evaluated: per-tile counts written by the waves, summed here
+            std::vector<int> ts(c->plan.pg || c->plan.join ? (size_t)0 : (size_t)h.n_work * c->plan.pf_waves);
             if (!ts.empty()) HIP_TRY(hipMemcpy(ts.data(), c->d_tile_slots, ts.size() * 4, hipMemcpyDeviceToHost));
             int64_t acc = c->plan.pg ? (int64_t)h.pairs_filtered : 0;  // prefix groups: members of the rows' groups visited
             for (size_t t = 0; t < ts.size(); t++) acc += ts[t];  // tiles of other ranks' cells hold 0

@@ -138,8 +138,12 @@ __device__ __forceinline__ uint32_t hash3(uint32_t x) {
 // ------------------------------------------------------------------------------------------------
 // k_maxlen: validate indptr, find the longest row (bind time only)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens*/) {
+__global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens, [3]=indptr[n], [4]=indptr[0]*/) {
     __shared__ int s_k[4], s_short[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[3] = indptr[n];
+        out[4] = indptr[0];
+    }
     int kmax = 0, n_short = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // (grid-stride: one set of atomics per block)
         int k = indptr[i + 1] - indptr[i];

@@ -13,17 +13,24 @@
 //   k_tok_rowbits  one thread per row: row_off validated (monotone, inside the text), bit `row start` set
 //   k_tok_scan     16 bytes per lane, 1 KiB per wave step: separator bytes by SWAR compare -> 16-bit masks; a token
 //                  STARTS at a non-separator byte whose predecessor is a separator or which starts a row; a token ENDS
-//                  at the next separator or row start.  Start / bound masks are stored (T/8 bytes each), token starts are
-//                  counted per window and prefix-summed over the whole text by a decoupled look-back (one pass)
+//                  at the next separator or row start.  Start / bound masks are stored (T/8 bytes each), token starts
+//                  counted per 1 KiB window
+//   k_scan_single  exclusive prefix sum of the window counts by ONE block (n/1024 values: 31k at 100k rows, 325k at 1M).
+//                  (A decoupled look-back inside k_tok_scan was tried first: blocks of equal, tiny work all start together
+//                  and every one of them then walks back over ~2000 unfinished predecessors — 85 ns per block, serial:
+//                  1.7 ms at 1M rows against 0.03 ms for this kernel)
 //   k_tok_hash     a lane takes the tokens that start in its 16 bytes: end from the bound bits, 32-bit hash of the bytes,
 //                  insert into an open-addressing table of 64-bit words {tag : length : byte offset of the token}:
 //                  empty -> compare-and-swap; tag and length equal -> the BYTES are compared (the table is exact: hash
 //                  collisions cost a probe, never an id) and the word is lowered to the smaller offset by atomicMin, so
-//                  a slot ends up holding the offset of the token's FIRST occurrence.  Per token: slot + offset stored
-//   k_tok_rows     one thread per row: indptr[r] = number of token starts in front of row_off[r]
-//   k_tok_first    a token is the first occurrence of its vocabulary entry iff its offset is the one its slot holds;
-//                  first-appearance id = number of first occurrences in front of it = a prefix sum over the token
-//                  sequence (look-back again) — no sort of the vocabulary
+//                  a slot ends up holding the offset of the token's FIRST occurrence.  Per token: its slot is stored.
+//                  The first 4 KiB of text go first, in a launch of their own: the tokens every row carries are in
+//                  the table before 8000 waves ask for them at once (same-address atomics serialise at ~11 ns each)
+//   k_tok_rows     one thread per row: indptr[r] = number of token starts in front of row_off[r]; and one thread per
+//                  table slot: bit `first occurrence` set at the byte offset the slot holds
+//   k_voc_count    first-occurrence bits counted per window; k_scan_single again -> vocabulary entries in front of a window
+//   k_voc_ids      one thread per slot: FIRST-APPEARANCE id = first occurrences in front of the slot's offset — ids by
+//                  counting bits, no sort of the vocabulary and no pass over the tokens
 //   k_tok_ids      indices[g] = id of token g's slot
 //
 // Every buffer is O(text): at 1M rows (333 MB of text) ~2 GB of the 288.
@@ -68,40 +75,6 @@ __device__ __forceinline__ uint32_t eq_bytes4(uint32_t w, uint32_t sepx4) {
     return (z * 0x01020408u) >> 24;
 }
 
-// Decoupled look-back over a chain of status words (flag << 62 | value), one word per logical block; called by ONE full
-// wave of the block with the block's total.  Returns the sum of the totals of the blocks in front.  A block's logical
-// index comes from an arrival ticket, so it only ever waits for blocks that have started.
-__device__ __forceinline__ unsigned lookback_exclusive(unsigned long long *chain, int bid, unsigned total, int lane, int *fail) {
-    const unsigned long long FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VAL = (1ull << 62) - 1ull;
-    if (lane == 0 && bid > 0) __hip_atomic_store(&chain[bid], FLAG_AGG | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long before = 0;
-    for (int w0 = bid - 1; w0 >= 0; w0 -= 64) {
-        const int p = w0 - lane;
-        unsigned long long v = 0ull;
-        if (p >= 0) {
-            int spins = 0;
-            while (((v = __hip_atomic_load(&chain[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) {  // never expected: bound the spin
-                    atomicOr(fail, TOK_FAIL_SPIN);
-                    v = FLAG_INC;
-                    break;
-                }
-            }
-        }
-        const unsigned long long inc_mask = __builtin_amdgcn_ballot_w64(p >= 0 && (v >> 62) == 2ull);
-        const int stop = inc_mask ? (int)__builtin_ctzll(inc_mask) : 64;
-        unsigned long long val = (p >= 0 && lane <= stop) ? (v & VAL) : 0ull;
-        for (int s = 32; s > 0; s >>= 1) val += __shfl_xor(val, s);
-        before += val;
-        if (inc_mask) break;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (lane == 0)
-        __hip_atomic_store(&chain[bid], FLAG_INC | (before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    return (unsigned)before;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -117,15 +90,11 @@ __global__ __launch_bounds__(256) void k_tok_rowbits(TokArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tok_scan(TokArgs a) {
-    __shared__ unsigned s_cnt[4 * TOK_WPW];
-    __shared__ int s_bid;
+__global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a) {
+    __shared__ unsigned s_cnt[TOK_SCAN_WINS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.tc->ticket_scan, 1u);
-    __syncthreads();
-    const int bid = s_bid;
-    const uint32_t win0 = ((uint32_t)bid * 4 + wave) * TOK_WPW;  // this wave's first window
+    const uint32_t win0 = (uint32_t)blockIdx.x * TOK_SCAN_WINS + wave * TOK_WPW;  // this wave's first window
     const uint32_t sepx4 = (uint32_t)a.sep * 0x01010101u;
     uint4 v[TOK_WPW];
     uint32_t rb[TOK_WPW];
@@ -151,22 +120,58 @@ __global__ __launch_bounds__(256) void k_tok_scan(TokArgs a) {
         reinterpret_cast<uint16_t *>(a.startbits)[(w0 >> 4) + lane] = (uint16_t)start;
         reinterpret_cast<uint16_t *>(a.boundbits)[(w0 >> 4) + lane] = (uint16_t)bound;
         const int inc = tok_wave_incl_scan(__popc(start));
-        const unsigned tot = (unsigned)__builtin_amdgcn_readlane(inc, 63);
-        if (lane == 0) s_cnt[wave * TOK_WPW + i] = tot;
+        if (lane == 63) s_cnt[wave * TOK_WPW + i] = (unsigned)inc;
         prev_sep = ((uint32_t)__builtin_amdgcn_readlane((int)m, 63) >> 15) & 1u;
     }
     __syncthreads();
-    if (wave == 0) {
-        constexpr int NW = 4 * TOK_WPW;
-        const int c = lane < NW ? (int)s_cnt[lane] : 0;
+    if (wave == 0) {  // tokens in front of every window INSIDE the block; the block's total goes to the scan of the blocks
+        const int c = (int)s_cnt[lane];
         const int inc = tok_wave_incl_scan(c);
-        const unsigned total = (unsigned)__builtin_amdgcn_readlane(inc, 63);
-        const unsigned before = lookback_exclusive(a.chain_scan, bid, total, lane, &a.tc->fail);
-        if (lane < NW) a.winbase[(uint32_t)bid * NW + lane] = before + (unsigned)(inc - c);
-        if (lane == 0 && bid + 1 == (int)gridDim.x) {
-            a.tc->nnz = before + total;
-            a.winbase[(uint32_t)gridDim.x * NW] = before + total;
-        }
+        a.winbase[(uint32_t)blockIdx.x * TOK_SCAN_WINS + lane] = (uint32_t)(inc - c);
+        if (lane == 63) a.blkbase[blockIdx.x] = (uint32_t)inc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_single: in-place exclusive prefix sum of data[0 .. n) by one block of 1024 threads, data[n] = *total_out = sum.
+// Thread t owns a contiguous piece (a multiple of 4 values: 16-byte loads and stores).
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n, unsigned *total_out) {
+    __shared__ unsigned s_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u;
+    const uint32_t b = min(n, threadIdx.x * per), e = min(n, b + per);
+    unsigned sum = 0;
+    uint32_t i = b;
+    for (; i + 4 <= e; i += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(data + i);
+        sum += q.x + q.y + q.z + q.w;
+    }
+    for (; i < e; i++) sum += data[i];
+    const unsigned inc = (unsigned)tok_wave_incl_scan((int)sum);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned run = inc - sum;
+    unsigned total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) run += s_w[w];
+        total += s_w[w];
+    }
+    i = b;
+    for (; i + 4 <= e; i += 4) {
+        uint4 q = *reinterpret_cast<const uint4 *>(data + i);
+        const unsigned x0 = run, x1 = x0 + q.x, x2 = x1 + q.y, x3 = x2 + q.z;
+        run = x3 + q.w;
+        q.x = x0; q.y = x1; q.z = x2; q.w = x3;
+        *reinterpret_cast<uint4 *>(data + i) = q;
+    }
+    for (; i < e; i++) {
+        const unsigned x = data[i];
+        data[i] = run;
+        run += x;
+    }
+    if (threadIdx.x == 0) {
+        data[n] = total;
+        *total_out = total;
     }
 }
 
@@ -197,130 +202,211 @@ __device__ __forceinline__ bool same_bytes(const uint8_t *p, const uint8_t *q, u
     return ((ldu64(p + k) ^ ldu64(q + k)) & mask) == 0ull;
 }
 
-__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a) {
+// tokens of at most 16 bytes (all of a mutation profile's): bytes in two registers, no loop
+__device__ __forceinline__ unsigned long long low_bytes(unsigned long long w, uint32_t n) {  // n in 0..8
+    return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
+}
+
+// the probe chain of one token from `slot` on (any token length): -> the token's slot
+__device__ __forceinline__ uint32_t tok_probe(const TokArgs &a, uint32_t slot, uint32_t hi, uint32_t j, uint32_t len) {
+    const uint8_t *p = a.text + j;
+    const unsigned long long me = ((unsigned long long)hi << 32) | j;
+    for (int probes = 0;; probes++) {
+        // system scope: past this XCD's L2 (a slot filled by another XCD must not keep looking empty here)
+        unsigned long long cur = __hip_atomic_load(&a.table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cur == TOK_EMPTY) {
+            cur = atomicCAS(&a.table[slot], TOK_EMPTY, me);
+            if (cur == TOK_EMPTY) return slot;
+        }
+        if ((uint32_t)(cur >> 32) == hi && ((uint32_t)cur == j || same_bytes(a.text + (uint32_t)cur, p, len))) {
+            if ((uint32_t)cur > j) atomicMin(&a.table[slot], me);
+            return slot;
+        }
+        if (probes >= TOK_MAX_PROBE) {  // table too full: the host enlarges it and runs again
+            atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
+            return 0;
+        }
+        slot = (slot + 1) & a.tmask;
+    }
+}
+
+// k_tok_hash: a wave owns a UNIT of TOK_WPW consecutive windows (4 KiB of text).  The positions of the unit's token
+// starts go into a list in the wave's LDS (prefix sums of the lanes' bit counts: the list is in text order, so token t
+// of the list is token `first token of the unit + t` of the whole input), and the lanes then take tokens from the list,
+// four per lane and round — every lane busy whatever the token lengths, the per-token stores coalesced, and four
+// independent chains {bound bits + first 16 bytes -> table word -> bytes of the entry} in flight per lane.  (A lane
+// working through the tokens of its own 16 bytes, one window after the other: half the lanes idle and one dependent load
+// at a time.)  The first probe of a token is part of the pipelined round; the few it does not settle (a slot taken by
+// another token, tokens over 16 bytes) go through tok_probe one at a time.
+__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units) {
+    constexpr int U = 4;
+    __shared__ uint16_t s_list[4][TOK_WPW * TOK_WIN];  // a token per byte at worst (rows of one byte)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t win0 = ((uint32_t)blockIdx.x * 4 + wave) * TOK_WPW;
-    uint32_t st[TOK_WPW], base[TOK_WPW];
+    const uint32_t unit = unit0 + (uint32_t)blockIdx.x * 4 + wave;
+    if (unit >= n_units) return;
+    const uint32_t win0 = unit * TOK_WPW;
+    uint16_t *list = s_list[wave];
+    uint32_t st[TOK_WPW];
 #pragma unroll
-    for (int i = 0; i < TOK_WPW; i++) {
-        const uint32_t w0 = (win0 + i) * TOK_WIN;
-        st[i] = reinterpret_cast<const uint16_t *>(a.startbits)[(w0 >> 4) + lane];
-        base[i] = a.winbase[win0 + i];
+    for (int u = 0; u < TOK_WPW; u++) st[u] = reinterpret_cast<const uint16_t *>(a.startbits)[(win0 + u) * (TOK_WIN / 16) + lane];
+    const uint32_t g0 = a.blkbase[win0 / TOK_SCAN_WINS] + a.winbase[win0];  // (a unit lies in one scan block)
+    uint32_t total = 0;
+#pragma unroll
+    for (int u = 0; u < TOK_WPW; u++) {
+        const int c = __popc(st[u]);
+        const int inc = tok_wave_incl_scan(c);
+        uint32_t o = total + (uint32_t)(inc - c);
+        for (uint32_t s = st[u]; s; s &= s - 1) list[o++] = (uint16_t)(u * TOK_WIN + 16 * lane + __builtin_ctz(s));
+        total += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t text0 = win0 * TOK_WIN;
+    for (uint32_t r0 = 0; r0 < total; r0 += 64 * U) {
+        bool act[U];
+        uint32_t j[U], wi[U], bw0[U], bw1[U];
+        unsigned long long t0[U], t1[U];
 #pragma unroll
-    for (int i = 0; i < TOK_WPW; i++) {
-        const uint32_t w0 = (win0 + i) * TOK_WIN;
-        uint32_t s = st[i];
-        const int c = __popc(s);
-        uint32_t g = base[i] + (uint32_t)(tok_wave_incl_scan(c) - c);
-        while (s) {  // the tokens that start in this lane's 16 bytes (two on average)
-            const uint32_t b = (uint32_t)__builtin_ctz(s);
-            s &= s - 1;
-            const uint32_t j = w0 + 16 * lane + b;
+        for (int u = 0; u < U; u++) {  // stage 1: four tokens of the list; bound bits + first 16 bytes requested
+            const uint32_t t = r0 + u * 64 + lane;
+            act[u] = t < total;
+            j[u] = text0 + (act[u] ? (uint32_t)list[t] : 0u);
+            wi[u] = (j[u] + 1) >> 5;
+            bw0[u] = a.boundbits[wi[u]];
+            bw1[u] = a.boundbits[wi[u] + 1];
+            t0[u] = ldu64(a.text + j[u]);
+            t1[u] = ldu64(a.text + j[u] + 8);
+        }
+        uint32_t len[U], hi[U], slot[U];
+        unsigned long long m0[U], m1[U], cur[U];
+        bool small[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // stage 2: token end -> length -> hash -> table word requested
             // end of the token: the first bound bit (separator or row start) behind j; the padding is all separators
-            uint32_t wi = (j + 1) >> 5;
-            uint32_t bw = a.boundbits[wi] & (~0u << ((j + 1) & 31u));
-            while (!bw) bw = a.boundbits[++wi];
-            const uint32_t len = wi * 32 + (uint32_t)__builtin_ctz(bw) - j;
-            uint32_t slot = ~0u;
-            if (len > TOK_MAX_LEN) {
-                atomicOr(&a.tc->fail, TOK_FAIL_LONG);
-            } else {
-                const uint8_t *p = a.text + j;
-                uint32_t h = 0x9747B28Cu ^ len;
-                uint32_t k = 0;
-                for (; k + 4 <= len; k += 4) h = mur_step(h, ldu32(p + k));
-                if (len & 3u) h = mur_step(h, ldu32(p + k) & ((1u << (8 * (len & 3u))) - 1u));
-                h = mur_final(h);
-                const uint32_t hi = (h & 0xFFFF0000u) | len;  // tag : length
-                const unsigned long long me = ((unsigned long long)hi << 32) | j;
-                slot = h & a.tmask;
-                for (int probes = 0;; probes++) {
-                    // system scope: past this XCD's L2 (a slot filled by another XCD must not keep looking empty here)
-                    unsigned long long cur = __hip_atomic_load(&a.table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (cur == TOK_EMPTY) {
-                        cur = atomicCAS(&a.table[slot], TOK_EMPTY, me);
-                        if (cur == TOK_EMPTY) break;
-                    }
-                    if ((uint32_t)(cur >> 32) == hi && ((uint32_t)cur == j || same_bytes(a.text + (uint32_t)cur, p, len))) {
-                        if ((uint32_t)cur > j) atomicMin(&a.table[slot], me);
-                        break;
-                    }
-                    if (probes >= TOK_MAX_PROBE) {  // table too full: the host doubles it and runs again
-                        atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
-                        slot = ~0u;
-                        break;
-                    }
-                    slot = (slot + 1) & a.tmask;
-                }
+            uint32_t bw = bw0[u] & (~0u << ((j[u] + 1) & 31u));
+            uint32_t w = wi[u];
+            if (!bw) {
+                bw = bw1[u];
+                w++;
+                while (!bw) bw = a.boundbits[++w];
             }
-            a.tokslot[g] = slot;
-            a.tokoff[g] = j;
-            g++;
+            len[u] = w * 32 + (uint32_t)__builtin_ctz(bw) - j[u];
+            small[u] = len[u] <= 16;
+            m0[u] = low_bytes(t0[u], len[u]);
+            m1[u] = low_bytes(t1[u], len[u] > 8 ? len[u] - 8 : 0u);
+            uint32_t h = 0x9747B28Cu ^ len[u];
+            if (small[u]) {  // the same words the loop below feeds
+                h = mur_step(h, (uint32_t)m0[u]);
+                if (len[u] > 4) h = mur_step(h, (uint32_t)(m0[u] >> 32));
+                if (len[u] > 8) h = mur_step(h, (uint32_t)m1[u]);
+                if (len[u] > 12) h = mur_step(h, (uint32_t)(m1[u] >> 32));
+            } else if (act[u] && len[u] <= TOK_MAX_LEN) {
+                const uint8_t *p = a.text + j[u];
+                uint32_t k = 0;
+                for (; k + 4 <= len[u]; k += 4) h = mur_step(h, ldu32(p + k));
+                if (len[u] & 3u) h = mur_step(h, ldu32(p + k) & ((1u << (8 * (len[u] & 3u))) - 1u));
+            }
+            h = mur_final(h);
+            hi[u] = (h & 0xFFFF0000u) | (len[u] & 0xFFFFu);  // tag : length
+            slot[u] = h & a.tmask;
+            // PLAIN load (this XCD's L2): entries only ever appear and only ever move to smaller offsets, so a stale word
+            // is an older state — an entry seen here exists (its bytes are compared below), a stale offset is larger than
+            // the true one and at worst costs an atomicMin that changes nothing; only what looks free or foreign is read
+            // again past the L2.  The tokens every row carries are settled in L2 hits that way.
+            cur[u] = a.table[act[u] ? slot[u] : 0u];
+            if (a.dbg & 2) cur[u] = ((unsigned long long)hi[u] << 32) | j[u];
+        }
+        unsigned long long q0[U], q1[U];
+        bool cmp[U], done[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // stage 3: free slot -> claim it; tag and length equal -> the entry's bytes requested
+            done[u] = !act[u];
+            if (!done[u] && !(a.dbg & 1) && (cur[u] == TOK_EMPTY || (uint32_t)(cur[u] >> 32) != hi[u]))
+                cur[u] = __hip_atomic_load(&a.table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (act[u] && len[u] > TOK_MAX_LEN) {
+                atomicOr(&a.tc->fail, TOK_FAIL_LONG);
+                slot[u] = 0;
+                done[u] = true;
+            }
+            if (!done[u] && cur[u] == TOK_EMPTY) {
+                cur[u] = atomicCAS(&a.table[slot[u]], TOK_EMPTY, ((unsigned long long)hi[u] << 32) | j[u]);
+                done[u] = cur[u] == TOK_EMPTY;
+            }
+            cmp[u] = !done[u] && small[u] && (uint32_t)(cur[u] >> 32) == hi[u] && !(a.dbg & 4);
+            if (a.dbg & 4) done[u] = true;
+            const uint8_t *q = a.text + (cmp[u] ? (uint32_t)cur[u] : j[u]);
+            q0[u] = ldu64(q);
+            q1[u] = ldu64(q + 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // stage 4: same bytes -> this is the token's slot; lower the entry to the first occurrence
+            if (cmp[u] && low_bytes(q0[u], len[u]) == m0[u] && (len[u] <= 8 || low_bytes(q1[u], len[u] - 8) == m1[u])) {
+                if ((uint32_t)cur[u] > j[u]) atomicMin(&a.table[slot[u]], ((unsigned long long)hi[u] << 32) | j[u]);
+                done[u] = true;
+            }
+            if (!done[u])  // long tokens start here, short ones whose first slot holds another token go on behind it
+                slot[u] = tok_probe(a, small[u] ? ((slot[u] + 1) & a.tmask) : slot[u], hi[u], j[u], len[u]);
+            if (act[u]) a.tokslot[g0 + r0 + u * 64 + lane] = slot[u];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_tok_rows: thread r <= n_rows: indptr[r] = token starts in front of row_off[r] (the window's prefix + the bits of the
+// window in front of the offset).  The same grid then walks the table: a slot in use sets the bit `first occurrence`
+// at the byte offset it holds.
 __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r > a.n_rows) return;
-    long long ol = a.row_off[r] - a.base;
-    ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported by k_tok_rowbits)
-    const uint32_t o = (uint32_t)ol;
-    const uint32_t w = o / TOK_WIN;
-    uint32_t cnt = a.winbase[w];
-    for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.startbits[q]);
-    cnt += (uint32_t)__popc(a.startbits[o >> 5] & ((1u << (o & 31u)) - 1u));
-    a.indptr[r] = (int)cnt;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+    for (uint32_t r = tid; r <= (uint32_t)a.n_rows; r += nth) {
+        long long ol = a.row_off[r] - a.base;
+        ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported by k_tok_rowbits)
+        const uint32_t o = (uint32_t)ol;
+        const uint32_t w = o / TOK_WIN;
+        uint32_t cnt = a.blkbase[w / TOK_SCAN_WINS] + a.winbase[w];
+        for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.startbits[q]);
+        cnt += (uint32_t)__popc(a.startbits[o >> 5] & ((1u << (o & 31u)) - 1u));
+        a.indptr[r] = (int)cnt;
+    }
+    for (uint32_t s = tid; s <= a.tmask; s += nth) {
+        const unsigned long long e = a.table[s];
+        if (e != TOK_EMPTY) atomicOr(&a.firstbits[(uint32_t)e >> 5], 1u << ((uint32_t)e & 31u));
+    }
 }
 
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tok_first(TokArgs a) {
-    __shared__ unsigned s_w[4];
-    __shared__ unsigned s_base;
-    __shared__ int s_bid;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) s_bid = (int)atomicAdd(&a.tc->ticket_first, 1u);
+// first-occurrence bits per window (32 words): 8 lanes per window, a uint4 each; a block = the 64 windows of a scan block
+__global__ __launch_bounds__(512) void k_voc_count(TokArgs a) {
+    __shared__ unsigned s_cnt[TOK_SCAN_WINS];
+    const uint32_t t = blockIdx.x * 512u + threadIdx.x;  // word quad (T_pad is a multiple of the 64 KiB a block covers)
+    const uint4 q = reinterpret_cast<const uint4 *>(a.firstbits)[t];
+    uint32_t c = (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
+    c += __shfl_xor(c, 1);
+    c += __shfl_xor(c, 2);
+    c += __shfl_xor(c, 4);
+    if ((threadIdx.x & 7u) == 0) s_cnt[threadIdx.x >> 3] = c;
     __syncthreads();
-    const int bid = s_bid;
-    const uint32_t nnz = a.tc->nnz;
-    if ((unsigned long long)bid * TOK_FIRST_PER_BLOCK >= nnz) return;  // (every block in front of a working block works too)
-    const uint32_t g0 = (uint32_t)bid * TOK_FIRST_PER_BLOCK + threadIdx.x * 8;
-    uint32_t sl[8], of[8];
-    {
-        const uint4 s0 = *reinterpret_cast<const uint4 *>(a.tokslot + g0), s1 = *reinterpret_cast<const uint4 *>(a.tokslot + g0 + 4);
-        const uint4 o0 = *reinterpret_cast<const uint4 *>(a.tokoff + g0), o1 = *reinterpret_cast<const uint4 *>(a.tokoff + g0 + 4);
-        sl[0] = s0.x; sl[1] = s0.y; sl[2] = s0.z; sl[3] = s0.w; sl[4] = s1.x; sl[5] = s1.y; sl[6] = s1.z; sl[7] = s1.w;
-        of[0] = o0.x; of[1] = o0.y; of[2] = o0.z; of[3] = o0.w; of[4] = o1.x; of[5] = o1.y; of[6] = o1.z; of[7] = o1.w;
+    if (threadIdx.x < 64) {
+        const int v = (int)s_cnt[threadIdx.x];
+        const int inc = tok_wave_incl_scan(v);
+        a.vocwin[blockIdx.x * TOK_SCAN_WINS + threadIdx.x] = (uint32_t)(inc - v);
+        if (threadIdx.x == 63) a.vocblk[blockIdx.x] = (uint32_t)inc;
     }
-    uint32_t first = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const bool ok = g0 + q < nnz && sl[q] != ~0u;
-        const unsigned long long e = a.table[ok ? sl[q] : 0u];
-        if (ok && (uint32_t)e == of[q]) first |= 1u << q;
+}
+
+// one thread per slot in use: id = first occurrences in front of its offset
+__global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+    for (uint32_t s = tid; s <= a.tmask; s += nth) {
+        const unsigned long long e = a.table[s];
+        if (e == TOK_EMPTY) continue;
+        const uint32_t o = (uint32_t)e;
+        const uint32_t w = o / TOK_WIN;
+        uint32_t cnt = a.vocblk[w / TOK_SCAN_WINS] + a.vocwin[w];
+        for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.firstbits[q]);
+        cnt += (uint32_t)__popc(a.firstbits[o >> 5] & ((1u << (o & 31u)) - 1u));
+        a.tabid[s] = (int)cnt;
     }
-    const int c = __popc(first);
-    const int inc = tok_wave_incl_scan(c);
-    if (lane == 63) s_w[wave] = (unsigned)inc;
-    __syncthreads();
-    if (wave == 0) {
-        const unsigned total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        const unsigned before = lookback_exclusive(a.chain_first, bid, total, lane, &a.tc->fail);
-        if (lane == 0) {
-            s_base = before;
-            if ((unsigned long long)(bid + 1) * TOK_FIRST_PER_BLOCK >= nnz) a.tc->n_vocab = before + total;
-        }
-    }
-    __syncthreads();
-    unsigned id = s_base + (unsigned)(inc - c);
-    for (int w = 0; w < wave; w++) id += s_w[w];
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-        if (first & (1u << q)) a.tabid[sl[q]] = (int)id++;
 }
 
 __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
@@ -329,10 +415,10 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     if (g0 >= nnz) return;
     const uint4 s = *reinterpret_cast<const uint4 *>(a.tokslot + g0);
     uint4 o;
-    o.x = (uint32_t)a.tabid[s.x != ~0u ? s.x : 0u];
-    o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y != ~0u ? s.y : 0u] : 0u;
-    o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z != ~0u ? s.z : 0u] : 0u;
-    o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w != ~0u ? s.w : 0u] : 0u;
+    o.x = (uint32_t)a.tabid[s.x];
+    o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y] : 0u;
+    o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z] : 0u;
+    o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w] : 0u;
     *reinterpret_cast<uint4 *>(a.indices + g0) = o;
 }
 
@@ -343,25 +429,38 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
-// enqueue text -> CSR.  The caller has zeroed {counters, both chains, rowbits}, filled the table with TOK_EMPTY and
-// padded the text with separators up to T_pad + TOK_TEXT_SLACK.
+// enqueue text -> CSR.  The caller has zeroed {counters, rowbits, firstbits}, filled the table with TOK_EMPTY and padded
+// the text with separators up to T_pad + TOK_TEXT_SLACK.
 int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev) {
-    const unsigned scan_blocks = a.T_pad / TOK_BLOCK_BYTES;
+    const unsigned scan_blocks = a.T_pad / (TOK_SCAN_WINS * TOK_WIN);
+    const unsigned table_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)a.tmask + 256) / 256, 8192);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (a.n_rows > 0) {
         hipLaunchKernelGGL(k_tok_rowbits, dim3((a.n_rows + 255) / 256), dim3(256), 0, st, a);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tok_scan, dim3(scan_blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tok_scan, dim3(scan_blocks), dim3(1024), 0, st, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase, scan_blocks, &a.tc->nnz);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_tok_hash, dim3(scan_blocks), dim3(256), 0, st, a);
+    // the first 4 KiB alone (one wave), then the rest: the tokens every row carries are in the table before everyone asks
+    // for them at once
+    const unsigned n_units = a.T_pad / (TOK_WPW * TOK_WIN);
+    hipLaunchKernelGGL(k_tok_hash, dim3(1), dim3(64), 0, st, a, 0u, 1u);
     LAUNCH_CHECK();
+    if (n_units > 1) {
+        hipLaunchKernelGGL(k_tok_hash, dim3((n_units - 1 + 3) / 4), dim3(256), 0, st, a, 1u, n_units);
+        LAUNCH_CHECK();
+    }
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_tok_rows, dim3((a.n_rows + 1 + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_tok_rows, dim3(std::max(table_blocks, (unsigned)std::min(8192, (a.n_rows + 256) / 256))), dim3(256), 0, st, a);
     LAUNCH_CHECK();
-    const unsigned first_blocks = (unsigned)((a.nnz_cap + TOK_FIRST_PER_BLOCK - 1) / TOK_FIRST_PER_BLOCK);
-    hipLaunchKernelGGL(k_tok_first, dim3(std::max(1u, first_blocks)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.vocblk, scan_blocks, &a.tc->n_vocab);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_voc_ids, dim3(table_blocks), dim3(256), 0, st, a);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tok_ids, dim3(std::max(1u, (unsigned)((a.nnz_cap + 1023) / 1024))), dim3(256), 0, st, a);
     LAUNCH_CHECK();

@@ -76,6 +76,7 @@ class ShardedClusterer:
             raise ValueError("merge must be 'allgather' or 'allreduce'")
         self.e, self.rank, self.world, self.merge, self.group = engine, rank, world, merge, group
         self.rounds = 0
+        self._settled = set()  # max_dist values whose first step on the bound CSR has been synced (see step)
 
     def bind(self, indptr, indices):
         self.e.bind(indptr, indices)
@@ -83,6 +84,7 @@ class ShardedClusterer:
         self.labels = self.e.new_labels(1)
         self.gathered = self.e.new_labels(self.world) if self.world > 1 else None
         self.flag = self.e.new_flag()
+        self._settled = set()
 
     def step(self, max_dist: int):
         """CSR (resident) -> global canonical labels on every rank.  Asynchronous on the GPU engine except
@@ -91,6 +93,16 @@ class ShardedClusterer:
             self.e.cluster_shard(max_dist, 0, 1, self.labels)
             return self.labels[0]
         self.e.cluster_shard(max_dist, self.rank, self.world, self.local)
+        if max_dist not in self._settled:
+            # The FIRST step on a CSR at this max_dist is synced before its labels are exchanged: a candidate generator
+            # that gives up on the input (variant join: probe chains; prefix groups: groups too big) or a candidate queue
+            # that overflows is repaired inside sync() — the shard is redone on the band kernels / in slices, `local` is
+            # rewritten — and what is merged below is the repaired shard.  The context remembers the give-up and the grown
+            # queue for this CSR, so later steps run clean and stay asynchronous.  (Merging first and repairing later
+            # would leave every rank with labels that miss this shard's edges: stats `n_retry_slices != 0` after an
+            # UNSYNCED exchange means exactly that.)
+            self.e.sync()
+            self._settled.add(max_dist)
         if self.merge == "allgather":
             dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
             self.e.merge(self.gathered, self.world, self.labels)

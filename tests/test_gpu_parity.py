@@ -820,6 +820,41 @@ def test_allreduce_min_merge_reaches_the_fix_point():
         assert np.array_equal(l, want)
 
 
+_ORACLE_LABELS = {}
+
+
+def oracle_labels_indel(n, d):
+    """labels of the CPU oracle for generate_profiles(n, indels kept) at max-dist d (16 host threads: ~15 s at 20k rows and
+    d = 3, ~25 s at d = 5), computed once per session"""
+    if (n, d) not in _ORACLE_LABELS:
+        uf = list(dict.fromkeys(generate_profiles(n, p_del=0.05, p_ins=0.01)))
+        indptr, indices, _ = _lib.build_csr(uf, " ")
+        _ORACLE_LABELS[(n, d)] = orc.cluster_csr(indptr, indices, d, n_threads=16)["labels"]
+    return _ORACLE_LABELS[(n, d)]
+
+
+@pytest.mark.parametrize("d", [3, 5])
+def test_default_configuration_equals_the_oracle_at_20k_rows(d):
+    """what a caller gets with no knob set at max-dist 3 and 5 on 20k rows with indels kept — automatic generator choice,
+    candidates of already connected rows dropped unchecked (k_verify_connected) — against the FULL oracle; and the prefix
+    groups forced (below their automatic threshold at d = 3) on the same input"""
+    uf = list(dict.fromkeys(generate_profiles(20000, p_del=0.05, p_ins=0.01)))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want = oracle_labels_indel(20000, d)
+    labels, st = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(labels, want)
+    assert st["n_retry_slices"] == 0
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("prefix")
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * len(uf))
+    ctx.cluster(d, d_out)
+    st2 = ctx.sync()
+    assert st2["path"] == 2 and np.array_equal(ctx.download_i32(d_out, len(uf)), want)
+    assert st2["n_connected"] > 0  # the pruning verify was the one that ran
+    ctx.close()
+
+
 # ---- prefix groups (max-dist >= 4 on large inputs; any max-dist 2..7 when forced) against the band kernels and the oracle ----
 @pytest.mark.exact_edges
 @pytest.mark.parametrize("n,d,indels", [(3000, 2, False), (20000, 3, True), (20000, 5, True), (60000, 4, True), (777, 7, True)])
@@ -853,6 +888,8 @@ def test_prefix_groups_equal_the_band_path(n, d, indels):
     ctx.close()
     if n <= 3000:
         assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
+    elif n <= 20000 and indels:  # the oracle for every size it can afford
+        assert np.array_equal(want, oracle_labels_indel(n, d))
 
 
 @pytest.mark.exact_edges

@@ -2,6 +2,7 @@
 reference's fixtures and the golden vectors.  Nothing here needs a GPU: max-dist 0 never reaches libbfk."""
 
 import io
+import os
 from contextlib import redirect_stdout
 from pathlib import Path
 
@@ -9,7 +10,7 @@ import click.testing
 import numpy as np
 import pandas as pd
 import pytest
-from conftest import GOLD
+from conftest import GOLD, ROOT
 
 from breakfast_amd import breakfast, console
 
@@ -157,3 +158,39 @@ def test_reference_cache_file_is_readable():
     with redirect_stdout(io.StringIO()):
         c = ca.load(GOLD / "ref_cache_testfile_d1.pkl.gz", 1)
     assert len(c["neigh"]) == 5 and list(c["meta"].columns) == ["id", "feature"]
+
+
+def _cli_process(args, cwd):
+    """the CLI as a real process (python -m breakfast_amd): exit status and stderr as a shell sees them"""
+    import subprocess
+    import sys
+
+    return subprocess.run([sys.executable, "-m", "breakfast_amd", *args], cwd=str(cwd), capture_output=True, text=True,
+                          env={**os.environ, "PYTHONPATH": str(ROOT)})
+
+
+@pytest.mark.parametrize("args,ok", [
+    (["--input-file", "testfile.tsv", "--max-dist=0"], True),            # '=' form: no preload, d = 0 path
+    (["--input-file", "testfile.tsv", "--max-dist", "0"], True),
+    (["--input-file", "duplicate-ids.tsv", "--max-dist", "0"], False),   # declined by the native reader -> the reference's ValueError
+    (["--input-file", "testfile.tsv", "--id-col", "nope", "--max-dist", "0"], False),
+    (["--input-file", "testfile.tsv", "--id-col", "nope"], False),       # preload started, the run dies in the reader
+    (["--input-file", "testfile.tsv", "--help"], True),
+])
+def test_cli_process_never_aborts(tmp_path, args, ok):
+    """every exit path joins the preload thread: the process ends with the CLI's own status — never SIGABRT (134) with
+    'terminate called without an active exception' from a still-joinable std::thread (ADVICE r02)"""
+    res = _cli_process(args + ["--outdir", str(tmp_path / "o")], FIX)
+    assert "terminate called" not in res.stderr, res.stderr[-500:]
+    assert res.returncode not in (134, -6), (res.returncode, res.stderr[-500:])
+    assert (res.returncode == 0) == ok, (res.returncode, res.stderr[-500:])
+
+
+def test_cli_process_max_dist_1_without_a_gpu_fails_loudly_not_by_abort(tmp_path):
+    """with the preload thread running (max-dist 1): on a box without a GPU the run reports BFK_ENODEV and exits non-zero;
+    on a GPU box it succeeds — either way through a normal exit"""
+    res = _cli_process(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "o")], FIX)
+    assert "terminate called" not in res.stderr and res.returncode not in (134, -6), (res.returncode, res.stderr[-500:])
+    import torch
+
+    assert (res.returncode == 0) == torch.cuda.is_available(), res.stderr[-500:]
