@@ -2084,12 +2084,16 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
         return;
     }
     __shared__ int s_set[WAVES][SCAP];
-    __shared__ int4 s_q[WAVES][64];  // fresh pairs {A, B, k_A, k_B} waiting for their queue slots (20 KiB of LDS in all: 8 blocks per CU)
+    __shared__ int4 s_q[WAVES][64];  // fresh pairs {A, B, k_A, k_B} waiting for their queue slots
+    __shared__ int2 s_pend[WAVES][128];  // members {row, length} that passed the second level, waiting to be settled
+    __shared__ unsigned char s_pstep[WAVES][128];  // ... and the step of the group they were met in (25 KiB of LDS in all)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     int *set = s_set[wave];
     int4 *sq = s_q[wave];
+    int2 *pend = s_pend[wave];
+    unsigned char *pstep = s_pstep[wave];
     for (int i = lane; i < SCAP; i += 64) set[i] = -1;
     __syncthreads();
     int cshard = (blockIdx.x * WAVES + wave) & (CAND_SHARDS - 1);
@@ -2193,6 +2197,74 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
         };
         int n_in = 0;         // entries of the set (wave-uniform)
         bool full = false;    // the set stopped taking entries
+        int np = 0;           // members that passed the second level and wait in `pend` (wave-uniform, < 64 between chunks)
+        // The chunk loop only TESTS (length, signature) and parks what passes — ~7% of the members — in the wave's LDS; the
+        // set, the slow test and the queue see them 64 at a time, one per lane (`settle`).  Doing that inside the loop meant
+        // ~100 wave-instructions per chunk for the 4 lanes of 64 that had something to do: the walk is bound by its
+        // instruction stream, not by its loads (1.44 -> see DESIGN 6d for the measured step).
+        auto settle = [&](int cnt) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool have = lane < cnt;
+            const int2 pe = have ? pend[lane] : make_int2(0, 0);
+            const int B = pe.x, len_b = pe.y;
+            const int step = have ? (int)pstep[lane] : 0;
+            // seen in another group of A?
+            bool fresh = false, unknown = false;
+            if (pa.dbg & 256) {  // (BFK_PF_DEBUG=256: no set, every member that passes is queued; timing experiments)
+                fresh = have;
+            } else if (have) {
+                // (the set by plain LDS reads and writes of {row : lane} slots — read, write if empty, read back: in order per
+                // wave, the last writer stays — instead of the compare-and-swap: 2.81 ms against 2.33 for this kernel at 1M
+                // rows, max_dist 5, 1.30 against 0.53 at 100k rows: three dependent LDS round trips per probe instead of one)
+                uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 22;  // SCAP = 1024 slots
+                for (;;) {
+                    const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
+                    if (old == B) break;                     // seen: a duplicate
+                    if (old == -1) {
+                        // (just inserted; or the set takes no more entries: a labels-only step lets the pair through — the
+                        // verify drops a second copy as connected — the others decide it the slow way)
+                        fresh = !full || pa.skip_connected;
+                        unknown = full && !pa.skip_connected;
+                        break;
+                    }
+                    h = (h + 1) & (SCAP - 1);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(unknown) != 0ull) {
+                // the slow exact test: one of A's earlier elements among B's records
+                bool dup = false;
+                if (unknown) {
+                    const uint32_t *kb = keys + (size_t)B * recs;
+                    uint32_t gb[PG_MAX_DIST + 2];
+#pragma unroll
+                    for (int j = 0; j < PG_MAX_DIST + 2; j++) gb[j] = j < recs ? kb[j] : PG_NONE;
+                    for (int e2 = 0; e2 < step; e2++) {
+                        const uint32_t y = keys[(size_t)A_now * recs + (e2 == 0 ? recs - 1 : e2 - 1)];
+                        if (y == PG_NONE) continue;
+#pragma unroll
+                        for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || gb[j] == y;
+                    }
+                }
+                fresh = fresh || (unknown && !dup);
+            }
+            n_in += __popcll(__builtin_amdgcn_ballot_w64(fresh && !full));
+            // (wave-uniform; entries made so far stay valid.)  Half full, not three quarters: the rows that get there are the
+            // hubs — an early profile with hundreds of descendants within max_dist — and at 75% load the linear probe
+            // chains of those rows were most of this kernel: 2.27 -> 1.44 ms at 1M rows, max_dist 5, 0.49 -> 0.23 at 100k
+            // (a set of 2048 slots at 3/4: 1.92 / 0.24 — the LDS it takes costs more waves than the shorter chains give)
+            if (n_in > SCAP / 2) full = true;
+            // the fresh pairs wait in LDS for their queue slots
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
+            if (fm != 0ull) {
+                const int nf = __popcll(fm);
+                if (nq + nf > 64) flush();
+                if (fresh) sq[nq + below(fm)] = make_int4(A_now, B, len_a, len_b);
+                nq += nf;
+                if (pa.dbg & 128) nq = 0;  // (BFK_PF_DEBUG=128: nothing is queued; timing experiments, results invalid)
+            }
+        };
         const int nch = (T + 63) >> 6;
         int st0 = 0, st1 = 0, st2 = 0;
         int4 rec0 = make_int4(0, 0, 0, 0), rec1 = rec0;
@@ -2210,65 +2282,34 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
             }
             {
                 const int4 rec = rec0;
-                const int step = st0;
                 const bool inb = c * 64 + lane < T;
                 visits += (unsigned long long)min(64, T - c * 64);
-                const int B = rec.x, len_b = rec.y;
-                bool pass = inb && abs(len_b - len_a) <= d && __popc((uint32_t)rec.z ^ sa0) + __popc((uint32_t)rec.w ^ sa1) <= d;
+                bool pass = inb && abs(rec.y - len_a) <= d && __popc((uint32_t)rec.z ^ sa0) + __popc((uint32_t)rec.w ^ sa1) <= d;
                 if (pa.dbg & 64) pass = false;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
-                // seen in another group of A?
-                bool fresh = false, unknown = false;
-                if (pa.dbg & 256) {  // (BFK_PF_DEBUG=256: no set, every member that passes is queued; timing experiments)
-                    fresh = pass;
-                } else if (pass) {
-                    // (the set by plain LDS reads and writes of {row : lane} slots — read, write if empty, read back: in order per
-                    // wave, the last writer stays — instead of the compare-and-swap: 2.81 ms against 2.33 for this kernel at 1M
-                    // rows, max_dist 5, 1.30 against 0.53 at 100k rows: three dependent LDS round trips per probe instead of one)
-                    uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 22;  // SCAP = 1024 slots
-                    for (;;) {
-                        const int old = full ? set[h] : atomicCAS(&set[h], -1, B);
-                        if (old == B) break;                     // seen: a duplicate
-                        if (old == -1) {
-                            // (just inserted; or the set takes no more entries: a labels-only step lets the pair through — the
-                            // verify drops a second copy as connected — the others decide it the slow way)
-                            fresh = !full || pa.skip_connected;
-                            unknown = full && !pa.skip_connected;
-                            break;
-                        }
-                        h = (h + 1) & (SCAP - 1);
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass);
+                if (pm != 0ull) {
+                    if (pass) {
+                        const int i = np + below(pm);
+                        pend[i] = make_int2(rec.x, rec.y);
+                        pstep[i] = (unsigned char)st0;
                     }
-                }
-                if (__builtin_amdgcn_ballot_w64(unknown) != 0ull) {
-                    // the slow exact test: one of A's earlier elements among B's records
-                    bool dup = false;
-                    if (unknown) {
-                        const uint32_t *kb = keys + (size_t)B * recs;
-                        uint32_t gb[PG_MAX_DIST + 2];
-#pragma unroll
-                        for (int j = 0; j < PG_MAX_DIST + 2; j++) gb[j] = j < recs ? kb[j] : PG_NONE;
-                        for (int e2 = 0; e2 < step; e2++) {
-                            const uint32_t y = keys[(size_t)A_now * recs + (e2 == 0 ? recs - 1 : e2 - 1)];
-                            if (y == PG_NONE) continue;
-#pragma unroll
-                            for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || gb[j] == y;
+                    np += __popcll(pm);
+                    if (np >= 64) {
+                        settle(64);
+                        // what is left moves to the front
+                        const int left = np - 64;
+                        __builtin_amdgcn_wave_barrier();
+                        const int2 mv = lane < left ? pend[64 + lane] : make_int2(0, 0);
+                        const unsigned char ms = lane < left ? pstep[64 + lane] : (unsigned char)0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < left) {
+                            pend[lane] = mv;
+                            pstep[lane] = ms;
                         }
+                        np = left;
                     }
-                    fresh = fresh || (unknown && !dup);
-                }
-                n_in += __popcll(__builtin_amdgcn_ballot_w64(fresh && !full));
-                // (wave-uniform; entries made so far stay valid.)  Half full, not three quarters: the rows that get there are the
-                // hubs — an early profile with hundreds of descendants within max_dist — and at 75% load the linear probe
-                // chains of those rows were most of this kernel: 2.27 -> 1.44 ms at 1M rows, max_dist 5, 0.49 -> 0.23 at 100k
-                // (a set of 2048 slots at 3/4: 1.92 / 0.24 — the LDS it takes costs more waves than the shorter chains give)
-                if (n_in > SCAP / 2) full = true;
-                // the fresh pairs wait in LDS for their queue slots
-                const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
-                if (fm != 0ull) {
-                    const int nf = __popcll(fm);
-                    if (nq + nf > 64) flush();
-                    if (fresh) sq[nq + below(fm)] = make_int4(A_now, B, len_a, len_b);
-                    nq += nf;
-                    if (pa.dbg & 128) nq = 0;  // (BFK_PF_DEBUG=128: nothing is queued; timing experiments, results invalid)
                 }
             }
             rec0 = rec1;
@@ -2276,6 +2317,7 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
             rec1 = rec2;
             st1 = st2;
         }
+        if (np > 0) settle(np);  // (the set is this row's: nothing waits across rows)
         // clean the set for the next row
         if (n_in > 0 || full)
             for (int i = lane; i < SCAP; i += 64) set[i] = -1;
