@@ -30,7 +30,7 @@ class Stats(C.Structure):
         ("pairs_filtered", C.c_int64), ("n_candidates", C.c_int64), ("n_edges", C.c_int64), ("n_retry_slices", C.c_int64),
         ("max_row_len", C.c_int32), ("sig_words", C.c_int32), ("n_work_items", C.c_int32), ("profiled", C.c_int32),
         ("ms_prep", C.c_float), ("ms_prefilter", C.c_float), ("ms_verify", C.c_float), ("ms_flatten", C.c_float),
-        ("ms_total", C.c_float), ("path", C.c_int32), ("reserved_", C.c_int32), ("n_connected", C.c_int64),
+        ("ms_total", C.c_float), ("path", C.c_int32), ("n_gpus_used", C.c_int32), ("n_connected", C.c_int64),
     ]
 
     def as_dict(self):
@@ -71,7 +71,7 @@ EXPORTS = {
     "bfk_build_csr_device": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i32p, C.POINTER(c_i32p),
                                        c_i64p, c_i32p]),
     "bfk_cluster_text": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, C.c_int32, c_i32p, C.POINTER(Stats),
-                                   c_i64p, c_i32p]),
+                                   c_i64p, c_i32p, c_i32p]),
     "bfk_ctx_build_csr": (C.c_int, [C.c_void_p, C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i64p, c_i32p]),
     "bfk_ctx_download_csr": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
     "bfk_ctx_text_stats": (C.c_int, [C.c_void_p, C.POINTER(TextStats)]),
@@ -214,9 +214,10 @@ def build_csr_device(features, sep: str):
     return build_csr_bytes(buf, off, sep, device=True)
 
 
-def cluster_text(buf: bytes, row_off, sep: str, max_dist: int, want_stats: bool = True):
+def cluster_text(buf: bytes, row_off, sep: str, max_dist: int, want_stats: bool = True, indptr_out=None):
     """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device.
-    want_stats=False passes stats_out = NULL (the counters that need host-side sums are then not gathered)."""
+    want_stats=False passes stats_out = NULL (the counters that need host-side sums are then not gathered);
+    indptr_out: optional int32[N+1] array that receives the CSR's row pointer."""
     lib = load()
     off = np.ascontiguousarray(row_off, dtype=np.int64)
     n = len(off) - 1
@@ -225,7 +226,8 @@ def cluster_text(buf: bytes, row_off, sep: str, max_dist: int, want_stats: bool 
     st = Stats()
     nnz, nv = C.c_int64(), C.c_int32()
     rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels),
-                              C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv))
+                              C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv),
+                              None if indptr_out is None else _p32(indptr_out))
     if rc == -1 and len(sepb) == 0:
         raise ValueError("empty separator")
     _check(rc)

@@ -6,9 +6,11 @@ strings and the component labels runs in libbfk.so (HIP, gfx950) through breakfa
   read_input              breakfast.py:16-29     pandas reader + duplicate-id ValueError
   filter_features         breakfast.py:116-190   per-token classification, memoised per distinct token
   collapse_duplicates     breakfast.py:72-79
-  sparse_feature_matrix   breakfast.py:193-215   -> bfk_build_csr
+  sparse_feature_matrix   breakfast.py:193-215   -> bfk_build_csr_device (HIP tokeniser; bfk_build_csr, the host tokeniser of
+                                                    the same contract, for what it declines and for GPU-less callers)
   get_neighbours_batch    breakfast.py:223-276   -> bfk_neighbours_csr (+ the band selection)
-  cluster_features        breakfast.py:279-340   -> bfk_cluster_csr
+  cluster_features        breakfast.py:279-340   -> bfk_cluster_text (text -> labels in one call; with a cache or several GPUs:
+                                                    the CSR from above + bfk_cluster_csr / the cache path)
   cluster_identical_features breakfast.py:343-364
   cluster                 breakfast.py:82-89
   write_output            breakfast.py:32-69
@@ -120,7 +122,16 @@ def cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_c
 
 
 def _feature_csr(features, feature_sep):
-    return _lib.build_csr(list(features), feature_sep)
+    """sparse_feature_matrix's CSR (breakfast.py:193-215): tokenised on the GPU (bfk_build_csr_device) when there is one; the
+    host tokeniser of the same library (bfk_build_csr — same contract, same CSR) takes what the device path declines
+    (multi-byte separators, 4 GiB of text) and the GPU-less callers of this function (the shell tests, the cache tools)."""
+    features = list(features)
+    if _lib.load().bfk_device_count() > 0 and len(feature_sep.encode()) == 1:
+        try:
+            return _lib.build_csr_device(features, feature_sep)
+        except _lib.Unsupported:
+            pass
+    return _lib.build_csr(features, feature_sep)
 
 
 def sparse_feature_matrix(features, feature_sep):
@@ -174,6 +185,19 @@ def _assign_cluster_ids(meta, labels, min_cluster_size):
 
 
 def cluster_features(meta, feature_sep, max_dist, min_cluster_size, input_cache, output_cache, n_gpus=1):
+    if input_cache is None and not output_cache and n_gpus == 1 and len(feature_sep) > 0:
+        # no cache, one GPU: text -> labels in ONE call (bfk_cluster_text): the CSR is built on the device and stays there
+        buf, off = _lib.pack_rows(list(meta["feature"]))
+        indptr = np.zeros(len(off), dtype=np.int32)
+        labels, _, nnz, _ = _lib.cluster_text(buf, off, feature_sep, max_dist, want_stats=False, indptr_out=indptr)
+        if nnz == 0:
+            raise ValueError("unable to infer matrix dimensions")  # (the reference dies here, :214)
+        meta["n_features"] = np.diff(indptr).astype(np.int64)
+        print("Imported cached results are not available. "
+              "Distance matrix of complete dataset will be calculated.")
+        print("Create graph and recover connected components")
+        print("Save clusters")
+        return _assign_cluster_ids(meta, labels, min_cluster_size)
     indptr, indices, _ = _feature_csr(meta["feature"], feature_sep)
     if len(indices) == 0:
         # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)

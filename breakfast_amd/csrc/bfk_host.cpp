@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace bfk;
@@ -1065,6 +1066,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         s.sig_words = c->last_w1;
         s.n_work_items = (int32_t)h.n_work;
         s.path = c->plan.join ? 1 : (c->plan.pg ? 2 : 0);
+        s.n_gpus_used = 1;
         c->last_tiles = (int64_t)h.n_work;
         if (c->profiling && c->n_prof_calls > 0) {
             const int used = std::min(c->n_prof_calls, (int)bfk_ctx::EV_SLOTS);
@@ -1223,13 +1225,27 @@ static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t 
         if (int rc = bfk_ctx_create(one ? 0 : (int)g_multi.size(), &c)) return rc;
         g_multi.push_back(c);
     }
-    for (int g = 0; g < n_gpus; g++) {
-        bfk_ctx *c = g_multi[(size_t)g];
-        if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
-        if (int rc = ctx_own_labels(c, n_rows)) return rc;
+    // one host thread per device: the CSR goes up to all devices at once (every device has its own PCIe link; one after the
+    // other, each upload with its syncs, was n_gpus x 3 ms at 1M rows before the first kernel ran) and each device's shard is
+    // enqueued as soon as ITS copy has landed
+    {
+        std::vector<int> rcs((size_t)n_gpus, BFK_OK);
+        std::vector<std::string> msgs((size_t)n_gpus);
+        auto work = [&](int g) {
+            bfk_ctx *c = g_multi[(size_t)g];
+            int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows);
+            if (!rc) rc = ctx_own_labels(c, n_rows);
+            if (!rc) rc = bfk_ctx_cluster(c, max_dist, g, n_gpus, c->own_labels);
+            rcs[(size_t)g] = rc;
+            if (rc) msgs[(size_t)g] = bfk_last_error();  // (thread-local: carried over to the caller's thread below)
+        };
+        std::vector<std::thread> th;
+        for (int g = 1; g < n_gpus; g++) th.emplace_back(work, g);
+        work(0);
+        for (auto &t : th) t.join();
+        for (int g = 0; g < n_gpus; g++)
+            if (rcs[(size_t)g]) return fail(rcs[(size_t)g], "device " + std::to_string(g) + ": " + msgs[(size_t)g]);
     }
-    for (int g = 0; g < n_gpus; g++)  // asynchronous: the devices work side by side
-        if (int rc = bfk_ctx_cluster(g_multi[(size_t)g], max_dist, g, n_gpus, g_multi[(size_t)g]->own_labels)) return rc;
     bfk_stats total{};
     for (int g = 0; g < n_gpus; g++) {
         bfk_stats st{};
@@ -1243,6 +1259,7 @@ static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t 
         }
     }
     total.pairs_resolved = n_rows * (n_rows - 1) / 2;
+    total.n_gpus_used = n_gpus;
     bfk_ctx *c0 = g_multi[0];
     if (int rc = ctx_enter(c0)) return rc;
     if (n_rows > 0) {
@@ -1258,12 +1275,35 @@ static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t 
     return BFK_OK;
 }
 
+// Is a one-shot call worth several devices?  Every device needs the whole CSR (an upload each, in parallel), the shards'
+// labels have to meet on one device (peer copies) and be merged there: (n_gpus - 1) * N pseudo-edges into one forest — 0.11 ms
+// at 1M rows and max-dist 1, 0.2 ms at max-dist 2, but ~1 ms from max-dist 3 on (dense graphs: every rank's forest is one big
+// tree with a root of its own).  What the extra devices take off is the SHARDED part of the step (pair kernel + verify; the
+// prep is replicated).  One-device rehearsal of the split, each shard alone on the GPU (profiles/r03_rehearsal_shard_tables.json,
+// 1M rows, kernels of the slowest shard at 1 / 8 ranks): max-dist 1: 0.48 / 0.25 ms (+ 0.11 merge: break-even), max-dist 2:
+// 1.47 / 0.49 (+ 0.22: a 2x win), max-dist 3 on the band kernels: 4.4 / 1.5 (+ 0.9: slower than one device on the prefix
+// groups, 1.9), prefix groups: the verify of a shard gets SLOWER the fewer edges its forest sees.  So: several devices at
+// max-dist 2 from 300k rows and at max-dist 1 from 2M; everything else runs on one device whatever n_gpus says
+// (bfk_stats.n_gpus_used tells).  BFK_MULTI_FORCE=1 (and the one-device rehearsal mode of the tests) shards regardless.
+static bool multi_worth(int64_t n_rows, int32_t max_dist) {
+    if (getenv("BFK_MULTI_FORCE") && atoi(getenv("BFK_MULTI_FORCE")) != 0) return true;
+    if (getenv("BFK_MULTI_ONE_DEVICE") && atoi(getenv("BFK_MULTI_ONE_DEVICE")) != 0) return true;
+    if (max_dist <= 1) return n_rows >= 2000000;
+    if (max_dist == 2) return n_rows >= 300000;
+    return false;
+}
+
 extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
                                int32_t n_gpus, int32_t *labels_out, bfk_stats *stats_out) {
     if (n_rows < 0 || !indptr || (n_rows > 0 && !labels_out)) return fail(BFK_EARG, "bad arguments");
     if (n_gpus < 1 || n_gpus > 64) return fail(BFK_EARG, "n_gpus must be 1..64");
     std::lock_guard<std::mutex> lk(g_mu);
-    if (n_gpus > 1) return cluster_multi(indptr, indices, n_rows, max_dist, n_gpus, labels_out, stats_out);
+    if (n_gpus > 1) {
+        const bool one = getenv("BFK_MULTI_ONE_DEVICE") && atoi(getenv("BFK_MULTI_ONE_DEVICE")) != 0;
+        const int ndev = bfk_device_count();
+        if (!one && n_gpus > ndev) return fail(BFK_ENODEV, "bfk_cluster_csr: n_gpus = " + std::to_string(n_gpus) + " but " + std::to_string(ndev) + " gfx950 device(s) visible");
+        if (multi_worth(n_rows, max_dist)) return cluster_multi(indptr, indices, n_rows, max_dist, n_gpus, labels_out, stats_out);
+    }
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
@@ -1302,7 +1342,8 @@ extern "C" int bfk_build_csr_device(const char *buf, const int64_t *row_off, int
 // a1 .. a8 in one call: profile text in host memory -> canonical labels in host memory.  The text goes to the device once
 // (56 GB/s from the caller's buffer), the CSR is built there (bfk_text.hip) and never visits the host.
 extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
-                                int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out) {
+                                int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out,
+                                int32_t *indptr_out) {
     if (!row_off || n_rows < 0 || (n_rows > 0 && !labels_out)) return fail(BFK_EARG, "bfk_cluster_text: bad arguments");
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
@@ -1324,6 +1365,9 @@ extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t
     if (rc) return rc;
     if (int r2 = ctx_own_labels(c, n_rows)) return r2;
     rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
+    if (!rc && indptr_out)  // the row lengths (n_features of the reference's frame, :287) ride along with the kernels
+        if (hipMemcpyAsync(indptr_out, c->d_indptr, (size_t)(n_rows + 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = fail(BFK_EHIP, "bfk_cluster_text: indptr copy failed");
     if (!rc) rc = bfk_ctx_sync(c, stats_out);
     if (!rc) rc = bfk_ctx_download(c, c->own_labels, labels_out, n_rows * 4);
     return rc;

@@ -212,6 +212,7 @@ struct CellArgs {
     unsigned long long *chain;  // one status word per block of k_cells (zeroed again by k_place)
     Counters *ctr;
     int n, cells, tr_shift, tile_cap;
+    int shard0, nshards;  // multi-GPU: only the tiles of this rank's cells are listed (owner of a cell = hash of its key mod ranks)
 };
 
 // inclusive prefix sum over the 64 lanes (DPP row prefix, then row broadcasts)
@@ -274,7 +275,12 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         rows += part[q];
     }
     const int trm = (1 << a.tr_shift) - 1;
-    const int tl = (rows + trm) >> a.tr_shift;
+    // Multi-GPU: a CELL belongs to one rank, never a tile (the order of the rows inside a cell comes from atomics and differs
+    // from rank to rank; whole cells and whole column cells are the same sets everywhere), and a rank lists ONLY its own
+    // cells' tiles: the pair kernel's grid is its share of the work.  (Listing every tile and letting the pair kernel skip
+    // the foreign ones left 0.146 of 0.231 ms on every rank of an 8-way split at 1M rows: 7/8 of the blocks only to exit.)
+    const bool owned = a.nshards <= 1 || (int)((((uint32_t)c * 0x9E3779B1u) >> 12) % (uint32_t)a.nshards) == a.shard0;
+    const int tl = owned ? (rows + trm) >> a.tr_shift : 0;
     const int inc_r = wave_incl_scan_add(rows), inc_t = wave_incl_scan_add(tl);
     if (lane == 63) {
         s_wr[wave] = inc_r;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_cells(CellArgs a) {
         }
         const int tr = 1 << a.tr_shift;
         const int t_first = t;  // every tile carries the index of its cell's first tile: the multi-GPU owner key
-        for (int r0 = 0; r0 < rows; r0 += tr, t++)
+        for (int r0 = 0; owned && r0 < rows; r0 += tr, t++)
             if (t < a.tile_cap) a.tiles[t] = make_int4(pos + r0, min(tr, rows - r0), c, t_first);
     }
     if (bid + 1 == (int)gridDim.x) PLAN_STAMP(1)
@@ -704,9 +710,6 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     uint32_t *myrow = srow[wave];
     // Work items = (tile, wave slot) pairs of this shard, taken by WAVES, grid-stride: the host launches one
     // block per expected tile (the count lives on the device; any grid is correct).
-    // Multi-GPU: a CELL belongs to one rank (owner = index of the cell's first tile mod ranks), never a tile.
-    // The order of the rows inside a cell comes from atomics and differs from rank to rank, so which rows sit in
-    // "tile 3 of the cell" differs too; whole cells and whole column cells are the same sets on every rank.
     const int n_items = max(n_tiles - t_begin, 0) * PW;
     int item = (int)blockIdx.x * PW + wave;
     while (item < n_items) {
@@ -716,12 +719,7 @@ __global__ __launch_bounds__(PW * 64) void k_prefilter(const uint32_t *__restric
     unsigned long long t_rng = 0, t_main = 0;
     int dbg_hits = 0, dbg_chunks = 0;
     int qn = 0;  // fill level of this wave's hit queue (wave-uniform)
-    const int4 tile = ba.tiles[t];
-    if (nshards > 1 && (tile.w % nshards) != shard0) {  // another rank's cell
-        if (lane == 0) ba.tile_slots[t * PW + wslot] = 0;
-        item += (int)gridDim.x * PW;
-        continue;
-    }
+    const int4 tile = ba.tiles[t];  // (multi-GPU: k_cells listed this rank's cells only)
     const int row0 = tile.x, nrows = tile.y;
     const int fb = ba.key.fb, gb = ba.key.gb, hb = ba.key.hb;
     // fb, gb, hb are powers of two
@@ -2365,6 +2363,7 @@ __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict
 __global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, int n_parts, Counters *ctr, int skip, int splice) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    int last = i;  // (a part that says what the part before said adds nothing: in a dense graph most parts name one root)
     for (int g = 0; g < n_parts; g++) {
         if (g == skip) continue;
         int l = gathered[(size_t)g * n + i];
@@ -2372,6 +2371,8 @@ __global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, in
             atomicOr(&ctr->err, ERR_LABEL);
             continue;
         }
+        if (l == last) continue;
+        last = l;
         if (l == i) continue;
         if (splice) uf_link(parent, i, l); else uf_union(parent, i, l);
     }
@@ -2666,6 +2667,8 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
     ca.cells = (pl.kcap + 1) * pl.fb * pl.gb * pl.hb;
     ca.tr_shift = 6 + (pl.rows_per_lane == 1 ? 0 : (pl.rows_per_lane == 2 ? 1 : 2));
     ca.start3c = pl.start3c;
+    ca.shard0 = pl.shard;
+    ca.nshards = pl.n_shards;
     const int cell_blocks = (ca.cells + 1023) / 1024;
     const int copies = pl.hist_copies;
     ca.tile_cap = pl.tile_cap;

@@ -63,7 +63,7 @@ typedef struct bfk_stats {
     float ms_flatten;        /* label flatten */
     float ms_total;          /* first launch to last launch completion */
     int32_t path;            /* candidate generator of the step: 0 band kernels, 1 variant join, 2 prefix groups (pairs_filtered = group members visited) */
-    int32_t reserved_;
+    int32_t n_gpus_used;     /* devices the call ran on: bfk_cluster_csr(n_gpus > 1) declines inputs whose step is too short to win (1) */
     int64_t n_connected;     /* candidates dropped unchecked because their rows were in one component already (labels-only
                               * steps at max_dist >= 3; 0 with bfk_ctx_set_exact_edges(ctx, 1), BFK_EXACT_EDGES=1 or edge capture) */
 } bfk_stats;
@@ -98,17 +98,20 @@ int bfk_build_csr_device(const char *buf, const int64_t *row_off, int64_t n_rows
 /* ---- a1..a8 one-shot: profile text in host memory -> labels in host memory -------------------------------------------
  * sparse_feature_matrix (:193-215) + the body of cluster_features (:287-326) in one call: the text is copied to the device
  * once, tokenised there (bfk_build_csr_device's kernels; the host tokeniser + an upload when they decline the input),
- * the CSR stays in HBM and is clustered like bfk_cluster_csr.  nnz_out / n_vocab_out / stats_out may be NULL.            */
+ * the CSR stays in HBM and is clustered like bfk_cluster_csr.  nnz_out / n_vocab_out / stats_out may be NULL; indptr_out
+ * (int32[n_rows + 1], may be NULL) receives the CSR's row pointer — np.diff of it is the frame's n_features (:287).       */
 int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
-                     int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out);
+                     int32_t max_dist, int32_t *labels_out, bfk_stats *stats_out, int64_t *nnz_out, int32_t *n_vocab_out,
+                     int32_t *indptr_out);
 
 /* ---- a2..a8 one-shot, host buffers ------------------------------------------------------------
  * Replaces the body of cluster_features between the CSR and the components:
  *   n_features / band loop (:287-319) -> get_neighbours_batch (:223-276) -> sklearn _sparse_manhattan
  *   -> _reduce_func (:226-228) -> _to_graph (:93-113) -> networkx connected_components (:325-326).
  * indices may be unsorted and may contain repeats (multiset rows).  labels_out: int32[n_rows].
- * n_gpus > 1: one context per device in THIS process, the work sharded over the devices (CSR replicated), label arrays
- * copied to the first device (peer copies over xGMI) and merged there; the one-process-per-GPU form with RCCL collectives
+ * n_gpus > 1: one context per device in THIS process, the work sharded over the devices (CSR replicated: uploaded to all
+ * devices at once, a host thread each), label arrays copied to the first device (peer copies over xGMI) and merged there;
+ * inputs whose single-GPU step is shorter than what the exchange costs run on one device (bfk_stats.n_gpus_used); the one-process-per-GPU form with RCCL collectives
  * goes through the ctx API below (breakfast_amd/distributed.py).  Same labels either way.
  * stats_out may be NULL.                                                                            */
 int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist, int32_t n_gpus,

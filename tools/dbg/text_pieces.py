@@ -1,6 +1,6 @@
 """where does bfk_cluster_text spend its time on the host side (pieces through the ctx API)"""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from breakfast_amd import _lib
 from breakfast_amd.synth import generate_profiles
