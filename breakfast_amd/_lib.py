@@ -41,10 +41,10 @@ class TextStats(C.Structure):
     _fields_ = [("text_bytes", C.c_int64), ("n_rows", C.c_int64), ("nnz", C.c_int64), ("table_slots", C.c_int64),
                 ("n_vocab", C.c_int32), ("table_growths", C.c_int32), ("host_fallback", C.c_int32), ("reserved_", C.c_int32),
                 ("ms_h2d", C.c_float), ("ms_scan", C.c_float), ("ms_hash", C.c_float), ("ms_ids", C.c_float),
-                ("ms_total", C.c_float)]
+                ("ms_total", C.c_float), ("ms_head", C.c_float), ("reserved2_", C.c_float)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved_"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class FilterOpts(C.Structure):

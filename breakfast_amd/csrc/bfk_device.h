@@ -116,6 +116,7 @@ constexpr int TOK_SCAN_WINS = 64;                      // windows per block of k
 constexpr int TOK_PAD_BYTES = TOK_SCAN_WINS * TOK_WIN; // the text is padded to a multiple of this
 constexpr int TOK_TEXT_SLACK = 64;                     // separator bytes behind T_pad (unaligned 8-byte reads of a token's tail)
 constexpr uint32_t TOK_MAX_LEN = 65534;                // longest token the table word can describe (16-bit length)
+constexpr unsigned TOK_HOLD_UNITS = 17;                // hash units (4 KiB) at the end of a text piece that wait for the next piece: > TOK_MAX_LEN + 64 bytes
 constexpr int TOK_MAX_PROBE = 512;                     // probe chain at which the table counts as too full
 constexpr unsigned long long TOK_EMPTY = ~0ull;        // free slot of the vocabulary table {tag16 : len16 : offset32}
 enum : int { TOK_FAIL_ROWOFF = 1, TOK_FAIL_LONG = 2, TOK_FAIL_TABLE = 4 };
@@ -147,7 +148,8 @@ struct TokArgs {
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
     int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 2 no table loads, 4 no byte compares
 };
-int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev);  // bfk_text.hip
+int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_pieces, const unsigned *piece_blk,
+                    hipEvent_t *piece_ev);  // bfk_text.hip
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st);  // bfk_sort.hip

@@ -125,8 +125,12 @@ struct bfk_ctx {
     int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_table_cap = 0,
             tk_tabid_cap = 0;
     int tk_grow = 0;  // how often the table was enlarged 8x for this context's inputs (kept: the next input is likely alike)
-    hipEvent_t tk_ev[6] = {};
+    hipEvent_t tk_ev[7] = {};
     bool tk_ev_ready = false;
+    // the text goes up in pieces on a copy stream of its own while the pieces already there are tokenised (ctx_build_text)
+    static constexpr int TK_PIECES = 8;
+    hipStream_t tk_copy_stream = nullptr;
+    hipEvent_t tk_piece_ev[TK_PIECES] = {}, tk_start_ev = nullptr;
     bfk_text_stats tk_stats{};
     bool tok_pending = false;  // the tokeniser's counters (d_small[8..15]) are to come back with the next bind's copy
     int tok_host[8] = {0};
@@ -204,6 +208,10 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
             if (e) (void)hipEventDestroy(e);
     for (auto &e : c->tk_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->tk_piece_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->tk_start_ev) (void)hipEventDestroy(c->tk_start_ev);
+    if (c->tk_copy_stream) (void)hipStreamDestroy(c->tk_copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return BFK_OK;
@@ -441,12 +449,48 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         c->tk_ev_ready = true;
     }
     hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
-    // the text and the row offsets: the caller's (pageable) buffers, borrowed until the copies are done
+    // The text and the row offsets: the caller's (pageable) buffers, borrowed until the copies are done.  ONE copy of the
+    // whole text, then the kernels.  BFK_TOK_PIECES=n (2..8, texts from 8 MB) sends the text in n pieces on a copy stream of
+    // its own and tokenises piece k under the copy of piece k + 1 — measured and left off: every copy from pageable memory
+    // costs ~60 us of driver work before it moves a byte, which is more than the ~30 us of kernels a piece hides
+    // (bfk_cluster_text, 100k rows / 31 MB: 1.10 ms in one piece, 1.20-1.28 in two, 1.24 in four, 1.43 in eight; 1M rows /
+    // 333 MB: 7.8 against 8.0-8.4).  (With profiling on everything runs on the one stream, the phases one after the other.)
+    int n_pieces = 1;
+    unsigned piece_blk[bfk_ctx::TK_PIECES + 1] = {0};
+    const int64_t scan_blocks = T_pad / TOK_PAD_BYTES;
+    if (!c->profiling && T >= ((int64_t)8 << 20) && getenv("BFK_TOK_PIECES") && atoi(getenv("BFK_TOK_PIECES")) >= 2) {
+        n_pieces = std::min((int)bfk_ctx::TK_PIECES, atoi(getenv("BFK_TOK_PIECES")));
+        for (int k = 0; k <= n_pieces; k++)  // boundaries at multiples of 4 scan blocks (256 KiB: 16-byte pieces of blkbase)
+            piece_blk[k] = k == n_pieces ? (unsigned)scan_blocks : (unsigned)(scan_blocks * k / n_pieces / 4 * 4);
+        if (!c->tk_copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->tk_copy_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->tk_start_ev, hipEventDisableTiming));
+            for (auto &e : c->tk_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[4], c->stream));
-    if (T > 0) HIP_TRY(hipMemcpyAsync(c->tk_text, buf + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->tk_text + T, (unsigned char)sep[0], (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
+    if (n_pieces == 1) {
+        if (T > 0) HIP_TRY(hipMemcpyAsync(c->tk_text, buf + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // the copy stream may not write the text before the launch stream is done with what it holds (an earlier build)
+        HIP_TRY(hipEventRecord(c->tk_start_ev, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->tk_copy_stream, c->tk_start_ev, 0));
+        for (int k = 0; k < n_pieces; k++) {
+            const int64_t o0 = (int64_t)piece_blk[k] * TOK_PAD_BYTES, o1 = std::min<int64_t>(T, (int64_t)piece_blk[k + 1] * TOK_PAD_BYTES);
+            if (o1 > o0) HIP_TRY(hipMemcpyAsync(c->tk_text + o0, buf + base + o0, (size_t)(o1 - o0), hipMemcpyHostToDevice, c->tk_copy_stream));
+            HIP_TRY(hipEventRecord(c->tk_piece_ev[k], c->tk_copy_stream));
+        }
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
+    // whatever way this function is left, the caller's buffer is no longer being read when it returns
+    struct CopyGuard {
+        hipStream_t s;
+        ~CopyGuard() {
+            if (s) (void)hipStreamSynchronize(s);
+        }
+    } copy_guard{n_pieces > 1 ? c->tk_copy_stream : nullptr};
     TokCounters tc{};
     int rc_bind = BFK_OK;
     for (int attempt = 0;; attempt++) {
@@ -488,7 +532,10 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         a.indptr = c->own_indptr;
         a.nnz_cap = nnz_cap;
         a.dbg = getenv("BFK_TOK_DEBUG") ? atoi(getenv("BFK_TOK_DEBUG")) : 0;
-        if (int e = launch_tokenize(a, c->stream, ev)) return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
+        // (a second attempt — the table grew — finds the text resident: no pieces to wait for)
+        const bool pieces = n_pieces > 1 && attempt == 0;
+        if (int e = launch_tokenize(a, c->stream, ev, pieces ? n_pieces : 1, piece_blk, pieces ? c->tk_piece_ev : nullptr))
+            return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
         // bind: its one copy + sync (longest row, nnz) also lands the tokeniser's counters
         c->d_indptr = c->own_indptr;
         c->d_indices = c->own_indices;
@@ -523,6 +570,7 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->tk_stats.ms_h2d = ms;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
         if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->tk_stats.ms_hash = ms;
+        if (hipEventElapsedTime(&ms, ev[1], ev[6]) == hipSuccess) c->tk_stats.ms_head = ms;
         if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->tk_stats.ms_ids = ms;
         if (hipEventElapsedTime(&ms, ev[4], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
     }

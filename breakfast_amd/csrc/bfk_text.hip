@@ -19,13 +19,15 @@
 //                  (A decoupled look-back inside k_tok_scan was tried first: blocks of equal, tiny work all start together
 //                  and every one of them then walks back over ~2000 unfinished predecessors — 85 ns per block, serial:
 //                  1.7 ms at 1M rows against 0.03 ms for this kernel)
-//   k_tok_hash     a lane takes the tokens that start in its 16 bytes: end from the bound bits, 32-bit hash of the bytes,
+//   k_tok_hash     a wave takes 4 KiB of text: the token starts go into a list in LDS (text order), the lanes take tokens
+//                  from it, four per lane and round: end from the bound bits, 32-bit hash of the bytes,
 //                  insert into an open-addressing table of 64-bit words {tag : length : byte offset of the token}:
 //                  empty -> compare-and-swap; tag and length equal -> the BYTES are compared (the table is exact: hash
 //                  collisions cost a probe, never an id) and the word is lowered to the smaller offset by atomicMin, so
 //                  a slot ends up holding the offset of the token's FIRST occurrence.  Per token: its slot is stored.
-//                  The first 4 KiB of text go first, in a launch of their own: the tokens every row carries are in
-//                  the table before 8000 waves ask for them at once (same-address atomics serialise at ~11 ns each)
+//   k_tok_head     the same for the first 4 KiB of text alone, BEFORE k_tok_hash: the tokens every row carries are in the
+//                  table before 8000 waves ask for them at once (same-address atomics serialise at ~11 ns each: 357 us for
+//                  k_tok_hash at 100k rows without this launch, ~80 with it)
 //   k_tok_rows     one thread per row: indptr[r] = number of token starts in front of row_off[r]; and one thread per
 //                  table slot: bit `first occurrence` set at the byte offset the slot holds
 //   k_voc_count    first-occurrence bits counted per window; k_scan_single again -> vocabulary entries in front of a window
@@ -90,11 +92,12 @@ __global__ __launch_bounds__(256) void k_tok_rowbits(TokArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a) {
+__global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a, uint32_t blk0) {
     __shared__ unsigned s_cnt[TOK_SCAN_WINS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t win0 = (uint32_t)blockIdx.x * TOK_SCAN_WINS + wave * TOK_WPW;  // this wave's first window
+    const uint32_t blk = blk0 + (uint32_t)blockIdx.x;
+    const uint32_t win0 = blk * TOK_SCAN_WINS + wave * TOK_WPW;  // this wave's first window
     const uint32_t sepx4 = (uint32_t)a.sep * 0x01010101u;
     uint4 v[TOK_WPW];
     uint32_t rb[TOK_WPW];
@@ -127,17 +130,20 @@ __global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a) {
     if (wave == 0) {  // tokens in front of every window INSIDE the block; the block's total goes to the scan of the blocks
         const int c = (int)s_cnt[lane];
         const int inc = tok_wave_incl_scan(c);
-        a.winbase[(uint32_t)blockIdx.x * TOK_SCAN_WINS + lane] = (uint32_t)(inc - c);
-        if (lane == 63) a.blkbase[blockIdx.x] = (uint32_t)inc;
+        a.winbase[blk * TOK_SCAN_WINS + lane] = (uint32_t)(inc - c);
+        if (lane == 63) a.blkbase[blk] = (uint32_t)inc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scan_single: in-place exclusive prefix sum of data[0 .. n) by one block of 1024 threads, data[n] = *total_out = sum.
-// Thread t owns a contiguous piece (a multiple of 4 values: 16-byte loads and stores).
+// k_scan_single: in-place exclusive prefix sum of data[0 .. n) by one block of 1024 threads, CONTINUING from *total (the sum
+// of what earlier calls scanned: the text arrives in pieces and every piece is scanned when it is there): data[i] = *total +
+// sum of data[0 .. i), then data[n] = *total = the new running sum.  Thread t owns a contiguous piece (a multiple of 4
+// values: 16-byte loads and stores; `data` 16-byte aligned).
 __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n, unsigned *total_out) {
     __shared__ unsigned s_w[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned carry = *total_out;  // (read by every thread before the barrier below, written by thread 0 after it)
     const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u;
     const uint32_t b = min(n, threadIdx.x * per), e = min(n, b + per);
     unsigned sum = 0;
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n
     const unsigned inc = (unsigned)tok_wave_incl_scan((int)sum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    unsigned run = inc - sum;
-    unsigned total = 0;
+    unsigned run = carry + inc - sum;
+    unsigned total = carry;
     for (int w = 0; w < 16; w++) {
         if (w < wave) run += s_w[w];
         total += s_w[w];
@@ -238,15 +244,10 @@ __device__ __forceinline__ uint32_t tok_probe(const TokArgs &a, uint32_t slot, u
 // working through the tokens of its own 16 bytes, one window after the other: half the lanes idle and one dependent load
 // at a time.)  The first probe of a token is part of the pipelined round; the few it does not settle (a slot taken by
 // another token, tokens over 16 bytes) go through tok_probe one at a time.
-__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units) {
+__device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, uint16_t *list /*LDS: TOK_WPW * TOK_WIN entries*/) {
     constexpr int U = 4;
-    __shared__ uint16_t s_list[4][TOK_WPW * TOK_WIN];  // a token per byte at worst (rows of one byte)
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t unit = unit0 + (uint32_t)blockIdx.x * 4 + wave;
-    if (unit >= n_units) return;
     const uint32_t win0 = unit * TOK_WPW;
-    uint16_t *list = s_list[wave];
     uint32_t st[TOK_WPW];
 #pragma unroll
     for (int u = 0; u < TOK_WPW; u++) st[u] = reinterpret_cast<const uint16_t *>(a.startbits)[(win0 + u) * (TOK_WIN / 16) + lane];
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uin
             if (!bw) {
                 bw = bw1[u];
                 w++;
-                while (!bw) bw = a.boundbits[++w];
+                const uint32_t w_max = (j[u] + TOK_MAX_LEN + 64u) >> 5;  // (beyond: the token is too long whatever follows)
+                while (!bw && w < w_max) bw = a.boundbits[++w];
+                if (!bw) bw = 1u;
             }
             len[u] = w * 32 + (uint32_t)__builtin_ctz(bw) - j[u];
             small[u] = len[u] <= 16;
@@ -351,6 +354,20 @@ __global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uin
             if (act[u]) a.tokslot[g0 + r0 + u * 64 + lane] = slot[u];
         }
     }
+}
+
+// the unit of the first 4 KiB, alone: the tokens every row carries are in the table before the whole text asks for them
+__global__ __launch_bounds__(64) void k_tok_head(TokArgs a) {
+    __shared__ uint16_t s_list[TOK_WPW * TOK_WIN];  // a token per byte at worst (rows of one byte)
+    tok_hash_unit(a, 0u, s_list);
+}
+
+__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units) {
+    __shared__ uint16_t s_list[4][TOK_WPW * TOK_WIN];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t unit = unit0 + (uint32_t)blockIdx.x * 4 + wave;
+    if (unit >= n_units) return;
+    tok_hash_unit(a, unit, s_list[wave]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,28 +447,50 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     } while (0)
 
 // enqueue text -> CSR.  The caller has zeroed {counters, rowbits, firstbits}, filled the table with TOK_EMPTY and padded
-// the text with separators up to T_pad + TOK_TEXT_SLACK.
-int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev) {
+// the text with separators up to T_pad + TOK_TEXT_SLACK.  The text may still be on its way: piece k (scan blocks
+// [piece_blk[k], piece_blk[k + 1])) is scanned and hashed as soon as piece_ev[k] — recorded on the copy stream behind the
+// piece's copy — has fired, so the kernels of one piece run under the copy of the next (n_pieces = 1, piece_ev = NULL: the
+// text is there).
+int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_pieces, const unsigned *piece_blk, hipEvent_t *piece_ev) {
     const unsigned scan_blocks = a.T_pad / (TOK_SCAN_WINS * TOK_WIN);
     const unsigned table_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)a.tmask + 256) / 256, 8192);
+    constexpr unsigned UNITS_PER_BLK = TOK_SCAN_WINS / TOK_WPW;  // hash units (4 KiB) per scan block (64 KiB)
     if (ev) (void)hipEventRecord(ev[0], st);
     if (a.n_rows > 0) {
         hipLaunchKernelGGL(k_tok_rowbits, dim3((a.n_rows + 255) / 256), dim3(256), 0, st, a);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tok_scan, dim3(scan_blocks), dim3(1024), 0, st, a);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase, scan_blocks, &a.tc->nnz);
-    LAUNCH_CHECK();
-    if (ev) (void)hipEventRecord(ev[1], st);
-    // the first 4 KiB alone (one wave), then the rest: the tokens every row carries are in the table before everyone asks
-    // for them at once
-    const unsigned n_units = a.T_pad / (TOK_WPW * TOK_WIN);
-    hipLaunchKernelGGL(k_tok_hash, dim3(1), dim3(64), 0, st, a, 0u, 1u);
-    LAUNCH_CHECK();
-    if (n_units > 1) {
-        hipLaunchKernelGGL(k_tok_hash, dim3((n_units - 1 + 3) / 4), dim3(256), 0, st, a, 1u, n_units);
-        LAUNCH_CHECK();
+    unsigned hashed = 0;  // hash units done so far
+    for (int k = 0; k < n_pieces; k++) {
+        const unsigned b0 = n_pieces > 1 ? piece_blk[k] : 0u, b1 = n_pieces > 1 ? piece_blk[k + 1] : scan_blocks;
+        if (piece_ev && hipStreamWaitEvent(st, piece_ev[k], 0) != hipSuccess) return (int)hipGetLastError();
+        if (b1 > b0) {
+            hipLaunchKernelGGL(k_tok_scan, dim3(b1 - b0), dim3(1024), 0, st, a, b0);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase + b0, b1 - b0, &a.tc->nnz);
+            LAUNCH_CHECK();
+        }
+        if (ev && k == 0) (void)hipEventRecord(ev[1], st);
+        // A token that starts near the end of the piece may reach into the next one (up to TOK_MAX_LEN bytes), whose text and
+        // bound bits are not there yet: the last TOK_HOLD_UNITS units of a piece wait for the next piece's scan.
+        unsigned u0 = hashed;
+        const unsigned u_end = b1 * UNITS_PER_BLK;
+        const unsigned u1 = k + 1 == n_pieces ? u_end : (u_end > hashed + TOK_HOLD_UNITS ? u_end - TOK_HOLD_UNITS : hashed);
+        if (k == 0) {
+            // the first 4 KiB alone (one wave), then the rest: the tokens every row carries are in the table before everyone
+            // asks for them at once.  (A text so short that its first piece is held back whole hashes unit 0 with the rest.)
+            if (u1 >= 1) {
+                hipLaunchKernelGGL(k_tok_head, dim3(1), dim3(64), 0, st, a);
+                LAUNCH_CHECK();
+                u0 = 1;
+            }
+            if (ev) (void)hipEventRecord(ev[6], st);
+        }
+        if (u1 > u0) {
+            hipLaunchKernelGGL(k_tok_hash, dim3((u1 - u0 + 3) / 4), dim3(256), 0, st, a, u0, u1);
+            LAUNCH_CHECK();
+        }
+        hashed = std::max(hashed, u1);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_tok_rows, dim3(std::max(table_blocks, (unsigned)std::min(8192, (a.n_rows + 256) / 256))), dim3(256), 0, st, a);

@@ -171,9 +171,11 @@ typedef struct bfk_text_stats {
     int32_t reserved_;
     float ms_h2d;            /* text + row offsets, host -> device */
     float ms_scan;           /* k_tok_rowbits + k_tok_scan */
-    float ms_hash;           /* k_tok_hash */
+    float ms_hash;           /* k_tok_head + k_tok_hash */
     float ms_ids;            /* k_tok_rows + k_tok_first + k_tok_ids */
     float ms_total;          /* first copy to last kernel */
+    float ms_head;           /* k_tok_head alone (part of ms_hash): one wave, the first 4 KiB */
+    float reserved2_;
 } bfk_text_stats;
 int bfk_ctx_text_stats(bfk_ctx *ctx, bfk_text_stats *out);
 

@@ -172,3 +172,16 @@ def test_cluster_text_matches_oracle_labels():
     for d in (1, 3):
         lab, st, _, _ = _lib.cluster_text(buf, off, " ", d)
         assert np.array_equal(lab, orc.cluster_csr(ip, ix, d, n_threads=8)["labels"])
+
+
+def test_device_csr_with_the_text_sent_in_pieces(monkeypatch):
+    """BFK_TOK_PIECES (opt-in: the text goes up in pieces on a copy stream, piece k is tokenised under the copy of piece
+    k + 1; the last units of a piece wait for the next piece — a token may reach into it): the same CSR"""
+    rows = list(dict.fromkeys(generate_profiles(100000)))
+    # long tokens across the piece borders too
+    rows[len(rows) // 2] += " " + "L" * 60000 + " " + "M" * 5000
+    buf, off = _lib.pack_rows(rows)
+    host = _lib.build_csr_bytes(buf, off, " ")
+    for pieces in ("2", "5", "8"):
+        monkeypatch.setenv("BFK_TOK_PIECES", pieces)
+        _same(_lib.build_csr_bytes(buf, off, " ", device=True), host)
