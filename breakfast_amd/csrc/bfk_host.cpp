@@ -105,7 +105,7 @@ struct bfk_ctx {
     // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
     uint32_t *pg_cnt = nullptr;
     int64_t n_short = 0;  // rows of at most 2 * PG_MAX_DIST tokens (bind time): they all meet in one group
-    uint32_t *pg_keys = nullptr, *pg_keys_s = nullptr;
+    uint32_t *pg_keys = nullptr, *pg_keys_s = nullptr, *pg_keys_pm = nullptr, *pg_ck = nullptr;
     int max_tok = -1;  // largest token id of the bound CSR (found when the prefix groups are first considered for it)
     int *pg_rows = nullptr, *pg_rows_s = nullptr;
     int2 *pg_recpos = nullptr;
@@ -199,7 +199,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->tk_text, c->tk_rowoff,
+                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->pg_ck, c->tk_text, c->tk_rowoff,
                     c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -695,6 +695,8 @@ static int ctx_size_pg(bfk_ctx *c, int recs, int key_bits, size_t *temp_bytes) {
         int rc = 0;
         cap = 0; rc |= dev_realloc(&c->pg_keys, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_keys_s, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_keys_pm, &cap, total);
+        cap = 0; rc |= dev_realloc(&c->pg_ck, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_rows, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_rows_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_srec, &cap, total + SIG_PAD_ROWS);
@@ -872,6 +874,10 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     pl.pg = 0;
     if (!pl.join && pg_wanted(c, max_dist)) {
         if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
+        // positional filter (k_pgplace): the composite {token key : slot} it bisects on needs 3 bits above the token's and must
+        // stay below PG_NONE; BFK_PG_POS=0 walks whole groups (round 2's walk)
+        pl.pg_pb = pl.pg_tb + 3 <= 31 ? 3 : 0;
+        if (const char *e = getenv("BFK_PG_POS")) pl.pg_pb = atoi(e) && pl.pg_tb + 3 <= 31 ? 3 : 0;
         size_t tb = 0;
         if (int rc = ctx_size_pg(c, max_dist + 2, pl.pg_tb, &tb)) return rc;
         pl.pg = 1;
@@ -884,6 +890,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.pg_temp = c->pg_temp;
         pl.pg_temp_bytes = tb;
         pl.pg_srec = c->pg_srec;
+        pl.pg_keys_pm = c->pg_keys_pm;
+        pl.pg_ck = c->pg_ck;
         pl.pg_recpos = c->pg_recpos;
         pl.pg_rowinfo = c->pg_rowinfo;
     }

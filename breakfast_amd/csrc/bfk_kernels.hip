@@ -1939,8 +1939,8 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
 // of a token is 32 bits: (sampled count, saturated) above (2^tb - 2 - token), tb = bits of the largest token id + 2.
 __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
-                                                int *__restrict__ rows, int kcap, int *__restrict__ parent, int4 *__restrict__ rowinfo,
-                                                Counters *ctr) {
+                                                uint32_t *__restrict__ keys_pm, int *__restrict__ rows_pm, int pm, int kcap,
+                                                int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr) {
     const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->n_work = (unsigned)((n + 63) >> 6);  // work items of k_pgjoin: blocks of 64 rows (k_cells left its tile count here)
@@ -1990,67 +1990,85 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
         parent[r] = r;
         if (e - b < 0 || e - b > kcap) atomicOr(&ctr->err_rows, ERR_ROWLEN);  // the CSR changed after the bind
     }
-    if (l16 < pre) {
-        keys[(size_t)r * recs + l16] = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
-        rows[(size_t)r * recs + l16] = r * recs + l16;  // the sort carries (row, slot)
-    } else if (l16 == pre) {
+    // The records go out twice: row-major (keys[row][slot]: what k_pgjoin reads row by row) and POSITION-major
+    // (keys_pm[slot][row] with their (row, slot) values: the sort's input).  The sort is stable, so the group of a token comes
+    // out as its records of slot 0 (rows ascending), then slot 1, ... — the order the positional filter of k_pgplace needs —
+    // without a single key bit spent on the position.
+    if (l16 < recs) {
+        uint32_t key;
+        if (l16 < pre) key = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
         // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
         // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
-        keys[(size_t)r * recs + pre] = (e - b) <= 2 * max_dist ? 0u : PG_NONE;
-        rows[(size_t)r * recs + pre] = r * recs + pre;
+        else key = (e - b) <= 2 * max_dist ? 0u : PG_NONE;
+        keys[(size_t)r * recs + l16] = key;
+        // (pm = 0 — the positional filter is off: token ids that leave no room for the composite key — keeps the records in
+        // row order, so that a group comes out with its rows ascending as the whole-group walk needs it)
+        const size_t o = pm ? (size_t)l16 * n + r : (size_t)r * recs + l16;
+        keys_pm[o] = key;
+        rows_pm[o] = r * recs + l16;  // the sort carries (row, slot)
     }
 }
 
-// one thread per position of the sorted records: {row, length, second-level signature} of the position's row in group
-// order (k_pgjoin reads the members of a group as one coalesced stream), and for every record of a row where it went and
-// how many members its group has BEHIND it — the walk of a row is then a list of chunks known in advance, whose loads can
-// be in flight together.  The end of a position's group: the next position whose key differs, found by a suffix minimum
-// over the block, and from the block's last position by galloping over the sorted keys.
-__global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s, const int *__restrict__ vals_s, int total,
-                                                 int recs, const int4 *__restrict__ rowinfo, int4 *__restrict__ srec,
-                                                 int2 *__restrict__ recpos, Counters *ctr) {
-    __shared__ int s_nh[256];
-    const int t = threadIdx.x, p = blockIdx.x * 256 + t;
-    const bool inb = p < total;
-    const uint32_t key = inb ? keys_s[p] : PG_NONE;
-    int row = 0, v = 0;
-    if (inb) {
-        v = vals_s[p];
-        row = v / recs;
-        const int4 ri = rowinfo[row];
-        srec[p] = make_int4(row, ri.x, ri.y, ri.z);
+// after the sort: the composite {token key : slot} of every position (what the positional filter bisects on; a SHORT record
+// and a PG_NONE stay what they are), and the position's {row, length, second-level signature} in group order (k_pgjoin reads the
+// members of a group as one coalesced stream)
+__global__ __launch_bounds__(256) void k_pgcomp(const uint32_t *__restrict__ keys_s, const int *__restrict__ vals_s, int total, int recs,
+                                                int pb, const int4 *__restrict__ rowinfo, uint32_t *__restrict__ ck,
+                                                int4 *__restrict__ srec) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t key = keys_s[p];
+    const int v = vals_s[p];
+    const int row = v / recs;
+    const int4 ri = rowinfo[row];
+    srec[p] = make_int4(row, ri.x, ri.y, ri.z);
+    ck[p] = (key == PG_NONE || key == 0u) ? key : ((key << pb) | (pb ? (uint32_t)(v - row * recs) : 0u));
+}
+
+// one thread per position of the sorted records: for every record of a row where it went and how many positions behind it
+// the row has to walk.
+//
+// POSITIONAL FILTER (round 3).  Let t* be the first element (in the global order) that rows A and B within max_dist = d share,
+// at position i of A's prefix and j of B's (from 0).  The i elements of A in front of t* are not in B and the j elements of B
+// in front of it are not in A, so i + j <= |A delta B| <= d.  Keys are {token : position}, so the group of a token lies in the
+// sorted order as its sub-groups of position 0, 1, .. d one after the other, rows ascending inside each.  A pair is looked at
+// from the row whose position is smaller (from the smaller row if they are equal): the record of row A at position i walks
+// the rest of its own sub-group (the rows behind A) and then the sub-groups of positions i + 1 .. d - i WHOLE — ONE contiguous
+// range of the sorted order, [p + 1, end of sub-group d - i) — and nothing at all when d - i < i.  The sub-groups that hold a
+// token late in BOTH rows' prefixes — the big ones: a token that is late in a prefix is a common one — are never walked.
+// Every pair within d is still met at t* by exactly one row; a pair can now also be met a second time from the other row
+// at a later shared token, which a labels-only step lets through (the verify drops it as connected) and an exact-edges step
+// decides by the records test for every candidate (k_pgjoin).
+__global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s /*composite: k_pgcomp*/, const int *__restrict__ vals_s,
+                                                 int total, int2 *__restrict__ recpos, Counters *ctr, int pb, int max_dist) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t key = keys_s[p];
+    const int v = vals_s[p];
+    if (key == PG_NONE) return;
+    // the last key this record walks to: its own (SHORT record, or no position bits), or {token : d - i}
+    uint32_t target = key;
+    bool walks = true;
+    if (pb && key != 0u) {
+        const int i = (int)(key & ((1u << pb) - 1u));
+        walks = max_dist - i >= i;
+        target = (key & ~((1u << pb) - 1u)) | (uint32_t)max(max_dist - i, 0);
     }
-    // first position behind p that starts another group, if the block can tell
-    int nh = !inb ? total : ((p + 1 < total && keys_s[p + 1] == key) ? 0x7FFFFFFF : p + 1);
-    if (t == 255 && nh == 0x7FFFFFFF) {
-        if (key == PG_NONE) {
-            nh = total;
-        } else {  // the group goes on behind the block: gallop, then bisect
-            int lo = p + 1, step = 1;  // keys_s[lo] == key
-            while (lo + step < total && keys_s[lo + step] == key) {
-                lo += step;
-                step <<= 1;
-            }
-            int hi = min(total, lo + step);
-            while (hi - lo > 1) {
-                const int mid = lo + ((hi - lo) >> 1);
-                if (keys_s[mid] == key) lo = mid;
-                else hi = mid;
-            }
-            nh = lo + 1;
+    int behind = 0;
+    if (walks) {  // first position whose key is above the target: gallop from p, then bisect (keys_s[p] <= target)
+        int lo = p, step = 1;
+        while (lo + step < total && keys_s[lo + step] <= target) {
+            lo += step;
+            step <<= 1;
         }
+        int hi = min(total, lo + step);
+        while (hi - lo > 1) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (keys_s[mid] <= target) lo = mid;
+            else hi = mid;
+        }
+        behind = lo - p;
     }
-    s_nh[t] = nh;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // suffix minimum
-        const int o = t + off < 256 ? s_nh[t + off] : 0x7FFFFFFF;
-        __syncthreads();
-        nh = min(nh, o);
-        s_nh[t] = nh;
-        __syncthreads();
-    }
-    if (!inb || key == PG_NONE) return;
-    const int behind = nh - p - 1;
     recpos[v] = make_int2(p, behind);
     // every PG_EST_STRIDE-th position reports what k_pgjoin will walk from it, so that the walk can be called off when the
     // groups are too big
@@ -2071,7 +2089,7 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
 // Work items are blocks of 64 rows (t_begin / t_end and the multi-GPU owner rule count in those).
 __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
                                                 const uint32_t *__restrict__ keys, const int4 *__restrict__ rowinfo, int n, int recs,
-                                                int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
+                                                int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb) {
     constexpr int SCAP = 1024, WAVES = 4;
     // A token that many rows carry can still be among a row's first d + 1 (small alphabets, random rows): the groups are then a
     // large part of all rows and walking them is quadratic.  k_pgplace reported the walk from every PG_EST_STRIDE-th position
@@ -2223,8 +2241,10 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
                     if (old == -1) {
                         // (just inserted; or the set takes no more entries: a labels-only step lets the pair through — the
                         // verify drops a second copy as connected — the others decide it the slow way)
-                        fresh = !full || pa.skip_connected;
-                        unknown = full && !pa.skip_connected;
+                        // (with position bits a pair can also be met from its OTHER row, at a later shared token: an exact-edges
+                        // step decides every candidate by the records)
+                        fresh = (!full && !(pb && !pa.skip_connected)) || pa.skip_connected;
+                        unknown = (full || pb) && !pa.skip_connected;
                         break;
                     }
                     h = (h + 1) & (SCAP - 1);
@@ -2552,7 +2572,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
         hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
-                           n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
+                           n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         return launch_verify(pl, pa, st, ev);
@@ -2634,13 +2654,16 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
-                           pl.pg_keys, pl.pg_rows, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr);
+                           pl.pg_keys, pl.pg_keys_pm, pl.pg_rows, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys_pm, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
             return e;
-        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
-                           pl.pg_srec, pl.pg_recpos, pl.ctr);
+        hipLaunchKernelGGL(k_pgcomp, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_pb,
+                           pl.pg_rowinfo, pl.pg_ck, pl.pg_srec);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_ck, pl.pg_rows_s, total, pl.pg_recpos, pl.ctr,
+                           pl.pg_pb, pl.d);
         LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[1], st);
         if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
