@@ -52,3 +52,13 @@ def kats():
 @pytest.fixture(scope="session")
 def cli_runs():
     return json.loads((GOLD / "cli_runs.json").read_text())
+
+
+def set_generator(monkeypatch, generator):
+    """force the candidate generator of the max-dist >= 2 kernels for a test: the band kernels, the prefix groups as small
+    inputs get them (whole-group walk), or the prefix groups with the positional filter that large inputs (>= 60k rows) get"""
+    monkeypatch.setenv("BFK_PG", "0" if generator == "band" else "1")
+    if generator == "prefix_pos":
+        monkeypatch.setenv("BFK_PG_POS", "1")
+    else:
+        monkeypatch.delenv("BFK_PG_POS", raising=False)

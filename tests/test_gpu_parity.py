@@ -12,7 +12,7 @@ import click.testing
 import numpy as np
 import pandas as pd
 import pytest
-from conftest import GOLD, load_stage, stage_names
+from conftest import GOLD, load_stage, stage_names, set_generator
 
 from breakfast_amd import fastpath, _lib, breakfast, console
 from breakfast_amd.synth import generate_profiles
@@ -678,14 +678,14 @@ def fuzz_case(rng):
 
 
 @pytest.mark.exact_edges
-@pytest.mark.parametrize("generator", ["band", "prefix"])
+@pytest.mark.parametrize("generator", ["band", "prefix", "prefix_pos"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
 def test_all_pairs_fuzz_vs_oracle(seed, generator, monkeypatch):
     """the general path on many small inputs at max-dist 2 .. 5 (splicing and find + hook unions, one- and two-phase
     verify, both certificates and the counting table), with the candidates from the band kernels and from the prefix
     groups (tiny alphabets, rows shorter than the prefix, repeated tokens, shuffled rows): labels against the oracle, edge
     counts against brute force"""
-    monkeypatch.setenv("BFK_PG", "1" if generator == "prefix" else "0")
+    set_generator(monkeypatch, generator)
     rng = np.random.default_rng(5000 + seed)
     for it in range(20):
         rows, indptr, indices, d, alphabet = fuzz_case(rng)
@@ -844,23 +844,31 @@ def test_default_configuration_equals_the_oracle_at_20k_rows(d):
     labels, st = _lib.cluster_csr(indptr, indices, d)
     assert np.array_equal(labels, want)
     assert st["n_retry_slices"] == 0
-    ctx = _lib.Context(0)
-    ctx.set_candidate_path("prefix")
-    ctx.upload_csr(indptr, indices)
-    d_out = ctx.alloc(4 * len(uf))
-    ctx.cluster(d, d_out)
-    st2 = ctx.sync()
-    assert st2["path"] == 2 and np.array_equal(ctx.download_i32(d_out, len(uf)), want)
-    assert st2["n_connected"] > 0  # the pruning verify was the one that ran
-    ctx.close()
+    for pos in ("0", "1"):  # whole-group walk / positional filter (what inputs from 60k rows get)
+        os.environ["BFK_PG_POS"] = pos
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_candidate_path("prefix")
+            ctx.upload_csr(indptr, indices)
+            d_out = ctx.alloc(4 * len(uf))
+            ctx.cluster(d, d_out)
+            st2 = ctx.sync()
+            assert st2["path"] == 2 and np.array_equal(ctx.download_i32(d_out, len(uf)), want)
+            assert st2["n_connected"] > 0  # the pruning verify was the one that ran
+            ctx.close()
+        finally:
+            del os.environ["BFK_PG_POS"]
 
 
 # ---- prefix groups (max-dist >= 4 on large inputs; any max-dist 2..7 when forced) against the band kernels and the oracle ----
 @pytest.mark.exact_edges
+@pytest.mark.parametrize("pos", ["0", "1"])
 @pytest.mark.parametrize("n,d,indels", [(3000, 2, False), (20000, 3, True), (20000, 5, True), (60000, 4, True), (777, 7, True)])
-def test_prefix_groups_equal_the_band_path(n, d, indels):
+def test_prefix_groups_equal_the_band_path(n, d, indels, pos, monkeypatch):
     """bfk_ctx_set_candidate_path(3): candidates from the groups of the rows' prefix elements instead of (k,f,g)
-    bands — same labels, same number of edges (every pair queued once, at the first element its rows share)"""
+    bands — same labels, same number of edges (every pair counted once, at the first element its rows share) — with the
+    whole-group walk (pos 0) and with the positional filter (pos 1: a record walks one range of position sub-groups)"""
+    monkeypatch.setenv("BFK_PG_POS", pos)
     kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
     uf = list(dict.fromkeys(generate_profiles(n, **kw)))
     indptr, indices, _ = _lib.build_csr(uf, " ")

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import load_stage, stage_names
+from conftest import load_stage, stage_names, set_generator
 from test_gpu_parity import fuzz_case
 
 from breakfast_amd import _lib
@@ -42,11 +42,11 @@ def test_golden_labels_with_pruning(name, force, monkeypatch):
     _invariants(st, labels)
 
 
-@pytest.mark.parametrize("generator", ["band", "prefix"])
+@pytest.mark.parametrize("generator", ["band", "prefix", "prefix_pos"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
 def test_fuzz_vs_oracle_with_pruning(seed, generator, monkeypatch):
     """the inputs of test_all_pairs_fuzz_vs_oracle (max-dist 2 .. 5) with the pruning kernel at every max-dist"""
-    monkeypatch.setenv("BFK_PG", "1" if generator == "prefix" else "0")
+    set_generator(monkeypatch, generator)
     monkeypatch.setenv("BFK_SKIP_CONNECTED", "1")
     rng = np.random.default_rng(5000 + seed)
     dropped = 0
