@@ -459,14 +459,15 @@ def main():
     exchange = one_gpu = None
     if world > 1 and a.merge == "allgather" and pipe == 1:
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(16)]
-        for e4 in evs:
-            e4[0].record()
-            sc.e.cluster_shard(d, rank, world, sc.local)
-            e4[1].record()
-            dist.all_gather_into_tensor(sc.gathered.view(-1), sc.local.view(-1))
-            e4[2].record()
-            sc.e.merge(sc.gathered, world, sc.labels)
-            e4[3].record()
+        with eng.run():  # (the engine's stream: where a step's kernels and collectives go)
+            for e4 in evs:
+                e4[0].record()
+                sc.e.cluster_shard(d, rank, world, sc.local)
+                e4[1].record()
+                dist.all_gather_into_tensor(sc.gathered.view(-1), sc.local.view(-1))
+                e4[2].record()
+                sc.e.merge(sc.gathered, world, sc.labels)
+                e4[3].record()
         torch.cuda.synchronize()
         eng.sync()
         med = lambda xs: sorted(xs)[len(xs) // 2]

@@ -32,13 +32,18 @@ from . import _lib
 
 
 class GpuEngine:
-    """libbfk resident context on one GPU; tensors are torch CUDA tensors, launches go to torch's current stream."""
+    """libbfk resident context on one GPU; tensors are torch CUDA tensors.  The engine owns ONE torch stream: the kernels of
+    libbfk and — through ShardedClusterer.step, which runs under it — the collectives between them are enqueued there, so the
+    label exchange is ordered behind the shard's kernels and the merge behind the exchange by the stream itself.  (Handing
+    libbfk the handle of torch's DEFAULT stream — 0 — means "the context's own stream" to bfk_ctx_set_stream: the kernels
+    then ran on a stream the collectives did not wait for.  Found by the round-3 rehearsal's per-phase events.)"""
 
     def __init__(self, device_index: int):
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(self.device)
         self.ctx = _lib.Context(device_index)
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.set_stream(self.stream.cuda_stream)
         self.n = 0
         self._keep = None
 
@@ -48,10 +53,14 @@ class GpuEngine:
         ix = torch.as_tensor(indices, dtype=torch.int32).to(self.device).contiguous()
         if ix.numel() == 0:
             ix = torch.zeros(1, dtype=torch.int32, device=self.device)
-        torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)  # (the copies above ran on the caller's stream)
         self._keep = (ip, ix)
         self.n = ip.numel() - 1
         self.ctx.bind_csr_device(ip.data_ptr(), ix.data_ptr(), self.n)
+
+    def run(self):
+        """context manager: what is enqueued inside goes to the engine's stream"""
+        return torch.cuda.stream(self.stream)
 
     def new_labels(self, parts: int = 1):
         return torch.empty((parts, max(self.n, 1)), dtype=torch.int32, device=self.device)
@@ -88,7 +97,15 @@ class ShardedClusterer:
 
     def step(self, max_dist: int):
         """CSR (resident) -> global canonical labels on every rank.  Asynchronous on the GPU engine except
-        for the fix-point test of merge='allreduce'."""
+        for the fix-point test of merge='allreduce'.  Everything — kernels, collectives, merge — is enqueued on the engine's
+        stream (engines without one, the CPU test engine, run in line)."""
+        run = getattr(self.e, "run", None)
+        if run is None:
+            return self._step(max_dist)
+        with run():
+            return self._step(max_dist)
+
+    def _step(self, max_dist: int):
         if self.world == 1:
             self.e.cluster_shard(max_dist, 0, 1, self.labels)
             return self.labels[0]
