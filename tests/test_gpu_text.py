@@ -185,3 +185,58 @@ def test_device_csr_with_the_text_sent_in_pieces(monkeypatch):
     for pieces in ("2", "5", "8"):
         monkeypatch.setenv("BFK_TOK_PIECES", pieces)
         _same(_lib.build_csr_bytes(buf, off, " ", device=True), host)
+
+
+def test_device_csr_degenerate_shapes():
+    """shapes that stress the byte-stream formulation: nothing but separators, a million empty rows, one row of megabytes,
+    separators and token bytes above 0x7f, NUL bytes inside tokens"""
+    # only separators / only empty rows
+    _same(_lib.build_csr_device(["   ", " ", ""], " "), orc.sparse_feature_matrix(["   ", " ", ""], " "))
+    ip, ix, nv = _lib.build_csr_device([""] * 1_000_000, " ")
+    assert ip[-1] == 0 and len(ip) == 1_000_001 and nv == 0 and len(ix) == 0
+    # one row of ~6 MB (800k tokens, 5k distinct) between two small ones
+    rng = np.random.default_rng(3)
+    big = " ".join(f"T{int(x)}" for x in rng.integers(0, 5000, 800_000))
+    rows = ["T1 T2", big, "T2 T4999 X"]
+    _same(_lib.build_csr_device(rows, " "), orc.sparse_feature_matrix(rows, " "))
+    # a separator byte above 0x7f and token bytes of every value except it (latin-1 keeps one byte per character on both sides)
+    sep = b"\xfe"
+    toks = [bytes([b]) * (1 + b % 5) for b in range(256) if b != 0xFE]
+    raw_rows = [sep.join(toks[i:i + 40]) for i in range(0, len(toks), 40)] + [sep.join(reversed(toks))]
+    buf = b"".join(raw_rows)
+    off = np.zeros(len(raw_rows) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r) for r in raw_rows])
+    lib = _lib.load()
+    import ctypes as C
+
+    def run(fn):
+        indptr = np.zeros(len(raw_rows) + 1, dtype=np.int32)
+        out, nnz, nvv = _lib.c_i32p(), C.c_int64(), C.c_int32()
+        rc = fn(buf, off.ctypes.data_as(_lib.c_i64p), len(raw_rows), sep, 1, indptr.ctypes.data_as(_lib.c_i32p), C.byref(out),
+                C.byref(nnz), C.byref(nvv))
+        assert rc == 0, lib.bfk_last_error()
+        idx = np.ctypeslib.as_array(out, shape=(max(nnz.value, 1),))[: nnz.value].copy()
+        lib.bfk_free(out)
+        return indptr, idx, nvv.value
+
+    _same(run(lib.bfk_build_csr_device), run(lib.bfk_build_csr))
+    # the oracle agrees with both (bytes in, no decoding anywhere)
+    ob = orc.lib()
+    o_ip = np.zeros(len(raw_rows) + 1, dtype=np.int32)
+    o_out, o_nnz, o_nv = orc.c_i32p(), C.c_int64(), C.c_int32()
+    assert ob.orc_build_csr(buf, off.ctypes.data_as(orc.c_i64p), len(raw_rows), sep, 1, o_ip.ctypes.data_as(orc.c_i32p),
+                            C.byref(o_out), C.byref(o_nnz), C.byref(o_nv)) == 0
+    o_ix = np.ctypeslib.as_array(o_out, shape=(max(o_nnz.value, 1),))[: o_nnz.value].copy()
+    ob.orc_free(o_out)
+    _same(run(lib.bfk_build_csr_device), (o_ip, o_ix, o_nv.value))
+
+
+def test_device_csr_a_million_one_byte_rows():
+    """rows that abut without any separator, one token per byte: the token list of a wave holds a token per byte"""
+    rng = np.random.default_rng(4)
+    rows = [chr(65 + int(x)) for x in rng.integers(0, 26, 1_000_000)]
+    ip, ix, nv = _lib.build_csr_device(rows, " ")
+    assert nv == 26 and np.array_equal(ip, np.arange(1_000_001, dtype=np.int32))
+    first = {}
+    want = np.fromiter((first.setdefault(r, len(first)) for r in rows), dtype=np.int32, count=len(rows))
+    assert np.array_equal(ix, want)
