@@ -7,7 +7,7 @@ def _early_preload():
     argv = []
     for a in sys.argv[1:]:  # "--opt=value" and "--opt value" are the same to click
         argv.extend(a.split("=", 1) if a.startswith("--") and "=" in a else [a])
-    if "--input-file" not in argv or "--input-cache" in argv or "--output-cache" in argv or "--help" in argv:
+    if "--input-file" not in argv or "--help" in argv:
         return
     try:
         i = argv.index("--max-dist") if "--max-dist" in argv else -1

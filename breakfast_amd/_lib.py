@@ -112,6 +112,9 @@ EXPORTS = {
     "bfk_table_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_cluster_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, c_i64p]),
+    "bfk_hash_rows": (C.c_int, [C.c_char_p, c_i64p, C.c_int64, C.POINTER(C.c_uint64)]),
+    "bfk_table_feature_hashes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bfk_match_hashes": (C.c_int, [C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_uint64), C.c_int64, c_i64p]),
     "bfk_warmup": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
     "bfk_preload_start": (C.c_int, [C.c_char_p, C.c_int, C.c_int64, C.c_int64]),
     "bfk_preload_wait": (C.c_int, []),
@@ -265,6 +268,34 @@ def neighbours_csr(indptr, indices, max_dist: int, select_ind=None):
     return nbr_indptr, nbr_indices
 
 
+def hash_rows(features):
+    """bfk_hash_rows on a sequence of str -> uint64[N, 2]: the two hashes of every feature string (side-car cache)"""
+    buf, off = pack_rows(features)
+    out = np.zeros((max(len(off) - 1, 1), 2), dtype=np.uint64)
+    _check(load().bfk_hash_rows(buf, _p64(off), len(off) - 1, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return out[: len(off) - 1]
+
+
+def match_hashes(cached, new):
+    """bfk_match_hashes: uint64[., 2] hash pairs -> int64[len(cached)]: the row of `new` with the same pair, or -1"""
+    a = np.ascontiguousarray(cached, dtype=np.uint64).reshape(-1, 2)
+    b = np.ascontiguousarray(new, dtype=np.uint64).reshape(-1, 2)
+    out = np.full(max(len(a), 1), -1, dtype=np.int64)
+    u64p = C.POINTER(C.c_uint64)
+    _check(load().bfk_match_hashes(a.ctypes.data_as(u64p), len(a), b.ctypes.data_as(u64p), len(b), _p64(out)))
+    return out[: len(a)]
+
+
+def labels_from_csr(n_rows: int, list_indptr, list_indices):
+    """bfk_labels_from_lists on lists given as CSR (int64 offsets, int32 members): no Python object per list"""
+    lib = load()
+    off = np.ascontiguousarray(list_indptr, dtype=np.int64)
+    flat = np.ascontiguousarray(list_indices if len(list_indices) else np.zeros(1, np.int32), dtype=np.int32)
+    labels = np.empty(max(n_rows, 1), dtype=np.int32)
+    _check(lib.bfk_labels_from_lists(int(n_rows), _p64(off), _p32(flat), len(off) - 1, _p32(labels)))
+    return labels[:n_rows]
+
+
 def labels_from_lists(n_rows: int, lists):
     """bfk_labels_from_lists: components of a list of index arrays (each list united as a path)."""
     lib = load()
@@ -403,6 +434,12 @@ class Table:
     def features(self):
         """filtered feature strings of the unique rows (collapse_duplicates order)"""
         return self._strings(self.lib.bfk_table_features, self.info.n_unique)
+
+    def feature_hashes(self):
+        """uint64[n_unique, 2]: the two hashes of every unique row's filtered feature string (side-car cache)"""
+        out = np.zeros((max(int(self.info.n_unique), 1), 2), dtype=np.uint64)
+        _check(self.lib.bfk_table_feature_hashes(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out[: int(self.info.n_unique)]
 
     def ids(self):
         """ids of the input rows"""

@@ -205,7 +205,15 @@ def cluster_features(meta, feature_sep, max_dist, min_cluster_size, input_cache,
     meta["n_features"] = np.diff(indptr).astype(np.int64)
 
     if input_cache is not None or output_cache:
-        labels = ca.cluster_with_cache(meta, indptr, indices, max_dist, input_cache, output_cache)
+        from . import sidecar
+
+        if sidecar.wants_sidecar(input_cache, output_cache):  # the cache's semantics on flat arrays (sidecar.py)
+            if output_cache and not str(output_cache).endswith(sidecar.SUFFIX):
+                raise ValueError(f"a side-car input cache can only be continued as a side-car: name the output cache *{sidecar.SUFFIX}")
+            labels = sidecar.cluster_with_sidecar(_lib.hash_rows(list(meta["feature"])), indptr, indices, max_dist,
+                                                  input_cache, output_cache)
+        else:
+            labels = ca.cluster_with_cache(meta, indptr, indices, max_dist, input_cache, output_cache)
     else:
         print("Imported cached results are not available. "
               "Distance matrix of complete dataset will be calculated.")

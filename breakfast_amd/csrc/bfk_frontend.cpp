@@ -883,6 +883,106 @@ extern "C" int bfk_table_features(const bfk_table *t, char **buf_out, int64_t **
     return BFK_OK;
 }
 
+// ---- side-car cache (breakfast_amd/sidecar.py): 128-bit hashes of feature strings ----------------------------------------
+// The reference's cache (src/breakfast/cache.py:94-112) matches the rows of a new input to the cached ones by their feature
+// STRING.  The side-car keeps two 64-bit hashes of the string instead of the string (16 bytes per row instead of ~330).
+namespace {
+inline uint64_t bytes_hash2(const char *p, size_t n) {  // independent of bytes_hash: other seed, other multiplier
+    uint64_t h = 0xD6E8FEB86659FD93ull ^ (n * 0x9FB21C651E98DF25ull);
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 31;
+        p += 8;
+        n -= 8;
+    }
+    uint64_t v = 0;
+    memcpy(&v, p, n);
+    h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+    return h ^ (h >> 29);
+}
+}  // namespace
+
+// out[2 r], out[2 r + 1] = the two hashes of row r = buf[off[r] .. off[r + 1])
+extern "C" int bfk_hash_rows(const char *buf, const int64_t *off, int64_t n_rows, uint64_t *out) {
+    if (!off || !out || n_rows < 0 || (!buf && n_rows > 0 && off[n_rows] > off[0])) return bfk_fail(BFK_EARG, "bfk_hash_rows: null argument");
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)host_threads(), n_rows / 8192 + 1));
+    parallel_chunks(parts, [&](int q) {
+        for (int64_t r = n_rows * q / parts; r < n_rows * (q + 1) / parts; r++) {
+            const size_t len = (size_t)std::max<int64_t>(0, off[r + 1] - off[r]);
+            out[2 * r] = bytes_hash(buf + off[r], len);
+            out[2 * r + 1] = bytes_hash2(buf + off[r], len);
+        }
+    });
+    return BFK_OK;
+}
+
+// a[2 i .. 2 i + 1] / b[2 j .. 2 j + 1]: hash pairs (the rows of b are distinct); out[i] = the j with b[j] == a[i], or -1
+// (cache.map_features, src/breakfast/cache.py:94-112, on the side-car's hashes)
+extern "C" int bfk_match_hashes(const uint64_t *a, int64_t n_a, const uint64_t *b, int64_t n_b, int64_t *out) {
+    if ((n_a > 0 && (!a || !out)) || (n_b > 0 && !b) || n_a < 0 || n_b < 0) return bfk_fail(BFK_EARG, "bfk_match_hashes: bad argument");
+    size_t cap = 16;
+    while (cap < (size_t)n_b * 2 + 16) cap <<= 1;
+    std::vector<int64_t> slot(cap, -1);
+    for (int64_t j = 0; j < n_b; j++) {
+        size_t i = (size_t)b[2 * j] & (cap - 1);
+        while (slot[i] >= 0) i = (i + 1) & (cap - 1);
+        slot[i] = j;
+    }
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)host_threads(), n_a / 65536 + 1));
+    parallel_chunks(parts, [&](int q) {
+        for (int64_t r = n_a * q / parts; r < n_a * (q + 1) / parts; r++) {
+            size_t i = (size_t)a[2 * r] & (cap - 1);
+            int64_t hit = -1;
+            while (slot[i] >= 0) {
+                const int64_t j = slot[i];
+                if (b[2 * j] == a[2 * r] && b[2 * j + 1] == a[2 * r + 1]) {
+                    hit = j;
+                    break;
+                }
+                i = (i + 1) & (cap - 1);
+            }
+            out[r] = hit;
+        }
+    });
+    return BFK_OK;
+}
+
+// the same for the filtered feature strings of a prepared table's unique rows (what bfk_table_features would hand out),
+// without building the strings' blob: out[2 u], out[2 u + 1]
+extern "C" int bfk_table_feature_hashes(const bfk_table *t, uint64_t *out) {
+    if (!t || !t->prepared || !out) return bfk_fail(BFK_EARG, "bfk_table_feature_hashes: bad argument");
+    const size_t nu = t->first_row.size();
+    const char *base = t->bytes.data();
+    const size_t sl = t->sep2.size();
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), nu / 8192 + 1));
+    parallel_chunks(parts, [&](int q) {
+        std::string tmp;
+        for (size_t u = nu * (size_t)q / (size_t)parts; u < nu * (size_t)(q + 1) / (size_t)parts; u++) {
+            const char *p;
+            size_t len;
+            if (!t->filtered) {
+                const Span f = t->feats[(size_t)t->first_row[u]];
+                p = base + f.off;
+                len = (size_t)f.len;
+            } else {
+                tmp.clear();
+                for (int32_t j = t->indptr[u]; j < t->indptr[u + 1]; j++) {
+                    if (j > t->indptr[u]) tmp.append(t->sep2.data(), sl);
+                    const Span v = t->vocab[(size_t)t->indices[(size_t)j]];
+                    tmp.append(base + v.off, (size_t)v.len);
+                }
+                p = tmp.data();
+                len = tmp.size();
+            }
+            out[2 * u] = bytes_hash(p, len);
+            out[2 * u + 1] = bytes_hash2(p, len);
+        }
+    });
+    return BFK_OK;
+}
+
 extern "C" int bfk_table_ids(const bfk_table *t, char **buf_out, int64_t **off_out) {
     if (!t || !buf_out || !off_out) return bfk_fail(BFK_EARG, "bfk_table_ids: bad argument");
     const size_t n = t->ids.size();

@@ -24,11 +24,12 @@ def cluster_ids(labels, weight, min_cluster_size):
     natively; used by the API path and the tests)"""
     import numpy as np
 
-    uniq, inv = np.unique(labels, return_inverse=True)
-    size = np.bincount(inv, weights=weight, minlength=len(uniq))
-    keep = size >= min_cluster_size
+    # labels are row indices (the smallest row of the component): sizes by one bincount over them, no sort
+    labels = np.asarray(labels, dtype=np.int64)
+    size = np.bincount(labels, weights=weight, minlength=len(labels))
+    keep = size >= min_cluster_size  # (only entries at component roots are populated: size 0 elsewhere)
     new_id = np.cumsum(keep) * keep
-    return new_id[inv].astype(np.int32), int(keep.sum())
+    return new_id[labels].astype(np.int32), int(keep.sum())
 
 
 def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
@@ -75,10 +76,10 @@ def _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins
     logic itself (cache.py: the reference's gzip-pickle of a DataFrame[id tuple, feature string] and a list of index arrays)
     needs the unique rows' strings and pandas for the pickle, nothing more.  Replaces the pandas reader, the per-token
     Python filter and the pandas writer of the mirror path for cache runs."""
+    _front.preload(input_file)  # (cache runs too: the HIP start-up overlaps the parsing)
     import numpy as np
-    import pandas as pd
 
-    from . import _lib, cache as ca
+    from . import _lib, sidecar
 
     try:
         table = _lib.Table.open(input_file, sep, id_col, clust_col)
@@ -94,6 +95,24 @@ def _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins
     if info.nnz == 0:
         raise ValueError("unable to infer matrix dimensions")  # (the reference dies here, :214)
     indptr, indices = table.indptr, table.indices
+    if sidecar.wants_sidecar(input_cache, output_cache):
+        # side-car container (sidecar.py): the cache's semantics on flat arrays — rows matched by two 64-bit hashes of their
+        # feature string, lists as one CSR; no pandas, no Python object per row
+        if output_cache and not str(output_cache).endswith(sidecar.SUFFIX):
+            raise ValueError(f"a side-car input cache can only be continued as a side-car: name the output cache *{sidecar.SUFFIX}")
+        labels = sidecar.cluster_with_sidecar(table.feature_hashes(), indptr, indices, max_dist, input_cache, output_cache)
+        print("Create graph and recover connected components")
+        print("Save clusters")
+        cid, n_clusters = cluster_ids(labels, table.weight, min_cluster_size)
+        print(f"Number of clusters found: {n_clusters}")
+        outdir.mkdir(parents=True, exist_ok=True)
+        table.write(outdir / "clusters.tsv", cid)
+        table.close()
+        return True
+    import pandas as pd
+
+    from . import cache as ca
+
     # the frame cache.py works on: id = tuple of the accessions of a unique row (input order), feature = its filtered string
     ids = table.ids()
     order = np.argsort(table.group, kind="stable")

@@ -278,6 +278,15 @@ int bfk_table_id(const bfk_table *t, int64_t r, const char **id_out, int64_t *le
 int bfk_table_features(const bfk_table *t, char **buf_out, int64_t **off_out);
 int bfk_table_ids(const bfk_table *t, char **buf_out, int64_t **off_out);
 
+/* ---- side-car cache (breakfast_amd/sidecar.py): the reference's cache (src/breakfast/cache.py) matches rows of a new input
+ * to cached rows by their feature STRING (:94-112); the side-car stores two 64-bit hashes of it instead.  bfk_hash_rows: rows
+ * are byte ranges of one buffer, out[2 r .. 2 r + 1] the hashes of row r; bfk_table_feature_hashes: the same for the filtered
+ * feature strings of a prepared table's unique rows (equal to bfk_hash_rows on bfk_table_features' output). */
+int bfk_hash_rows(const char *buf, const int64_t *off, int64_t n_rows, uint64_t *out);
+/* out[i] = the row j of b (hash pairs, rows distinct) equal to row i of a, or -1: cache.map_features (:94-112) on the hashes */
+int bfk_match_hashes(const uint64_t *a, int64_t n_a, const uint64_t *b, int64_t n_b, int64_t *out);
+int bfk_table_feature_hashes(const bfk_table *t, uint64_t *out);
+
 /* ---- the CLI's whole tail in one call -----------------------------------------------------------------------------
  * bfk_preload_start: a native thread loads `libbfk_path` (libbfk.so: HIP runtime, code object) and runs bfk_warmup(device,
  * hints) while the caller parses its input with the bfk_table_* functions of libbfk_front.so (which has no HIP dependency).

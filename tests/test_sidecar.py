@@ -1,0 +1,164 @@
+"""The side-car cache container (breakfast_amd/sidecar.py): CPU tests of its host logic (hashes, row matching, list update,
+file round trip, reading the reference's pickle) and — marked gpu — the reference's 8 cache scenarios through it."""
+
+import json
+
+import numpy as np
+import pandas as pd
+import pytest
+from conftest import GOLD
+
+from breakfast_amd import _lib, cache as ca, sidecar
+
+FIX = GOLD / "ref_fixtures"
+CACHE_INPUTS = ["AddedSeqs", "DisorderedOnly", "AddedAndDisorderedSeqs", "DeletedSingleSeq", "DeletedProfile", "ModifiedSeqs",
+                "MultipleTests", "NoChanges"]
+
+
+def test_hashes_identify_feature_strings():
+    feats = ["A1C G2T", "", "A1C G2T", "A1C  G2T", "G2T A1C", "x" * 1000, "x" * 1001]
+    h = _lib.hash_rows(feats)
+    assert h.shape == (7, 2) and (h[0] == h[2]).all()
+    assert len({tuple(r) for r in h.tolist()}) == 6  # every other pair differs (in both words, as it happens)
+    # the table's hashes are those of the filtered feature strings it would hand out
+    t = _lib.Table.from_lists([f"s{i}" for i in range(5)], ["A1C G2T", "G2T", "A1C G2T", "A1C G2T Q", ""])
+    t.prepare(" ", "raw", False, False, 0, 0, 29903)
+    assert np.array_equal(t.feature_hashes(), _lib.hash_rows(t.features()))
+    t2 = _lib.Table.from_lists([f"s{i}" for i in range(4)], ["A1C C241T del:5:3", "A1C", "A300C A1C", "A300C  A1C"])
+    t2.prepare(" ", "covsonar_dna", True, True, 264, 228, 29903)  # filtered: the strings are rebuilt from the kept tokens
+    assert np.array_equal(t2.feature_hashes(), _lib.hash_rows(t2.features()))
+
+
+def test_match_and_update_follow_the_reference_semantics():
+    cached = _lib.hash_rows(["a", "b", "c", "d"])
+    new = _lib.hash_rows(["d", "x", "b"])
+    c2n = sidecar.match_rows(cached, new)
+    assert c2n.tolist() == [-1, 2, -1, 0]
+    # lists [a b], [c], [b c d], [d]: rows that are gone leave their lists, a list that is left empty is dropped (cache.py:51-71)
+    off = np.array([0, 2, 3, 6, 7], dtype=np.int64)
+    flat = np.array([0, 1, 2, 1, 2, 3, 3], dtype=np.int32)
+    o2, f2 = sidecar.update_lists(off, flat, c2n)
+    assert o2.tolist() == [0, 1, 3, 4] and f2.tolist() == [2, 2, 0, 0]
+    want = ca.update_neighbours([flat[off[i]: off[i + 1]] for i in range(4)], c2n)
+    assert [x.tolist() for x in want] == [f2[o2[i]: o2[i + 1]].tolist() for i in range(len(o2) - 1)]
+    assert sidecar.match_rows(cached, _lib.hash_rows([])).tolist() == [-1] * 4
+
+
+def test_file_round_trip_and_magic(tmp_path, capsys):
+    h = _lib.hash_rows(["a", "b"])
+    off = np.array([0, 2, 3], dtype=np.int64)
+    flat = np.array([0, 1, 1], dtype=np.int32)
+    p = tmp_path / "deep" / "c.bfkc"
+    sidecar.save(p, 3, h, off, flat)
+    assert sidecar.is_sidecar(p) and not sidecar.is_sidecar(GOLD / "ref_cache_testfile_d1.pkl.gz") and not sidecar.is_sidecar(tmp_path / "nope")
+    h2, o2, f2 = sidecar.load(p, 3)
+    assert np.array_equal(h, h2) and np.array_equal(off, o2) and np.array_equal(flat, f2)
+    with pytest.raises(ca.CacheMismatch):  # another max-dist: the reference's warning, then a full computation
+        sidecar.load(p, 1)
+    assert "differnt max-dist" in capsys.readouterr().out
+    p.write_bytes(p.read_bytes()[:-2])
+    with pytest.raises(ValueError):
+        sidecar.load(p, 3)
+    assert sidecar.wants_sidecar(None, tmp_path / "x.bfkc") and not sidecar.wants_sidecar(None, tmp_path / "x.pkl.gz")
+
+
+def test_reference_pickle_reads_as_flat_arrays(cli_runs):
+    """a cache written by the reference itself (tests/golden/ref_cache_testfile_d1.pkl.gz), loaded as the side-car's arrays"""
+    h, off, flat = sidecar._load_any(GOLD / "ref_cache_testfile_d1.pkl.gz", 1)
+    ref = cli_runs["cache_init"]
+    assert np.array_equal(h, _lib.hash_rows(ref["meta_feature"]))
+    assert [flat[off[i]: off[i + 1]].tolist() for i in range(len(off) - 1)] == ref["neigh"]
+
+
+# ---- the reference's cache scenarios through the side-car (GPU: the lists and the components come from the device) -----------
+def _cli(args):
+    import click.testing
+
+    from breakfast_amd import console
+
+    res = click.testing.CliRunner().invoke(console.main, args)
+    assert res.exit_code == 0, (res.output, res.exception)
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reader", ["native", "pandas"])
+@pytest.mark.parametrize("start", ["sidecar", "reference_pickle"])
+@pytest.mark.parametrize("idx,name", list(enumerate(CACHE_INPUTS, 1)))
+def test_cache_scenarios_through_the_sidecar(idx, name, start, reader, cli_runs, tmp_path, monkeypatch):
+    """test_caching.py:58-103 with the side-car as the container: written by this build from testfile.tsv, or a pickle the
+    reference wrote continued as a side-car; both host paths; clusters.tsv equals what the reference produced — and the
+    side-car written by the run is itself a valid starting point for the same input again"""
+    if reader == "pandas":
+        monkeypatch.setenv("BFK_NO_FASTPATH", "1")
+    monkeypatch.chdir(FIX)
+    if start == "sidecar":
+        cache = tmp_path / "c0" / "init.bfkc"
+        _cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "init"), "--output-cache", str(cache), "--max-dist", "1"])
+        assert sidecar.is_sidecar(cache)
+        assert (tmp_path / "init" / "clusters.tsv").read_text() == cli_runs["dist1"]["clusters_tsv"]
+    else:
+        cache = GOLD / "ref_cache_testfile_d1.pkl.gz"
+    inp = f"testfile_caching{idx:02d}_{name}.tsv"
+    nxt = tmp_path / "next.bfkc"
+    res = _cli(["--input-file", inp, "--outdir", str(tmp_path / "out"), "--input-cache", str(cache), "--output-cache", str(nxt),
+                "--max-dist", "1"])
+    assert ("Import from side-car cache" in res.output) == (start == "sidecar")
+    assert (tmp_path / "out" / "clusters.tsv").read_text() == cli_runs[f"cache_caching{idx:02d}"]["clusters_tsv"]
+    exp = pd.read_table(f"expected_clusters_caching{idx:02d}_dist1.tsv", sep="\t")
+    assert exp.equals(pd.read_table(tmp_path / "out" / "clusters.tsv", sep="\t"))
+    _cli(["--input-file", inp, "--outdir", str(tmp_path / "again"), "--input-cache", str(nxt), "--max-dist", "1"])
+    assert (tmp_path / "again" / "clusters.tsv").read_text() == cli_runs[f"cache_caching{idx:02d}"]["clusters_tsv"]
+
+
+@pytest.mark.gpu
+def test_sidecar_other_max_dist_and_pickle_output(tmp_path, monkeypatch, cli_runs):
+    monkeypatch.chdir(FIX)
+    cache = tmp_path / "init.bfkc"
+    _cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "init"), "--output-cache", str(cache), "--max-dist", "1"])
+    res = _cli(["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "o"), "--input-cache", str(cache), "--max-dist", "2",
+                "--min-cluster-size", "3"])
+    assert "differnt max-dist" in res.output
+    assert (tmp_path / "o" / "clusters.tsv").read_text() == cli_runs["dist2_mcs3"]["clusters_tsv"]
+    import click.testing
+
+    from breakfast_amd import console
+
+    bad = click.testing.CliRunner().invoke(console.main, ["--input-file", "testfile.tsv", "--outdir", str(tmp_path / "p"),
+                                                          "--input-cache", str(cache), "--output-cache", str(tmp_path / "x.pkl.gz")])
+    assert bad.exit_code != 0 and "side-car" in str(bad.exception)
+
+
+@pytest.mark.gpu
+def test_sidecar_incremental_at_100k_rows_equals_a_fresh_run(tmp_path):
+    """grow a 90k-profile input to 100k through the side-car (and drop 5k old rows on the way): same clusters.tsv as a fresh
+    run of the final input, with lists computed only for the rows that are new"""
+    from breakfast_amd.synth import generate_profiles
+
+    rows = generate_profiles(100000)
+
+    def write(path, idx):
+        with open(path, "w") as f:
+            f.write("accession\tdna_profile\n")
+            for i in idx:
+                f.write(f"seq{i:07d}\t{rows[i]}\n")
+
+    write(tmp_path / "a.tsv", range(90000))
+    keep = list(range(0, 40000)) + list(range(45000, 100000))
+    write(tmp_path / "b.tsv", keep)
+    cache = tmp_path / "c.bfkc"
+    _cli(["--input-file", str(tmp_path / "a.tsv"), "--outdir", str(tmp_path / "oa"), "--output-cache", str(cache)])
+    assert cache.stat().st_size < 8_000_000  # 16 B of hashes per row + the lists: not the 30 MB of feature strings
+    _cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "ob"), "--input-cache", str(cache)])
+    _cli(["--input-file", str(tmp_path / "b.tsv"), "--outdir", str(tmp_path / "fresh")])
+    got, want = (tmp_path / "ob" / "clusters.tsv").read_bytes(), (tmp_path / "fresh" / "clusters.tsv").read_bytes()
+    # (a deleted row's cached list still chains its surviving neighbours — the reference's semantics, cache.py:51-71 — so the
+    # cached run may join what a fresh run keeps apart; with this generator a deleted parent's children are within max-dist 2 of
+    # each other, never within 1, and the partitions can differ there: compare as the reference would, component by component)
+    if got != want:
+        g = pd.read_table(tmp_path / "ob" / "clusters.tsv")
+        w = pd.read_table(tmp_path / "fresh" / "clusters.tsv")
+        assert g["id"].equals(w["id"])
+        # every fresh cluster lies inside one cached cluster (the cache can only ADD connections)
+        both = pd.DataFrame({"g": g["cluster_id"], "w": w["cluster_id"]}).dropna(subset=["w"])
+        assert both.groupby("w")["g"].nunique(dropna=False).max() == 1
