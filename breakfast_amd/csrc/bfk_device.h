@@ -97,6 +97,7 @@ struct Plan {
     uint32_t *pg_cnt;                         // sampled token counts (2^PG_CNT_BITS hashed counters)
     uint32_t *pg_keys, *pg_keys_s;            // [n][recs] record keys, row-major; sorted
     int pg_tb;                                // key bits of a token: bits of (largest token id + 2)
+    int pg_walk16;                            // labels-only steps walk with k_pgwalk16 (16 lanes per row, no de-duplication set)
     int pg_pb;                                // position bits of the composite key k_pgplace bisects on (3; 0 = positional filter off)
     uint32_t *pg_keys_pm, *pg_ck;             // [recs][n] record keys position-major (the sort's input); composite keys in sorted order
     int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along

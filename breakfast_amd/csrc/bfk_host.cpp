@@ -346,9 +346,11 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
         if (int rc = dev_realloc(&c->d_tile_slots, &c->tile_slots_cap, c->tile_cap * PF_WAVES_MAX, 1.0)) return rc;
     }
     {
-        // 16N candidate slots in all (d=1 needs ~0.7N, a dense d=5 graph ~15N); an overflow is repaired by
-        // bfk_ctx_sync (sliced re-run) and doubles the queue for the following runs
-        int64_t want = std::max<int64_t>(1024, (16 * n) / CAND_SHARDS + 256);
+        // 64N candidate slots in all up to 1M rows (1.5 GB there), 32N beyond 2M (d=1 needs ~0.7N; a dense d=5 graph 18N at
+        // 1M rows and 36N at 30k with the labels-only walk, which lets repeated pairs of hub rows through); an overflow is
+        // repaired by bfk_ctx_sync (sliced re-run) and doubles the queue for the following runs
+        const int64_t slots = std::max<int64_t>(32 * n, std::min<int64_t>(64 * n, 64ll << 20));
+        int64_t want = std::max<int64_t>(1024, slots / CAND_SHARDS + 256);
         if (int rc = ctx_size_cand(c, want * CAND_SHARDS)) return rc;
     }
     return BFK_OK;
@@ -881,6 +883,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         // rows: 0.49 / 0.55)
         pl.pg_pb = (pl.pg_tb + 3 <= 31 && c->n >= 60000) ? 3 : 0;
         if (const char *e = getenv("BFK_PG_POS")) pl.pg_pb = atoi(e) && pl.pg_tb + 3 <= 31 ? 3 : 0;
+        pl.pg_walk16 = 1;  // (labels-only steps; BFK_PG_WALK16=0: k_pgjoin for every step)
+        if (const char *e = getenv("BFK_PG_WALK16")) pl.pg_walk16 = atoi(e) != 0;
         size_t tb = 0;
         if (int rc = ctx_size_pg(c, max_dist + 2, pl.pg_tb, &tb)) return rc;
         pl.pg = 1;

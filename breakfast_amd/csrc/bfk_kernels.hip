@@ -1268,13 +1268,30 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     if (e_lo > j0) e_first = j0 + (e_lo - j0 + jstep - 1) / jstep * jstep;
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     unsigned n_edges = 0, n_conn = 0;  // wave-uniform
-    // A round takes `width` queue records per group: 1, 2, 4, 8, then 16 — in the first rounds nothing is connected yet and
-    // everything a wave looks at has to be checked, so they are kept short until the first unions have gone in
-    int width = 1;
-    for (int e0 = e_first;; e0 += width * jstep, width = min(16, width * 2)) {
-        const int e = e0 + l16 * jstep;
-        const bool have = l16 < width && e < e_hi;
-        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+    // A group reads 16 CONSECUTIVE records (blocks of 16, jstep blocks apart), not 16 records jstep apart as k_verify does:
+    // the queue is read once, in full lines (1M rows, max_dist 5: 0.95 -> 0.75 ms for this kernel; the records of a block are
+    // mostly pairs of one row, which are then looked up together — 8% more exact tests).  The first block of a group is taken
+    // in pieces of 1, 2, 4, 8 records: in the first rounds nothing is connected yet and everything a wave looks at has to be
+    // checked, so they are kept short until the first unions have gone in (a queue of a few records per lane would otherwise
+    // be one round).  (BFK_PF_DEBUG=512: k_verify's map, for comparison.)
+    const bool consec = (pa.dbg & 512) == 0;
+    int width = 1, lo = 0;
+    for (int e0 = consec ? j0 : e_first;;) {
+        const int e = consec ? e0 * 16 + l16 : e0 + l16 * jstep;
+        const bool have = consec ? (l16 >= lo && l16 < lo + width && e >= e_lo && e < e_hi) : (l16 < width && e < e_hi);
+        if (__builtin_amdgcn_ballot_w64(consec ? (long long)e0 * 16 < e_hi : have) == 0ull) break;
+        if (consec) {  // (the next piece of this block, or the next block)
+            lo += width;
+            width = min(16, width * 2);
+            if (lo >= 16) {
+                lo = 0;
+                width = 16;
+                e0 += jstep;
+            }
+        } else {
+            e0 += width * jstep;
+            width = min(16, width * 2);
+        }
         int4 rec = make_int4(0, 0, 0, 0);
         int2 kk = make_int2(0, 0);
         bool todo = false, conn = false;
@@ -1291,6 +1308,7 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
         n_conn += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(conn));
         const int ns = __popcll(tm), rank = below(tm);
         if (todo) {
+            if (rec.w < 0) rec.w = pa.indptr[rec.y];  // (k_pgwalk16 leaves B's offset to the few records that get this far)
             s_rec[wave][rank] = rec;
             s_kk[wave][rank] = kk;
         }
@@ -1338,7 +1356,8 @@ __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey
         const int2 kk = pa.candk[slot];
         const int ka = kk.x, kb = kk.y, kt = ka + kb;
         if (kt <= VERIFY_MAX_TOKENS) continue;  // done by k_verify
-        const int4 rec = pa.cand[slot];
+        int4 rec = pa.cand[slot];
+        if (rec.w < 0) rec.w = pa.indptr[rec.y];  // (k_pgwalk16)
         if (pa.skip_connected) {  // one thread decides for the block (trees merge while the block looks)
             if (threadIdx.x == 0) {
                 sdist = uf_find(pa.parent, rec.x) == uf_find(pa.parent, rec.y) ? 1 : 0;
@@ -2045,7 +2064,10 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
     if (p >= total) return;
     const uint32_t key = keys_s[p];
     const int v = vals_s[p];
-    if (key == PG_NONE) return;
+    if (key == PG_NONE) {  // no such record: nothing behind it (k_pgwalk16 reads the counts without looking at the keys)
+        recpos[v] = make_int2(p, 0);
+        return;
+    }
     // the last key this record walks to: its own (SHORT record, or no position bits), or {token : d - i}
     uint32_t target = key;
     bool walks = true;
@@ -2354,6 +2376,208 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
     }
 }
 
+// k_pgwalk16: the walk of LABELS-ONLY steps, 16 lanes per row (four rows per wave).  k_pgjoin gives a row a whole wave: with
+// the positional filter a row has ~110 members behind its records — less than two chunks of 64 — and the set-up of the list,
+// the clean-up of the de-duplication set and the launch of a wave are paid per row.  Two things bound that kernel at 1M rows
+// (0.91 ms): 62 500 blocks — the grid that gives every wave one row, for balance — cost 0.5 ms just to be dispatched (the same
+// walk without queueing: 0.80 ms on that grid, 0.31 on 8192 blocks), and the queue records took two scattered loads each (the
+// rows' offsets in the CSR).  Here a 16-lane group owns a row: the set-up is four DPP steps inside the group, the steps' ends
+// and bases sit in LDS, a chunk is 16 members with four chunks in flight, and a group that has finished its row takes its
+// next one while the other three go on (no wave-wide row boundary), so a grid of 32 blocks per CU balances.  A's offset
+// comes with the row's head; B's is left to the verify, which needs it for the ~6% of the records that are not dropped as
+// connected (`w` < 0 in the queue record).  The de-duplication set is 64 slots per group and stops taking entries at 32: what
+// it misses is queued twice and the verify drops the second copy as connected — which is why this kernel serves labels-only
+// steps (exact-edges steps and edge capture keep k_pgjoin, whose records test counts every pair once).
+__device__ __forceinline__ int row16_incl_scan(int x) {  // inclusive prefix sum inside each 16-lane row (DPP row_shr)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
+                                                  const int4 *__restrict__ rowinfo, int n, int recs, int shard0, int nshards,
+                                                  int t_begin, int t_end, PairArgs pa) {
+    constexpr int WAVES = 4, GSET = 64, U = 4;
+    if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) pa.ctr->pg_fail = 1;  // (groups too big to pay: the host redoes the step on the band kernels)
+        return;
+    }
+    __shared__ int s_end[WAVES][4][16], s_base[WAVES][4][16];  // per group: inclusive end of every step in the row's list, base position
+    __shared__ int s_set[WAVES][4][GSET];                       // per group: members of this row that were queued
+    __shared__ int4 s_q[WAVES][128];                            // pairs {A, B, offset of A, -1} waiting for their queue slots
+    __shared__ int2 s_qk[WAVES][128];                           // ... and {k_A, k_B}
+    __shared__ unsigned long long s_vis[WAVES];
+    const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+    int *g_end = s_end[wave][grp], *g_base = s_base[wave][grp], *g_set = s_set[wave][grp];
+    int4 *sq = s_q[wave];
+    int2 *sqk = s_qk[wave];
+#pragma unroll
+    for (int j = 0; j < GSET / 16; j++) g_set[l16 + 16 * j] = -1;
+    int cshard = (blockIdx.x * WAVES + wave) & (CAND_SHARDS - 1);
+    const int d = pa.d;
+    int nq = 0;  // pairs waiting in sq (wave-uniform)
+    unsigned long long visits = 0;
+    auto flush64 = [&]() {  // the first 64 waiting pairs go to the queue (full lines, one returning atomic), the rest moves to the front
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(nq, 64);
+        cshard = (cshard + 1) & (CAND_SHARDS - 1);
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&pa.ctr->ncand[cshard], (unsigned)cnt);
+        int4 e = make_int4(0, 0, 0, 0), mv = e;
+        int2 ek = make_int2(0, 0), mk = ek;
+        if (lane < cnt) {
+            e = sq[lane];
+            ek = sqk[lane];
+        }
+        if (64 + lane < nq) {
+            mv = sq[64 + lane];
+            mk = sqk[64 + lane];
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < cnt) {
+            const int idx = base + lane;
+            if (idx < pa.cand_cap_shard) {
+                const size_t o = (size_t)cshard * pa.cand_cap_shard + idx;
+                pa.cand[o] = e;
+                pa.candk[o] = ek;
+            } else {
+                pa.ctr->overflow = 1;  // dropped: the host re-runs the row range in smaller slices
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (64 + lane < nq) {
+            sq[lane] = mv;
+            sqk[lane] = mk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nq -= cnt;
+    };
+    const int r_begin = t_begin * 64, r_end = min(n, (int)min((long long)t_end * 64, (long long)n));
+    const int stride = (int)gridDim.x * WAVES * 4;
+    auto owned_from = [&](int A) {  // the first row at or behind A (in steps of the stride) that is this rank's
+        while (nshards > 1 && A < r_end && ((A >> 6) % nshards) != shard0) A += stride;
+        return A;
+    };
+    int A = owned_from(r_begin + (blockIdx.x * WAVES + wave) * 4 + grp);  // (group-uniform)
+    bool active = A < r_end, fresh_row = active;
+    // the head of the group's next row {its records' positions and counts, length, signature, offset} is asked for one row ahead
+    const int slot = l16 == 0 ? recs - 1 : l16 - 1;
+    int2 h_rp = make_int2(0, 0);
+    int4 h_ri = make_int4(0, 0, 0, 0);
+    if (active) {
+        if (l16 < recs) h_rp = recpos[(size_t)A * recs + slot];
+        h_ri = rowinfo[A];
+    }
+    int T = 0, f = 0, st = 0, len_a = 0, off_a = 0, n_in = 0;
+    uint32_t sa0 = 0, sa1 = 0;
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+        if (fresh_row) {
+            // the row's list: the members behind its records, step after step (step 0 = the SHORT record in slot recs - 1,
+            // step i = slot i - 1); lane l of the group holds step l
+            const int2 rp = h_rp;
+            const int4 ri = h_ri;
+            const int nx = owned_from(A + stride);
+            h_rp = make_int2(0, 0);
+            if (nx < r_end) {
+                if (l16 < recs) h_rp = recpos[(size_t)nx * recs + slot];
+                h_ri = rowinfo[nx];
+            }
+            const int incl = row16_incl_scan(rp.y);
+            g_end[l16] = incl;
+            g_base[l16] = rp.x + 1 - (incl - rp.y);  // entry e of the list, in step s, is position base[s] + e
+            len_a = ri.x;
+            sa0 = (uint32_t)ri.y;
+            sa1 = (uint32_t)ri.z;
+            off_a = ri.w;
+            f = l16;
+            st = 0;
+            fresh_row = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) T = g_end[15];  // (steps at and beyond recs repeat the total)
+        int4 rec[U];
+        bool have[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int fu = f + 16 * u;
+            have[u] = active && fu < T;
+            rec[u] = make_int4(0, 0, 0, 0);
+            if (have[u]) {
+                while (fu >= g_end[st]) st++;  // (fu < T = end[15]: stops at 15 at the latest)
+                rec[u] = srec[g_base[st] + fu];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bool pass = have[u] && abs(rec[u].y - len_a) <= d && __popc((uint32_t)rec[u].z ^ sa0) + __popc((uint32_t)rec[u].w ^ sa1) <= d;
+            if (pa.dbg & 64) pass = have[u] && rec[u].x == -7;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
+            visits += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have[u]));
+            if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+            // met in an earlier step of this row?  (the set takes entries while it is less than half full; a member it does
+            // not know is queued)
+            bool ins = false;
+            if (pass && n_in < GSET / 2 && !(pa.dbg & 256)) {
+                const int B = rec[u].x;
+                uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 26;  // GSET = 64 slots
+                for (;;) {
+                    const int old = atomicCAS(&g_set[h], -1, B);
+                    if (old == B) {
+                        pass = false;
+                        break;
+                    }
+                    if (old == -1) {
+                        ins = true;
+                        break;
+                    }
+                    h = (h + 1) & (GSET - 1);
+                }
+            }
+            n_in += __popc((unsigned)((__builtin_amdgcn_ballot_w64(ins) >> (grp * 16)) & 0xFFFFull));  // (group-uniform)
+            const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass);
+            if (pm != 0ull) {
+                if (pass) {
+                    const int i = nq + below(pm);
+                    sq[i] = make_int4(A, rec[u].x, off_a, -1);
+                    sqk[i] = make_int2(len_a, rec[u].y);
+                }
+                nq += __popcll(pm);
+                if (pa.dbg & 128) nq = 0;  // (BFK_PF_DEBUG=128: nothing is queued)
+                if (nq >= 64) flush64();
+            }
+        }
+        f += 16 * U;
+        if (active && f - l16 >= T) {  // (group-uniform) this row is walked: the group's next one
+            if (n_in > 0) {
+#pragma unroll
+                for (int j = 0; j < GSET / 16; j++) g_set[l16 + 16 * j] = -1;
+                n_in = 0;
+            }
+            A = owned_from(A + stride);
+            active = A < r_end;
+            fresh_row = active;
+        }
+    }
+    while (nq > 0) flush64();
+    if (lane == 0) s_vis[wave] = visits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0ull;
+        for (int w = 0; w < WAVES; w++) sum += s_vis[w];
+        if (sum) atomicAdd(&pa.ctr->pairs_filtered, sum);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_flatten: labels[i] = root(i).  k_merge: unite (i, gathered[g][i]).  k_changed: fix-point flag.
 // ------------------------------------------------------------------------------------------------
@@ -2571,8 +2795,20 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
         const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
-        hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
-                           n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
+        if (pa.skip_connected && pl.pg_walk16) {  // labels-only steps: 16 lanes per row
+            // (a group takes rows in turn: 32 blocks per CU balance as well as one row per group did, and 62 500 blocks cost 0.5 ms to dispatch)
+            const int wper = per_cu_env ? per_cu_env : 32;
+            auto walk = [&](int tb, int te) {
+                const int it = std::max(0, std::min(te, (n + 63) / 64) - tb);
+                const int wblocks = std::max(1, std::min(pl.pf_blocks / 256 * wper, (int)std::min<long long>((long long)it * 4, 1 << 20)));
+                hipLaunchKernelGGL(k_pgwalk16, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, n, pl.pg_recs, pl.shard,
+                                   pl.n_shards, tb, te, pa);
+            };
+            walk(t_begin, t_end);
+        } else {
+            hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
+                               n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
+        }
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         return launch_verify(pl, pa, st, ev);
@@ -2665,7 +2901,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_ck, pl.pg_rows_s, total, pl.pg_recpos, pl.ctr,
                            pl.pg_pb, pl.d);
         LAUNCH_CHECK();
-            if (ev) (void)hipEventRecord(ev[1], st);
+        if (ev) (void)hipEventRecord(ev[1], st);
         if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;
         return launch_flatten(pl, st, ev);
     }
