@@ -25,6 +25,7 @@ constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant jo
 constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
 constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
 constexpr int PG_GIVE_UP = 4096;        // group members behind a row's records, per row (sampled), beyond which the band path is used
+constexpr int PGK_ROWS = 4;             // rows per 16-lane group of k_pgkeys
 constexpr int PG_EST_STRIDE = 1024;     // every so many positions of the sorted records measure their walk (power of two)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };
@@ -99,7 +100,7 @@ struct Plan {
     int pg_tb;                                // key bits of a token: bits of (largest token id + 2)
     int pg_walk16;                            // labels-only steps walk with k_pgwalk16 (16 lanes per row, no de-duplication set)
     int pg_pb;                                // position bits of the composite key k_pgplace bisects on (3; 0 = positional filter off)
-    uint32_t *pg_keys_pm, *pg_ck;             // [recs][n] record keys position-major (the sort's input); composite keys in sorted order
+    uint32_t *pg_keys_pm;                     // [recs][n] record keys position-major (the sort's input)
     int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along
     void *pg_temp;
     size_t pg_temp_bytes;
@@ -155,7 +156,7 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
                     hipEvent_t *piece_ev);  // bfk_text.hip
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
-                 int *rows_out, size_t n, int bits, hipStream_t st);  // bfk_sort.hip
+                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);

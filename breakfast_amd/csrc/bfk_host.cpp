@@ -105,7 +105,7 @@ struct bfk_ctx {
     // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
     uint32_t *pg_cnt = nullptr;
     int64_t n_short = 0;  // rows of at most 2 * PG_MAX_DIST tokens (bind time): they all meet in one group
-    uint32_t *pg_keys = nullptr, *pg_keys_s = nullptr, *pg_keys_pm = nullptr, *pg_ck = nullptr;
+    uint32_t *pg_keys = nullptr, *pg_keys_s = nullptr, *pg_keys_pm = nullptr;
     int max_tok = -1;  // largest token id of the bound CSR (found when the prefix groups are first considered for it)
     int *pg_rows = nullptr, *pg_rows_s = nullptr;
     int2 *pg_recpos = nullptr;
@@ -199,7 +199,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
-                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->pg_ck, c->tk_text, c->tk_rowoff,
+                    c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
                     c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -657,8 +657,18 @@ static int ctx_size_join(bfk_ctx *c) {
 //   1M      1.49 / 1.72    4.54 / 1.91    13.2 / 2.16    21.0 / 2.99
 // the records, their sort and the group order cost 0.1 ms at 30k rows, 0.15 at 100k and 0.4 - 0.6 ms at 1M whatever max_dist
 // is, the band scan they replace grows steeply with it
+// round 3 (k_pgwalk16, positional filter at every size; profiles/r03_pg_matrix.txt), band / prefix groups:
+//   rows    d = 2          d = 3          d = 4          d = 5
+//   3k                     0.10 / 0.14    0.13 / 0.14    0.21 / 0.16
+//   5k                     0.12 / 0.14    0.18 / 0.16    0.29 / 0.19
+//   10k     0.10 / 0.14    0.17 / 0.16    0.28 / 0.17    0.52 / 0.22
+//   30k     0.12 / 0.21    0.25 / 0.19    0.44 / 0.27    0.93 / 0.29
+//   100k    0.18 / 0.37    0.40 / 0.32    0.77 / 0.34    1.52 / 0.42
+//   300k    0.47 / 0.49    1.21 / 0.49    1.97 / 0.52    3.11 / 0.60
+//   1M      1.46 / 1.28    (4.5) / 1.23                  (21) / 1.79
+//   3M      6.30 / <4.5
 static int64_t PG_MIN_ROWS(int max_dist) {
-    return max_dist >= 4 ? 25000 : (max_dist == 3 ? 150000 : ((int64_t)1 << 40));
+    return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : (max_dist == 3 ? 10000 : 400000));
 }
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist) {
@@ -698,7 +708,6 @@ static int ctx_size_pg(bfk_ctx *c, int recs, int key_bits, size_t *temp_bytes) {
         cap = 0; rc |= dev_realloc(&c->pg_keys, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_keys_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_keys_pm, &cap, total);
-        cap = 0; rc |= dev_realloc(&c->pg_ck, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_rows, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_rows_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_srec, &cap, total + SIG_PAD_ROWS);
@@ -878,10 +887,8 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
         // positional filter (k_pgplace): the composite {token key : slot} it bisects on needs 3 bits above the token's and must
         // stay below PG_NONE; BFK_PG_POS=0 walks whole groups (round 2's walk)
-        // (from 60k rows: below, the walk is a small part of the step and the order in which the positional walk queues its
-        // candidates costs the verify more than the walk saves — 30k rows, max-dist 5: 0.58 ms with it, 0.43 without; 100k
-        // rows: 0.49 / 0.55)
-        pl.pg_pb = (pl.pg_tb + 3 <= 31 && c->n >= 60000) ? 3 : 0;
+        // (at every size since the walk of labels-only steps is k_pgwalk16: 10k rows, max-dist 5: 0.35 ms without, 0.23 with)
+        pl.pg_pb = pl.pg_tb + 3 <= 31 ? 3 : 0;
         if (const char *e = getenv("BFK_PG_POS")) pl.pg_pb = atoi(e) && pl.pg_tb + 3 <= 31 ? 3 : 0;
         pl.pg_walk16 = 1;  // (labels-only steps; BFK_PG_WALK16=0: k_pgjoin for every step)
         if (const char *e = getenv("BFK_PG_WALK16")) pl.pg_walk16 = atoi(e) != 0;
@@ -898,7 +905,6 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.pg_temp_bytes = tb;
         pl.pg_srec = c->pg_srec;
         pl.pg_keys_pm = c->pg_keys_pm;
-        pl.pg_ck = c->pg_ck;
         pl.pg_recpos = c->pg_recpos;
         pl.pg_rowinfo = c->pg_rowinfo;
     }

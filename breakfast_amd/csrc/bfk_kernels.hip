@@ -1264,8 +1264,6 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     const int cnt = (int)min(pa.ctr->ncand[shard], (unsigned)pa.cand_cap_shard);
     if (j0 == 0 && l16 == 0 && cnt && pa.part_lo == 0) atomicAdd(&blk_cands, (unsigned)cnt);
     const int e_lo = (int)((long long)cnt * pa.part_lo / pa.part_den), e_hi = (int)((long long)cnt * pa.part_hi / pa.part_den);
-    int e_first = j0;
-    if (e_lo > j0) e_first = j0 + (e_lo - j0 + jstep - 1) / jstep * jstep;
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     unsigned n_edges = 0, n_conn = 0;  // wave-uniform
     // A group reads 16 CONSECUTIVE records (blocks of 16, jstep blocks apart), not 16 records jstep apart as k_verify does:
@@ -1273,36 +1271,59 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     // mostly pairs of one row, which are then looked up together — 8% more exact tests).  The first block of a group is taken
     // in pieces of 1, 2, 4, 8 records: in the first rounds nothing is connected yet and everything a wave looks at has to be
     // checked, so they are kept short until the first unions have gone in (a queue of a few records per lane would otherwise
-    // be one round).  (BFK_PF_DEBUG=512: k_verify's map, for comparison.)
-    const bool consec = (pa.dbg & 512) == 0;
-    int width = 1, lo = 0;
-    for (int e0 = consec ? j0 : e_first;;) {
-        const int e = consec ? e0 * 16 + l16 : e0 + l16 * jstep;
-        const bool have = consec ? (l16 >= lo && l16 < lo + width && e >= e_lo && e < e_hi) : (l16 < width && e < e_hi);
-        if (__builtin_amdgcn_ballot_w64(consec ? (long long)e0 * 16 < e_hi : have) == 0ull) break;
-        if (consec) {  // (the next piece of this block, or the next block)
-            lo += width;
-            width = min(16, width * 2);
-            if (lo >= 16) {
-                lo = 0;
-                width = 16;
-                e0 += jstep;
-            }
-        } else {
-            e0 += width * jstep;
-            width = min(16, width * 2);
+    // be one round).
+    // A round is a chain of dependent loads (record -> parents -> roots -> rows -> unions) and the kernel runs at 4 waves per
+    // SIMD (LDS): the records are asked for one round ahead.  (The parents too, one round ahead: slower — 0.63 -> 0.65 ms at 1M
+    // rows, max_dist 5, 0.19 -> 0.30 at 30k — a parent that is a round old says "not connected" where "connected" is true by
+    // now, and the exact tests that costs, +16% .. +90%, outweigh the round trip.)
+    int blk = j0, width = 1, lo = 0;
+    struct Slot {
+        int4 rec;
+        int2 kk;
+        int p0, p1;
+        bool have, more;
+    };
+    auto next_slot = [&]() {  // the next piece of the group's records; its queue record is requested
+        Slot sl;
+        const int e = blk * 16 + l16;
+        sl.more = (long long)blk * 16 < e_hi;
+        sl.have = l16 >= lo && l16 < lo + width && e >= e_lo && e < e_hi;
+        lo += width;
+        width = min(16, width * 2);
+        if (lo >= 16) {
+            lo = 0;
+            width = 16;
+            blk += jstep;
         }
-        int4 rec = make_int4(0, 0, 0, 0);
-        int2 kk = make_int2(0, 0);
+        sl.rec = make_int4(0, 0, 0, 0);
+        sl.kk = make_int2(0, 0);
+        sl.p0 = sl.p1 = 0;
+        if (sl.have) {
+            sl.rec = pa.cand[base + e];
+            sl.kk = pa.candk[base + e];
+        }
+        return sl;
+    };
+    auto ask_parents = [&](Slot &sl) {
+        // (pairs longer than a group table are k_verify_long's, which looks their roots up itself)
+        sl.have = sl.have && sl.kk.x + sl.kk.y <= VERIFY_MAX_TOKENS;
+        if (sl.have) {
+            sl.p0 = ld_agent(pa.parent + sl.rec.x);
+            sl.p1 = ld_agent(pa.parent + sl.rec.y);
+        }
+    };
+    Slot sA = next_slot();
+    for (;;) {
+        Slot cur = sA;
+        if (__builtin_amdgcn_ballot_w64(cur.more) == 0ull) break;
+        sA = next_slot();
+        ask_parents(cur);
+        int4 rec = cur.rec;
+        const int2 kk = cur.kk;
         bool todo = false, conn = false;
-        if (have) {
-            rec = pa.cand[base + e];
-            kk = pa.candk[base + e];
-            if (kk.x + kk.y <= VERIFY_MAX_TOKENS) {  // (longer pairs: k_verify_long, which looks their roots up itself)
-                const int p0 = ld_agent(pa.parent + rec.x), p1 = ld_agent(pa.parent + rec.y);
-                todo = p0 != p1 && uf_find_from(pa.parent, rec.x, p0) != uf_find_from(pa.parent, rec.y, p1);
-                conn = !todo;
-            }
+        if (cur.have) {
+            todo = cur.p0 != cur.p1 && uf_find_from(pa.parent, rec.x, cur.p0) != uf_find_from(pa.parent, rec.y, cur.p1);
+            conn = !todo;
         }
         const unsigned long long tm = __builtin_amdgcn_ballot_w64(todo);
         n_conn += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(conn));
@@ -1960,88 +1981,107 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
                                                 uint32_t *__restrict__ keys_pm, int *__restrict__ rows_pm, int pm, int kcap,
                                                 int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr) {
-    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+    // A group takes PGK_ROWS consecutive rows and has the token loads of all of them in flight, then the count look-ups of all
+    // of them: with one row per group a wave was three dependent loads and gone (190 us at 1M rows for 300 MB of traffic).
+    constexpr int R = PGK_ROWS;
+    const int r0 = (blockIdx.x * 16 + (threadIdx.x >> 4)) * R, l16 = threadIdx.x & 15;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctr->n_work = (unsigned)((n + 63) >> 6);  // work items of k_pgjoin: blocks of 64 rows (k_cells left its tile count here)
         ctr->pairs_filtered = 0ull;
     }
     // (no early return: the groups of a wave run the DPP reductions together)
-    const bool live = r < n;
-    const int b = live ? indptr[r] : 0, e = live ? indptr[r + 1] : 0;
+    int b[R], e[R], c0[R];
+    uint32_t sel[R], s2all[R], s2hi[R];  // lane i < pre: the i-th element so far; the row's second-level signature (XOR parity
+                                         // of one of 64 bits per token, as k_sig's)
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const bool live = r0 + q < n;
+        b[q] = live ? indptr[r0 + q] : 0;
+        e[q] = live ? indptr[r0 + q + 1] : 0;
+        c0[q] = b[q];
+        sel[q] = 0xFFFFFFFFu;
+        s2all[q] = s2hi[q] = 0u;
+    }
     const uint32_t cmax = (1u << (32 - tb)) - 1u, tinv = (1u << tb) - 2u;
     const int pre = recs - 1;  // = max_dist + 1
-    uint32_t sel = 0xFFFFFFFFu;  // lane i < pre: the i-th element so far
-    uint32_t s2all = 0u, s2hi = 0u;  // the row's second-level signature (XOR parity of one of 64 bits per token, as k_sig's)
-    for (int c0 = b;; c0 += 64) {
-        if (__builtin_amdgcn_ballot_w64(c0 < e) == 0ull) break;  // wave-uniform: until every group of the wave is through its row
-        uint32_t v[4];
+    for (;;) {
+        bool any = false;
 #pragma unroll
-        for (int st = 0; st < 4; st++) {
-            const int j = c0 + st * 16 + l16;
-            v[st] = 0xFFFFFFFFu;
-            if (j < e) {
-                const uint32_t x = indices[j];
-                const uint32_t t = x & 0x7FFFFFFFu;
-                v[st] = (min(cnt[pg_cnt_slot(t)], cmax) << tb) | (tinv - t);
-                const uint32_t h2 = sig_h2(sig_h1(x));
-                const uint32_t bit2 = 1u << ((h2 >> 24) & 31);
-                s2all ^= bit2;
-                s2hi ^= (uint32_t)((int)(h2 << 2) >> 31) & bit2;  // bit 29 selects the word
+        for (int q = 0; q < R; q++) any = any || c0[q] < e[q];
+        if (__builtin_amdgcn_ballot_w64(any) == 0ull) break;  // wave-uniform: until every group of the wave is through its rows
+        uint32_t x[R][4], v[R][4];
+#pragma unroll
+        for (int q = 0; q < R; q++)
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const int j = c0[q] + st * 16 + l16;
+                x[q][st] = j < e[q] ? indices[j] : 0xFFFFFFFFu;
             }
-        }
-        uint32_t carry = sel, nsel = 0xFFFFFFFFu;
-        for (int i = 0; i < pre; i++) {
-            const uint32_t m = row16_allmin_u(min(min(min(v[0], v[1]), min(v[2], v[3])), carry));
 #pragma unroll
-            for (int st = 0; st < 4; st++) v[st] = v[st] == m ? 0xFFFFFFFFu : v[st];  // every copy of the token leaves
-            carry = carry == m ? 0xFFFFFFFFu : carry;
-            if (l16 == i) nsel = m;
+        for (int q = 0; q < R; q++)
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const bool in = c0[q] + st * 16 + l16 < e[q];
+                v[q][st] = in ? cnt[pg_cnt_slot(x[q][st] & 0x7FFFFFFFu)] : 0u;
+            }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const bool in = c0[q] + st * 16 + l16 < e[q];
+                const uint32_t t = x[q][st] & 0x7FFFFFFFu;
+                v[q][st] = in ? (min(v[q][st], cmax) << tb) | (tinv - t) : 0xFFFFFFFFu;
+                if (in) {
+                    const uint32_t h2 = sig_h2(sig_h1(x[q][st]));
+                    const uint32_t bit2 = 1u << ((h2 >> 24) & 31);
+                    s2all[q] ^= bit2;
+                    s2hi[q] ^= (uint32_t)((int)(h2 << 2) >> 31) & bit2;  // bit 29 selects the word
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(c0[q] < e[q]) == 0ull) continue;  // (wave-uniform: nobody has a chunk of row q left)
+            uint32_t carry = sel[q], nsel = 0xFFFFFFFFu;
+            for (int i = 0; i < pre; i++) {
+                const uint32_t m = row16_allmin_u(min(min(min(v[q][0], v[q][1]), min(v[q][2], v[q][3])), carry));
+#pragma unroll
+                for (int st = 0; st < 4; st++) v[q][st] = v[q][st] == m ? 0xFFFFFFFFu : v[q][st];  // every copy of the token leaves
+                carry = carry == m ? 0xFFFFFFFFu : carry;
+                if (l16 == i) nsel = m;
+            }
+            sel[q] = nsel;
+            c0[q] += 64;
         }
-        sel = nsel;
     }
-    if (!live) return;
-    // {length, second-level signature, first token} of the row in one 16-byte record: what k_pgplace gathers per position and
-    // k_pgjoin per row
-    s2all = row16_allxor(s2all);
-    s2hi = row16_allxor(s2hi);
-    if (l16 == 15) {
-        rowinfo[r] = make_int4(e - b, (int)(s2all ^ s2hi), (int)s2hi, b);
-        parent[r] = r;
-        if (e - b < 0 || e - b > kcap) atomicOr(&ctr->err_rows, ERR_ROWLEN);  // the CSR changed after the bind
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int r = r0 + q;
+        // {length, second-level signature, offset} of the row in one 16-byte record: what k_pgcomp gathers per position and
+        // the walk per row
+        const uint32_t sa = row16_allxor(s2all[q]), sh = row16_allxor(s2hi[q]);
+        if (r >= n) continue;
+        const int len = e[q] - b[q];
+        if (l16 == 15) {
+            rowinfo[r] = make_int4(len, (int)(sa ^ sh), (int)sh, b[q]);
+            parent[r] = r;
+            if (len < 0 || len > kcap) atomicOr(&ctr->err_rows, ERR_ROWLEN);  // the CSR changed after the bind
+        }
+        // The records go out twice: row-major (keys[row][slot]: what k_pgjoin reads row by row) and POSITION-major
+        // (keys_pm[slot][row] with their (row, slot) values: the sort's input).  The sort is stable, so the group of a token comes
+        // out as its records of slot 0 (rows ascending), then slot 1, ... — the order the positional filter of k_pgplace needs —
+        // without a single key bit spent on the position.
+        if (l16 < recs) {
+            uint32_t key;
+            if (l16 < pre) key = sel[q] != 0xFFFFFFFFu ? tinv - (sel[q] & ((1u << tb) - 1u)) + 1u : PG_NONE;
+            // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
+            // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
+            else key = len <= 2 * max_dist ? 0u : PG_NONE;
+            keys[(size_t)r * recs + l16] = key;
+            // (pm = 0 — the positional filter is off: token ids that leave no room for the composite key — keeps the records in
+            // row order, so that a group comes out with its rows ascending as the whole-group walk needs it)
+            const size_t o = pm ? (size_t)l16 * n + r : (size_t)r * recs + l16;
+            keys_pm[o] = key;
+            rows_pm[o] = r * recs + l16;  // the sort carries (row, slot)
+        }
     }
-    // The records go out twice: row-major (keys[row][slot]: what k_pgjoin reads row by row) and POSITION-major
-    // (keys_pm[slot][row] with their (row, slot) values: the sort's input).  The sort is stable, so the group of a token comes
-    // out as its records of slot 0 (rows ascending), then slot 1, ... — the order the positional filter of k_pgplace needs —
-    // without a single key bit spent on the position.
-    if (l16 < recs) {
-        uint32_t key;
-        if (l16 < pre) key = sel != 0xFFFFFFFFu ? tinv - (sel & ((1u << tb) - 1u)) + 1u : PG_NONE;
-        // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
-        // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
-        else key = (e - b) <= 2 * max_dist ? 0u : PG_NONE;
-        keys[(size_t)r * recs + l16] = key;
-        // (pm = 0 — the positional filter is off: token ids that leave no room for the composite key — keeps the records in
-        // row order, so that a group comes out with its rows ascending as the whole-group walk needs it)
-        const size_t o = pm ? (size_t)l16 * n + r : (size_t)r * recs + l16;
-        keys_pm[o] = key;
-        rows_pm[o] = r * recs + l16;  // the sort carries (row, slot)
-    }
-}
-
-// after the sort: the composite {token key : slot} of every position (what the positional filter bisects on; a SHORT record
-// and a PG_NONE stay what they are), and the position's {row, length, second-level signature} in group order (k_pgjoin reads the
-// members of a group as one coalesced stream)
-__global__ __launch_bounds__(256) void k_pgcomp(const uint32_t *__restrict__ keys_s, const int *__restrict__ vals_s, int total, int recs,
-                                                int pb, const int4 *__restrict__ rowinfo, uint32_t *__restrict__ ck,
-                                                int4 *__restrict__ srec) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
-    const uint32_t key = keys_s[p];
-    const int v = vals_s[p];
-    const int row = v / recs;
-    const int4 ri = rowinfo[row];
-    srec[p] = make_int4(row, ri.x, ri.y, ri.z);
-    ck[p] = (key == PG_NONE || key == 0u) ? key : ((key << pb) | (pb ? (uint32_t)(v - row * recs) : 0u));
 }
 
 // one thread per position of the sorted records: for every record of a row where it went and how many positions behind it
@@ -2058,39 +2098,43 @@ __global__ __launch_bounds__(256) void k_pgcomp(const uint32_t *__restrict__ key
 // Every pair within d is still met at t* by exactly one row; a pair can now also be met a second time from the other row
 // at a later shared token, which a labels-only step lets through (the verify drops it as connected) and an exact-edges step
 // decides by the records test for every candidate (k_pgjoin).
-__global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s /*composite: k_pgcomp*/, const int *__restrict__ vals_s,
-                                                 int total, int2 *__restrict__ recpos, Counters *ctr, int pb, int max_dist) {
+__global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s /*composite {key : slot}: the sort's last pass*/,
+                                                 const int *__restrict__ vals_s, int total, int recs, const int4 *__restrict__ rowinfo,
+                                                 int4 *__restrict__ srec, int2 *__restrict__ recpos, Counters *ctr, int pb, int max_dist) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const uint32_t key = keys_s[p];
     const int v = vals_s[p];
-    if (key == PG_NONE) {  // no such record: nothing behind it (k_pgwalk16 reads the counts without looking at the keys)
-        recpos[v] = make_int2(p, 0);
-        return;
-    }
-    // the last key this record walks to: its own (SHORT record, or no position bits), or {token : d - i}
-    uint32_t target = key;
-    bool walks = true;
-    if (pb && key != 0u) {
-        const int i = (int)(key & ((1u << pb) - 1u));
-        walks = max_dist - i >= i;
-        target = (key & ~((1u << pb) - 1u)) | (uint32_t)max(max_dist - i, 0);
-    }
+    // the position's {row, length, second-level signature} in group order: the walk reads the members of a group as one
+    // coalesced stream (the gather is in flight while the record looks for the end of its walk)
+    const int row = v / recs;
+    const int4 ri = rowinfo[row];
     int behind = 0;
-    if (walks) {  // first position whose key is above the target: gallop from p, then bisect (keys_s[p] <= target)
-        int lo = p, step = 1;
-        while (lo + step < total && keys_s[lo + step] <= target) {
-            lo += step;
-            step <<= 1;
+    if (key != PG_NONE) {  // ("no such record": nothing behind it — the walk reads the counts without looking at the keys)
+        // the last key this record walks to: its own (SHORT record, or no position bits), or {token : d - i}
+        uint32_t target = key;
+        bool walks = true;
+        if (pb && key != 0u) {
+            const int i = (int)(key & ((1u << pb) - 1u));
+            walks = max_dist - i >= i;
+            target = (key & ~((1u << pb) - 1u)) | (uint32_t)max(max_dist - i, 0);
         }
-        int hi = min(total, lo + step);
-        while (hi - lo > 1) {
-            const int mid = lo + ((hi - lo) >> 1);
-            if (keys_s[mid] <= target) lo = mid;
-            else hi = mid;
+        if (walks) {  // first position whose key is above the target: gallop from p, then bisect (keys_s[p] <= target)
+            int lo = p, step = 1;
+            while (lo + step < total && keys_s[lo + step] <= target) {
+                lo += step;
+                step <<= 1;
+            }
+            int hi = min(total, lo + step);
+            while (hi - lo > 1) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (keys_s[mid] <= target) lo = mid;
+                else hi = mid;
+            }
+            behind = lo - p;
         }
-        behind = lo - p;
     }
+    srec[p] = make_int4(row, ri.x, ri.y, ri.z);
     recpos[v] = make_int2(p, behind);
     // every PG_EST_STRIDE-th position reports what k_pgjoin will walk from it, so that the walk can be called off when the
     // groups are too big
@@ -2790,10 +2834,11 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 
     if (pl.pg) {  // prefix-group path: one wave per row walks the row's groups (work items = blocks of 64 rows)
         const int items = std::max(0, std::min(t_end, (n + 63) / 64) - t_begin);
-        // the waves stride over the rows; blocks per CU: large inputs want many (the rows' walks differ in length)
-        // (measured, k_pgjoin at 8 / 16 / 32 / 64 / 256 blocks per CU: 1M rows 3.26 / 2.80 / 2.60 / 2.46 / 2.38 ms, 100k rows 0.56 / 0.52 / 0.51 / 0.51 / 0.55)
+        // the waves stride over the rows; blocks per CU, k_pgjoin at 16 / 32 / 64 / 128 / 256 (round 3: one row per wave — 62 500
+        // blocks at 1M rows — costs more to dispatch than its balance gives): 1M rows, max-dist 2: 0.45 / 0.44 / 0.45 / 0.58 / 0.86 ms;
+        // 300k rows: . / 0.18 / 0.24 / . / 0.80; exact-edges step at max-dist 5, 1M rows: . / 0.95 / 0.89 / . / 1.08
         static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
-        const int per_cu = per_cu_env ? per_cu_env : (n >= 400000 ? 256 : 64);
+        const int per_cu = per_cu_env ? per_cu_env : (pl.d <= 2 ? 32 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
         if (pa.skip_connected && pl.pg_walk16) {  // labels-only steps: 16 lanes per row
             // (a group takes rows in turn: 32 blocks per CU balance as well as one row per group did, and 62 500 blocks cost 0.5 ms to dispatch)
@@ -2889,17 +2934,16 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         const int sampled = (n + stride - 1) / stride;
         hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pgkeys, dim3((n + 15) / 16), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
+        hipLaunchKernelGGL(k_pgkeys, dim3((n + 16 * PGK_ROWS - 1) / (16 * PGK_ROWS)), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
                            pl.pg_keys, pl.pg_keys_pm, pl.pg_rows, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys_pm, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st))
+        // (the sort's last pass leaves the composite {key : slot} the positional filter bisects on)
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys_pm, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st,
+                                 pl.pg_pb ? pl.pg_recs : 0, pl.pg_pb))
             return e;
-        hipLaunchKernelGGL(k_pgcomp, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_pb,
-                           pl.pg_rowinfo, pl.pg_ck, pl.pg_srec);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_ck, pl.pg_rows_s, total, pl.pg_recpos, pl.ctr,
-                           pl.pg_pb, pl.d);
+        hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
+                           pl.pg_srec, pl.pg_recpos, pl.ctr, pl.pg_pb, pl.d);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;

@@ -77,7 +77,7 @@ template <int RB>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t n,
                                                            int shift, uint32_t n_blk, const uint32_t *__restrict__ hist,
                                                            const uint32_t *__restrict__ tot, uint32_t *__restrict__ keys_out,
-                                                           int *__restrict__ vals_out) {
+                                                           int *__restrict__ vals_out, int comp_recs, int comp_pb) {
     constexpr int R = 1 << RB;
     __shared__ uint32_t s_run[R];             // first OUTPUT position of the block's records of every digit
     __shared__ uint32_t s_loc[R];             // first position of the digit inside the block's (digit-ordered) tile
@@ -184,25 +184,29 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
         const uint32_t k = s_key[e];
         const uint32_t dg = (k >> shift) & (R - 1);
         const uint32_t o = s_run[dg] + (e - s_loc[dg]);
-        keys_out[o] = k;
-        vals_out[o] = s_val[e];
+        const int v = s_val[e];
+        // (the last pass of the prefix-group sort: the key leaves as the composite {key : slot} the positional filter bisects
+        // on — slot = value % recs; the SHORT key 0 and "no record" stay what they are)
+        keys_out[o] = (comp_recs > 0 && k != 0u && k != 0xFFFFFFFFu) ? (k << comp_pb) | (uint32_t)(v % comp_recs) : k;
+        vals_out[o] = v;
     }
 }
 
 template <int RB>
 int rs_pass(const uint32_t *kin, const int *vin, uint32_t *kout, int *vout, uint32_t n, int shift, uint32_t n_blk, uint32_t *hist,
-            uint32_t *tot, hipStream_t st) {
+            uint32_t *tot, hipStream_t st, int comp_recs, int comp_pb) {
     hipLaunchKernelGGL(k_rs_count<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, n, shift, n_blk, hist);
     hipLaunchKernelGGL(k_rs_rowscan, dim3(1 << RB), dim3(64), 0, st, hist, n_blk, tot);
-    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, vin, n, shift, n_blk, hist, tot, kout, vout);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, vin, n, shift, n_blk, hist, tot, kout, vout, comp_recs, comp_pb);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
 // temp == nullptr: only *temp_bytes is set.  Stable sort by key bits [0, bits); keys_in / rows_in stay intact.
+// comp_recs > 0: keys_out holds (key << comp_pb) | (row value % comp_recs) for every key but 0 and 0xFFFFFFFF.
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
-                 int *rows_out, size_t n, int bits, hipStream_t st) {
+                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs, int comp_pb) {
     bits = bits < 1 ? 1 : (bits > 32 ? 32 : bits);
     const int passes = (bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
     const int rb = (bits + passes - 1) / passes;  // 1 .. 11
@@ -229,13 +233,14 @@ int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         uint32_t *kout = to_out ? keys_out : tk;
         int *vout = to_out ? rows_out : tv;
+        const bool last = p == passes - 1;
         int e = 0;
         switch (rb) {
             case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8:
-                e = rs_pass<8>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st); break;
-            case 9: e = rs_pass<9>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st); break;
-            case 10: e = rs_pass<10>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st); break;
-            default: e = rs_pass<11>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st); break;
+                e = rs_pass<8>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
+            case 9: e = rs_pass<9>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
+            case 10: e = rs_pass<10>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
+            default: e = rs_pass<11>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
         }
         if (e) return e;
         kin = kout;

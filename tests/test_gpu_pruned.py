@@ -60,15 +60,16 @@ def test_fuzz_vs_oracle_with_pruning(seed, generator, monkeypatch):
     assert dropped > 0
 
 
-@pytest.mark.parametrize("d,indels", [(3, False), (4, True), (5, True)])
-def test_100k_rows_pruned_equals_exact(d, indels):
+@pytest.mark.parametrize("d,indels,path", [(3, False, "allpairs"), (3, False, "auto"), (4, True, "auto"), (5, True, "auto")])
+def test_100k_rows_pruned_equals_exact(d, indels, path):
     """both kernels on one resident context, alternating (the counters of one mode must not leak into the other); the
-    prefix groups at max-dist 4, 5, the band kernels (two-phase verify) at 3"""
+    prefix groups (the default at this size from max-dist 3), the band kernels (two-phase verify) at 3"""
     rows = generate_profiles(100_000, p_del=0.05, p_ins=0.01) if indels else generate_profiles(100_000)
     uf = list(dict.fromkeys(rows))
     indptr, indices, _ = _lib.build_csr(uf, " ")
     n = len(uf)
     ctx = _lib.Context(0)
+    ctx.set_candidate_path(path)
     ctx.upload_csr(indptr, indices)
     d_out = ctx.alloc(4 * n)
     res = {}
@@ -91,7 +92,7 @@ def test_100k_rows_pruned_equals_exact(d, indels):
     assert sp["n_candidates"] >= sx["n_candidates"] if sp["path"] == 2 else sp["n_candidates"] == sx["n_candidates"]
     assert sp["n_edges"] <= sx["n_edges"]
     _invariants(sp, lp)
-    assert sp["path"] == (2 if d >= 4 else 0)
+    assert sp["path"] == (0 if path == "allpairs" else 2)
 
 
 def test_pruned_sharded_runs_merge_to_the_one_shard_labels():
