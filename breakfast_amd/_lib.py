@@ -542,7 +542,11 @@ class Context:
         _check(self.lib.bfk_ctx_merge_labels(self.h, C.c_void_p(d_gathered), int(n_parts), C.c_void_p(d_labels),
                                              C.c_void_p(d_changed or 0)))
 
-    def sync(self) -> dict:
+    def sync(self, want_stats: bool = True) -> dict:
+        """want_stats=False: wait for the stream only (the statistics cost host work: band pair counts from the row lengths)"""
+        if not want_stats:
+            _check(self.lib.bfk_ctx_sync(self.h, None))
+            return {}
         st = Stats()
         _check(self.lib.bfk_ctx_sync(self.h, C.byref(st)))
         return st.as_dict()

@@ -664,19 +664,23 @@ static int ctx_size_join(bfk_ctx *c) {
 //   10k     0.10 / 0.14    0.17 / 0.16    0.28 / 0.17    0.52 / 0.22
 //   30k     0.12 / 0.21    0.25 / 0.19    0.44 / 0.27    0.93 / 0.29
 //   100k    0.18 / 0.37    0.40 / 0.32    0.77 / 0.34    1.52 / 0.42
-//   300k    0.47 / 0.49    1.21 / 0.49    1.97 / 0.52    3.11 / 0.60
-//   1M      1.46 / 1.28    (4.5) / 1.23                  (21) / 1.79
+//   200k    0.32 / 0.33
+//   300k    0.47 / 0.41    1.21 / 0.49    1.97 / 0.52    3.11 / 0.60
+//   1M      1.46 / 1.09    (4.5) / 1.23                  (21) / 1.79
 //   3M      6.30 / <4.5
 static int64_t PG_MIN_ROWS(int max_dist) {
-    return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : (max_dist == 3 ? 10000 : 400000));
+    return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : (max_dist == 3 ? 10000 : 250000));
 }
 
-static bool pg_wanted(const bfk_ctx *c, int max_dist) {
+static bool pg_wanted(const bfk_ctx *c, int max_dist, int n_shards) {
     if (max_dist < 2 || max_dist > PG_MAX_DIST || c->n < 2 || c->nnz <= 0 || c->pg_off) return false;
     if ((int64_t)c->n * (max_dist + 2) > (int64_t)INT32_MAX - 1024) return false;
     if (c->path_mode) return c->path_mode == 3;
     if (const char *e = getenv("BFK_PG")) return atoi(e) != 0;
     if (c->n_short > 4096) return false;
+    // a shard of a max-dist 2 step: the band kernels — their pair kernel is the step and shards, the groups' records and sort
+    // are replicated on every rank (one-device rehearsal, 1M rows, 8 ranks: 0.50 ms band / 1.05 groups)
+    if (n_shards > 1 && max_dist == 2) return false;
     return c->n >= PG_MIN_ROWS(max_dist);
 }
 
@@ -795,6 +799,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     if (const char *e = getenv("BFK_VERIFY_PHASE2")) pl.verify_phase2_union = std::max(0, std::min(2, atoi(e)));
     pl.tile_cap = (int)std::min<int64_t>(c->tile_cap, INT32_MAX);
     pl.pf_blocks = c->n_cus * 256;  // upper bound of the pair kernel's grid (it strides over the tile entries)
+    if (const char *e = getenv("BFK_PF_BLOCKS")) pl.pf_blocks = c->n_cus * std::max(1, atoi(e));
     pl.pf_waves = (c->rows_per_lane == 1 && c->n < 400000) ? 4 : 2;
     if (const char *e = getenv("BFK_PF_WAVES")) pl.pf_waves = atoi(e) == 4 && c->rows_per_lane == 1 ? 4 : 2;
     // grid of the pair kernel: the tile count of the previous step on this CSR (+12%), or a guess before the
@@ -883,7 +888,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.dbg = getenv("BFK_JOIN_DEBUG") ? atoi(getenv("BFK_JOIN_DEBUG")) : 0;
     }
     pl.pg = 0;
-    if (!pl.join && pg_wanted(c, max_dist)) {
+    if (!pl.join && pg_wanted(c, max_dist, n_shards)) {
         if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
         // positional filter (k_pgplace): the composite {token key : slot} it bisects on needs 3 bits above the token's and must
         // stay below PG_NONE; BFK_PG_POS=0 walks whole groups (round 2's walk)
@@ -1354,12 +1359,14 @@ static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t 
 // groups, 1.9), prefix groups: the verify of a shard gets SLOWER the fewer edges its forest sees.  So: several devices at
 // max-dist 2 from 300k rows and at max-dist 1 from 2M; everything else runs on one device whatever n_gpus says
 // (bfk_stats.n_gpus_used tells).  BFK_MULTI_FORCE=1 (and the one-device rehearsal mode of the tests) shards regardless.
-static bool multi_worth(int64_t n_rows, int32_t max_dist) {
+static bool multi_worth(int64_t n_rows, int32_t max_dist, int32_t n_gpus) {
     if (getenv("BFK_MULTI_FORCE") && atoi(getenv("BFK_MULTI_FORCE")) != 0) return true;
     if (getenv("BFK_MULTI_ONE_DEVICE") && atoi(getenv("BFK_MULTI_ONE_DEVICE")) != 0) return true;
     if (max_dist <= 1) return n_rows >= 2000000;
     if (max_dist == 2) return n_rows >= 300000;
-    return false;
+    // dense graphs (prefix groups): records and sort are replicated, walk and verify shard — 1M rows, max_dist 5, one-device
+    // rehearsal: 1.81 ms on one rank, 1.46 / 1.27 / 1.18 ms + exchange + merge (~0.3 ms) on 2 / 4 / 8
+    return n_rows >= 500000 && n_gpus >= 4;
 }
 
 extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
@@ -1371,7 +1378,7 @@ extern "C" int bfk_cluster_csr(const int32_t *indptr, const int32_t *indices, in
         const bool one = getenv("BFK_MULTI_ONE_DEVICE") && atoi(getenv("BFK_MULTI_ONE_DEVICE")) != 0;
         const int ndev = bfk_device_count();
         if (!one && n_gpus > ndev) return fail(BFK_ENODEV, "bfk_cluster_csr: n_gpus = " + std::to_string(n_gpus) + " but " + std::to_string(ndev) + " gfx950 device(s) visible");
-        if (multi_worth(n_rows, max_dist)) return cluster_multi(indptr, indices, n_rows, max_dist, n_gpus, labels_out, stats_out);
+        if (multi_worth(n_rows, max_dist, n_gpus)) return cluster_multi(indptr, indices, n_rows, max_dist, n_gpus, labels_out, stats_out);
     }
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;

@@ -2440,16 +2440,18 @@ __device__ __forceinline__ int row16_incl_scan(int x) {  // inclusive prefix sum
     return x;
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
-                                                  const int4 *__restrict__ rowinfo, int n, int recs, int shard0, int nshards,
-                                                  int t_begin, int t_end, PairArgs pa) {
+                                                  const int4 *__restrict__ rowinfo, const uint32_t *__restrict__ keys, int n, int recs,
+                                                  int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
     constexpr int WAVES = 4, GSET = 64, U = 4;
     if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
         if (blockIdx.x == 0 && threadIdx.x == 0) pa.ctr->pg_fail = 1;  // (groups too big to pay: the host redoes the step on the band kernels)
         return;
     }
     __shared__ int s_end[WAVES][4][16], s_base[WAVES][4][16];  // per group: inclusive end of every step in the row's list, base position
-    __shared__ int s_set[WAVES][4][GSET];                       // per group: members of this row that were queued
+    __shared__ int s_set[WAVES][4][GSET];                       // per group: members of this row that were queued (labels-only steps)
+    __shared__ uint32_t s_key[WAVES][4][16];                    // per group: the row's record keys, step by step (exact steps)
     __shared__ int4 s_q[WAVES][128];                            // pairs {A, B, offset of A, -1} waiting for their queue slots
     __shared__ int2 s_qk[WAVES][128];                           // ... and {k_A, k_B}
     __shared__ unsigned long long s_vis[WAVES];
@@ -2457,6 +2459,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     int *g_end = s_end[wave][grp], *g_base = s_base[wave][grp], *g_set = s_set[wave][grp];
+    uint32_t *g_key = s_key[wave][grp];
     int4 *sq = s_q[wave];
     int2 *sqk = s_qk[wave];
 #pragma unroll
@@ -2478,6 +2481,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
         if (lane < cnt) {
             e = sq[lane];
             ek = sqk[lane];
+            if (EXACT) e.w = pa.indptr[e.y];  // (k_verify reads both offsets from the record)
         }
         if (64 + lane < nq) {
             mv = sq[64 + lane];
@@ -2505,20 +2509,30 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         nq -= cnt;
     };
-    const int r_begin = t_begin * 64, r_end = min(n, (int)min((long long)t_end * 64, (long long)n));
+    // The rank's rows: the 64-row blocks b with b % nshards == shard0 inside [t_begin, t_end), numbered through — place v is
+    // row 64 * (b0 + (v / 64) * nshards) + v % 64 — so that the rank's share is spread over all groups of the grid (a group
+    // that skipped foreign rows in steps of the stride found either all of its rows or none: an 8th of the groups did the
+    // work of the rank, each as long as before)
+    const int blk_hi = (int)min((long long)t_end, ((long long)n + 63) >> 6);
+    const int b0 = t_begin + ((shard0 - t_begin % nshards) % nshards + nshards) % nshards;
+    const int v_end = b0 < blk_hi ? (blk_hi - b0 + nshards - 1) / nshards * 64 : 0;
     const int stride = (int)gridDim.x * WAVES * 4;
-    auto owned_from = [&](int A) {  // the first row at or behind A (in steps of the stride) that is this rank's
-        while (nshards > 1 && A < r_end && ((A >> 6) % nshards) != shard0) A += stride;
-        return A;
+    auto row_of = [&](int v) { return ((b0 + (v >> 6) * nshards) << 6) | (v & 63); };
+    auto place_from = [&](int v) {  // (only the input's last block has places without a row)
+        while (v < v_end && row_of(v) >= n) v += stride;
+        return v;
     };
-    int A = owned_from(r_begin + (blockIdx.x * WAVES + wave) * 4 + grp);  // (group-uniform)
-    bool active = A < r_end, fresh_row = active;
+    int at = place_from((blockIdx.x * WAVES + wave) * 4 + grp);  // (group-uniform)
+    int A = at < v_end ? row_of(at) : 0;
+    bool active = at < v_end, fresh_row = active;
     // the head of the group's next row {its records' positions and counts, length, signature, offset} is asked for one row ahead
     const int slot = l16 == 0 ? recs - 1 : l16 - 1;
     int2 h_rp = make_int2(0, 0);
     int4 h_ri = make_int4(0, 0, 0, 0);
+    uint32_t h_key = PG_NONE;
     if (active) {
         if (l16 < recs) h_rp = recpos[(size_t)A * recs + slot];
+        if (EXACT && l16 < recs) h_key = keys[(size_t)A * recs + slot];
         h_ri = rowinfo[A];
     }
     int T = 0, f = 0, st = 0, len_a = 0, off_a = 0, n_in = 0;
@@ -2529,10 +2543,14 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
             // step i = slot i - 1); lane l of the group holds step l
             const int2 rp = h_rp;
             const int4 ri = h_ri;
-            const int nx = owned_from(A + stride);
+            if (EXACT) g_key[l16] = h_key;
+            const int nat = place_from(at + stride);
             h_rp = make_int2(0, 0);
-            if (nx < r_end) {
+            h_key = PG_NONE;
+            if (nat < v_end) {
+                const int nx = row_of(nat);
                 if (l16 < recs) h_rp = recpos[(size_t)nx * recs + slot];
+                if (EXACT && l16 < recs) h_key = keys[(size_t)nx * recs + slot];
                 h_ri = rowinfo[nx];
             }
             const int incl = row16_incl_scan(rp.y);
@@ -2552,6 +2570,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
         if (active) T = g_end[15];  // (steps at and beyond recs repeat the total)
         int4 rec[U];
         bool have[U];
+        int step_u[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int fu = f + 16 * u;
@@ -2561,6 +2580,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
                 while (fu >= g_end[st]) st++;  // (fu < T = end[15]: stops at 15 at the latest)
                 rec[u] = srec[g_base[st] + fu];
             }
+            step_u[u] = st;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -2568,10 +2588,28 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
             if (pa.dbg & 64) pass = have[u] && rec[u].x == -7;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
             visits += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have[u]));
             if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-            // met in an earlier step of this row?  (the set takes entries while it is less than half full; a member it does
-            // not know is queued)
             bool ins = false;
-            if (pass && n_in < GSET / 2 && !(pa.dbg & 256)) {
+            if (EXACT) {
+                // exact-edges steps (and edge capture) count a pair once: where the FIRST element its rows share is met — one of
+                // A's earlier elements among B's records means this is a later one (seen from whichever row: both prefixes
+                // are in the global order)
+                if (pass) {
+                    const uint32_t *kb = keys + (size_t)rec[u].x * recs;
+                    uint32_t gb[PG_MAX_DIST + 2];
+#pragma unroll
+                    for (int j = 0; j < PG_MAX_DIST + 2; j++) gb[j] = j < recs ? kb[j] : PG_NONE;
+                    bool dup = false;
+                    for (int e2 = 0; e2 < step_u[u]; e2++) {
+                        const uint32_t y = g_key[e2];
+                        if (y == PG_NONE) continue;
+#pragma unroll
+                        for (int j = 0; j < PG_MAX_DIST + 2; j++) dup = dup || gb[j] == y;
+                    }
+                    pass = !dup;
+                }
+            } else if (pass && n_in < GSET / 2 && !(pa.dbg & 256)) {
+                // met in an earlier step of this row?  (the set takes entries while it is less than half full; a member it
+                // does not know is queued)
                 const int B = rec[u].x;
                 uint32_t h = ((uint32_t)B * 0x9E3779B1u) >> 26;  // GSET = 64 slots
                 for (;;) {
@@ -2607,8 +2645,9 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
                 for (int j = 0; j < GSET / 16; j++) g_set[l16 + 16 * j] = -1;
                 n_in = 0;
             }
-            A = owned_from(A + stride);
-            active = A < r_end;
+            at = place_from(at + stride);
+            active = at < v_end;
+            if (active) A = row_of(at);
             fresh_row = active;
         }
     }
@@ -2648,21 +2687,46 @@ __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict
 }
 
 // (skip = the part that came from this forest itself, or -1; splice: uf_link instead of uf_union, see make_pair_args)
+// The rank's own part IS its flat forest: own[i] = root of i.  A part that names own[i] adds nothing; otherwise (own[i], l)
+// are united — and in a dense graph (max_dist >= 3: a few dozen components) nearly every row carries the SAME pair
+// {the rank's giant root, the other rank's giant root}: a lane whose pair is its lower neighbour's leaves it to that lane.
+// (One union per row instead: 0.75 - 0.98 ms at 1M rows, max_dist 5 — a million finds that all end in one word of the forest,
+// served by one L2 channel per XCD.)
 __global__ void k_merge(int *parent, int n, const int *__restrict__ gathered, int n_parts, Counters *ctr, int skip, int splice) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int last = i;  // (a part that says what the part before said adds nothing: in a dense graph most parts name one root)
-    for (int g = 0; g < n_parts; g++) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int own = live && skip >= 0 ? gathered[(size_t)skip * n + i] : i;
+    if (live && (own < 0 || own >= n)) {
+        atomicOr(&ctr->err, ERR_LABEL);
+        live = false;
+        own = 0;
+    }
+    int last = own;  // (a part that says what the part before said adds nothing either)
+    for (int g = 0; g < n_parts; g++) {  // (uniform trip count: the shuffles below are executed by whole waves)
         if (g == skip) continue;
-        int l = gathered[(size_t)g * n + i];
-        if (l < 0 || l >= n) {
+        int l = live ? gathered[(size_t)g * n + i] : -1;
+        bool act = live;
+        if (live && (l < 0 || l >= n)) {
             atomicOr(&ctr->err, ERR_LABEL);
-            continue;
+            act = false;
         }
-        if (l == last) continue;
-        last = l;
-        if (l == i) continue;
-        if (splice) uf_link(parent, i, l); else uf_union(parent, i, l);
+        act = act && l != last && l != own;
+        if (act) last = l;
+        // the lower neighbour's pair (lane 0 of a wave has none)
+        const int own_dn = __shfl_up(own, 1), l_dn = __shfl_up(l, 1);
+        const bool act_dn = __shfl_up(act ? 1 : 0, 1) != 0;
+        const bool same = (threadIdx.x & 63) != 0 && act_dn && own_dn == own && l_dn == l;
+        if (act && !same) {
+            // a first look by plain loads (served by the CU's cache: in a dense graph every chain ends in the one word of the
+            // giant root, and a million coherent loads of one word queue up at one L2 channel): an ancestor is an ancestor
+            // whatever its age, so equal ancestors mean connected; anything else is decided by the coherent union
+            int ra = own, rb = l, nx;
+            while (ra > (nx = parent[ra])) ra = nx;
+            while (rb > (nx = parent[rb])) rb = nx;
+            if (ra != rb) {
+                if (splice) uf_link(parent, own, l); else uf_union(parent, own, l);
+            }
+        }
     }
 }
 
@@ -2840,16 +2904,18 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
         static const int per_cu_env = [] { const char *e = getenv("BFK_PG_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
         const int per_cu = per_cu_env ? per_cu_env : (pl.d <= 2 ? 32 : 64);
         const int blocks = std::max(1, std::min(std::min(pl.pf_blocks, pl.pf_blocks / 256 * per_cu), (int)std::min<long long>((long long)items * 16, 1 << 20)));
-        if (pa.skip_connected && pl.pg_walk16) {  // labels-only steps: 16 lanes per row
-            // (a group takes rows in turn: 32 blocks per CU balance as well as one row per group did, and 62 500 blocks cost 0.5 ms to dispatch)
+        if (pl.pg_walk16) {  // 16 lanes per row (BFK_PG_WALK16=0: a wave per row, k_pgjoin)
+            // (a group takes rows in turn: 32 blocks per CU balance as well as one row per group did, and 62 500 blocks cost 0.5 ms
+            // to dispatch; the grid is sized for the rank's share of the rows)
             const int wper = per_cu_env ? per_cu_env : 32;
-            auto walk = [&](int tb, int te) {
-                const int it = std::max(0, std::min(te, (n + 63) / 64) - tb);
-                const int wblocks = std::max(1, std::min(pl.pf_blocks / 256 * wper, (int)std::min<long long>((long long)it * 4, 1 << 20)));
-                hipLaunchKernelGGL(k_pgwalk16, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, n, pl.pg_recs, pl.shard,
-                                   pl.n_shards, tb, te, pa);
-            };
-            walk(t_begin, t_end);
+            const int own_items = (items + pl.n_shards - 1) / std::max(1, pl.n_shards);
+            const int wblocks = std::max(1, std::min(pl.pf_blocks / 256 * wper, (int)std::min<long long>((long long)own_items * 4, 1 << 20)));
+            if (pa.skip_connected)
+                hipLaunchKernelGGL(k_pgwalk16<false>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
+            else
+                hipLaunchKernelGGL(k_pgwalk16<true>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
         } else {
             hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
                                n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
