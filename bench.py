@@ -568,8 +568,9 @@ def main():
             join_partner_bytes = st["n_candidates"] * (4 * k_mean + 8)
         elif prefix:
             # prefix groups.  What the two long kernels must move:
-            #   k_pgjoin: 16 B (row record) per group member visited, the row heads (recs * (4 B key + 8 B position/count) +
-            #   16 B length/signature per row), 24 B written + 8 B of row extents read per queued pair
+            #   k_pgwalk16: 16 B (row record) per group member visited, the row heads (recs * 8 B position/count +
+            #   16 B length/signature/offset per row), 24 B written per queued pair (the offset of the second row is left to
+            #   the verify, which reads it for the candidates it checks)
             #   verify: the 24-byte queue record + the two parent words of every candidate, both rows' tokens (4 B each) of
             #   the candidates that are checked (all of them, or those not dropped as connected: counters.n_connected)
             recs = d + 2
@@ -578,7 +579,7 @@ def main():
             # bytes each kernel must move when everything is read / written ONCE (what `frac` prices), and — labelled
             # apart, never part of `frac` — the bytes of its repeated visits (a group member is visited by every row in
             # front of it in the group; a row is read by every candidate it is part of)
-            once_pgjoin = 24 * R + 16 * n_u / world + 32 * st["n_candidates"]
+            once_pgjoin = 24 * R + 16 * n_u / world + 24 * st["n_candidates"]
             once_verify = 32 * st["n_candidates"] + 8 * n_u + min(checked * 8 * k_mean, 4 * nnz + 4 * n_u)
             visits_pgjoin = st["pairs_filtered"] * 16
             visits_verify = checked * 8 * k_mean
@@ -591,11 +592,11 @@ def main():
                              "4 B written per row), the tokens of the rows that are checked (at most the CSR once)")
                 visits_what = "both rows' tokens (8*k_mean B) per candidate checked exactly (n_candidates - n_connected)"
             else:
-                dom = "k_pgjoin"
+                dom = "k_pgwalk16"
                 comp = once_pgjoin
                 visits = visits_pgjoin
                 comp_what = ("read / written once: the group order (16 B record + 8 B position/count per record, (d+2) records "
-                             "per row), 16 B of length / signature per row, 32 B per queued pair (record written, extents read)")
+                             "per row), 16 B of length / signature / offset per row, 24 B per queued pair")
                 visits_what = "16 B per group member visited (a member is visited once by every row in front of it in its group)"
             # whole step: tokens twice (k_pgfreq sample + k_pgkeys), 8 B per record out, three radix passes (8 B in and
             # out each), k_pgplace (8 B in, 16 B gathered, 24 B out), then the two kernels above, flatten
@@ -608,7 +609,7 @@ def main():
         achieved = comp / t_dom / 1e9 if t_dom > 0 else None
         wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'prefix' if prefix else 'allpairs'}"
         tr = measured_traffic("bfk::k_join" if join else ("void bfk::" + dom) if (prefix and dom.startswith("k_verify")) else
-                              "bfk::k_pgjoin" if prefix else "void bfk::k_prefilter", wl_key) if world == 1 else None
+                              "void bfk::k_pgwalk16" if prefix else "void bfk::k_prefilter", wl_key) if world == 1 else None
         roof = {
             "bound": "hbm", "kernel": dom,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -679,7 +680,7 @@ def main():
                 "workload_key": wl_key, "kernel_source_digest": kernel_source_digest(),
                 "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
                 "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else
-                                   "prefix groups (k_pgkeys .. radix sort .. k_pgplace .. k_pgjoin .. k_verify_connected, DESIGN 6d/6e)" if prefix else
+                                   "prefix groups (k_pgkeys .. radix sort .. k_pgplace .. k_pgwalk16 .. k_verify_connected, DESIGN 6d/6e)" if prefix else
                                    "all-pairs band kernels (k_sig .. k_prefilter .. k_verify)"),
                 "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
                              f"blocks of 64 rows (the walks of their groups) round-robin over {world} rank(s)" if prefix else

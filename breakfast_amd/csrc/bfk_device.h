@@ -98,6 +98,7 @@ struct Plan {
     uint32_t *pg_cnt;                         // sampled token counts (2^PG_CNT_BITS hashed counters)
     uint32_t *pg_keys, *pg_keys_s;            // [n][recs] record keys, row-major; sorted
     int pg_tb;                                // key bits of a token: bits of (largest token id + 2)
+    int pg_dense;                             // the token counters are indexed by the token id (largest id < 2^PG_CNT_BITS)
     int pg_walk16;                            // labels-only steps walk with k_pgwalk16 (16 lanes per row, no de-duplication set)
     int pg_pb;                                // position bits of the composite key k_pgplace bisects on (3; 0 = positional filter off)
     uint32_t *pg_keys_pm;                     // [recs][n] record keys position-major (the sort's input)

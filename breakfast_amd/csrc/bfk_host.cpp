@@ -895,7 +895,9 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         // (at every size since the walk of labels-only steps is k_pgwalk16: 10k rows, max-dist 5: 0.35 ms without, 0.23 with)
         pl.pg_pb = pl.pg_tb + 3 <= 31 ? 3 : 0;
         if (const char *e = getenv("BFK_PG_POS")) pl.pg_pb = atoi(e) && pl.pg_tb + 3 <= 31 ? 3 : 0;
-        pl.pg_walk16 = 1;  // (labels-only steps; BFK_PG_WALK16=0: k_pgjoin for every step)
+        pl.pg_dense = c->max_tok >= 0 && c->max_tok < (1 << PG_CNT_BITS) ? 1 : 0;
+        if (const char *e = getenv("BFK_PG_DENSE")) pl.pg_dense = pl.pg_dense && atoi(e) != 0;
+        pl.pg_walk16 = 1;  // (BFK_PG_WALK16=0: a wave per row, k_pgjoin)
         if (const char *e = getenv("BFK_PG_WALK16")) pl.pg_walk16 = atoi(e) != 0;
         size_t tb = 0;
         if (int rc = ctx_size_pg(c, max_dist + 2, pl.pg_tb, &tb)) return rc;

@@ -1914,7 +1914,10 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 // its rows ascending, a row looks at the members BEHIND it, and every unordered pair is seen from its smaller row.
 constexpr uint32_t PG_NONE = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t) { return (t * 0x9E3779B1u) >> (32 - PG_CNT_BITS); }
+// counter of a token: the token id itself while the vocabulary fits the table (ids are handed out by first appearance: the
+// common tokens are the low ids and share a few cache lines — hashed, the 70k tokens of the benchmark vocabulary were 70k
+// different lines of a 4 MB table), a multiplicative hash beyond
+__device__ __forceinline__ uint32_t pg_cnt_slot(uint32_t t, int dense) { return dense ? t : (t * 0x9E3779B1u) >> (32 - PG_CNT_BITS); }
 
 // bind-time helper of the path: the largest token id (sets the number of key bits to sort)
 __global__ __launch_bounds__(256) void k_maxtok(const uint32_t *__restrict__ indices, int nnz, int *out) {
@@ -1936,7 +1939,7 @@ __global__ __launch_bounds__(256) void k_maxtok(const uint32_t *__restrict__ ind
 // occurrence): the block first counts in LDS — a direct-mapped table of counter slots, a slot that is taken by another counter
 // sends the add to memory — and then adds what it holds, once per counter.  The totals are exact whatever the order.
 __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int stride,
-                                                uint32_t *__restrict__ cnt, Counters *ctr) {
+                                                uint32_t *__restrict__ cnt, Counters *ctr, int dense) {
     constexpr int LT = 2048, ROWS = 4;  // LDS slots; rows per 16-lane group
     __shared__ int l_tag[LT];
     __shared__ unsigned l_cnt[LT];
@@ -1961,7 +1964,7 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
         const long long r = (long long)((blockIdx.x * ROWS + q) * 16 + (threadIdx.x >> 4)) * stride;
         if (r >= n) continue;
         for (int j = indptr[r] + l16, e = indptr[r + 1]; j < e; j += 16) {
-            const int slot = (int)pg_cnt_slot(indices[j] & 0x7FFFFFFFu);
+            const int slot = (int)pg_cnt_slot(indices[j] & 0x7FFFFFFFu, dense);
             const int i = slot & (LT - 1);
             const int old = atomicCAS(&l_tag[i], -1, slot);
             if (old == -1 || old == slot) atomicAdd(&l_cnt[i], 1u);
@@ -1980,7 +1983,7 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
 __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
                                                 uint32_t *__restrict__ keys_pm, int *__restrict__ rows_pm, int pm, int kcap,
-                                                int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr) {
+                                                int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr, int dense) {
     // A group takes PGK_ROWS consecutive rows and has the token loads of all of them in flight, then the count look-ups of all
     // of them: with one row per group a wave was three dependent loads and gone (190 us at 1M rows for 300 MB of traffic).
     constexpr int R = PGK_ROWS;
@@ -2022,7 +2025,7 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
 #pragma unroll
             for (int st = 0; st < 4; st++) {
                 const bool in = c0[q] + st * 16 + l16 < e[q];
-                v[q][st] = in ? cnt[pg_cnt_slot(x[q][st] & 0x7FFFFFFFu)] : 0u;
+                v[q][st] = in ? cnt[pg_cnt_slot(x[q][st] & 0x7FFFFFFFu, dense)] : 0u;
             }
 #pragma unroll
         for (int q = 0; q < R; q++) {
@@ -2998,10 +3001,10 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
         const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
         const int sampled = (n + stride - 1) / stride;
-        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr);
+        hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr, pl.pg_dense);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_pgkeys, dim3((n + 16 * PGK_ROWS - 1) / (16 * PGK_ROWS)), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
-                           pl.pg_keys, pl.pg_keys_pm, pl.pg_rows, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr);
+                           pl.pg_keys, pl.pg_keys_pm, pl.pg_rows, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr, pl.pg_dense);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
         // (the sort's last pass leaves the composite {key : slot} the positional filter bisects on)
