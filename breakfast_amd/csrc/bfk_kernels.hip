@@ -2423,7 +2423,7 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
     }
 }
 
-// k_pgwalk16: the walk of LABELS-ONLY steps, 16 lanes per row (four rows per wave).  k_pgjoin gives a row a whole wave: with
+// k_pgwalk16: the walk of the prefix groups, 16 lanes per row (four rows per wave).  k_pgjoin gives a row a whole wave: with
 // the positional filter a row has ~110 members behind its records — less than two chunks of 64 — and the set-up of the list,
 // the clean-up of the de-duplication set and the launch of a wave are paid per row.  Two things bound that kernel at 1M rows
 // (0.91 ms): 62 500 blocks — the grid that gives every wave one row, for balance — cost 0.5 ms just to be dispatched (the same
@@ -2433,8 +2433,10 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
 // next one while the other three go on (no wave-wide row boundary), so a grid of 32 blocks per CU balances.  A's offset
 // comes with the row's head; B's is left to the verify, which needs it for the ~6% of the records that are not dropped as
 // connected (`w` < 0 in the queue record).  The de-duplication set is 64 slots per group and stops taking entries at 32: what
-// it misses is queued twice and the verify drops the second copy as connected — which is why this kernel serves labels-only
-// steps (exact-edges steps and edge capture keep k_pgjoin, whose records test counts every pair once).
+// it misses is queued twice and the verify drops the second copy as connected.  EXACT steps (max_dist 2, exact_edges, edge
+// capture) decide every member that passes by the records test instead — is one of A's earlier elements among B's records —
+// and write both offsets, so that every pair is queued exactly once and k_verify finds its records as from any other
+// generator.  (k_pgjoin, a wave per row, stays behind BFK_PG_WALK16=0 for comparison.)
 __device__ __forceinline__ int row16_incl_scan(int x) {  // inclusive prefix sum inside each 16-lane row (DPP row_shr)
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
