@@ -450,6 +450,54 @@ def test_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d):
     assert edges == st1["n_edges"]  # every edge found by exactly one shard
 
 
+@pytest.mark.parametrize("merge_all", [False, True])
+@pytest.mark.parametrize("n_shards,d", [(2, 5), (4, 3), (8, 5)])
+def test_dense_sharded_runs_merge_to_the_single_gpu_labels(n_shards, d, merge_all, monkeypatch):
+    """the merge on DENSE forests (a few components, every rank with a giant root of its own): k_merge unites (own root,
+    other label) from the rank's flat part, neighbouring lanes with one pair share the union; BFK_MERGE_ALL=1 takes the own
+    part like any other (pairs (row, label))"""
+    if merge_all:
+        monkeypatch.setenv("BFK_MERGE_ALL", "1")
+    rows = generate_profiles(30000, p_del=0.05, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n = len(uf)
+    want, _ = _lib.cluster_csr(indptr, indices, d)
+    assert len(np.unique(want)) < n // 20  # dense: few components
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_gath = ctx.alloc(4 * n * n_shards)
+    d_out = ctx.alloc(4 * n)
+    for s in list(range(1, n_shards)) + [0]:  # shard 0 last => the forest in the context is shard 0's
+        ctx.cluster(d, d_gath + 4 * n * s, s, n_shards)
+        ctx.sync()
+    ctx.merge_labels(d_gath, n_shards, d_out)
+    ctx.sync()
+    got = ctx.download_i32(d_out, n)
+    ctx.close()
+    assert np.array_equal(got, want)
+
+
+def test_merge_rejects_labels_out_of_range():
+    rows = list(dict.fromkeys(generate_profiles(2000)))
+    indptr, indices, _ = _lib.build_csr(rows, " ")
+    n = len(rows)
+    for bad_part in (0, 1):  # the rank's own part (its roots) / another rank's
+        ctx = _lib.Context(0)
+        ctx.upload_csr(indptr, indices)
+        d_gath = ctx.alloc(4 * n * 2)
+        d_out = ctx.alloc(4 * n)
+        ctx.cluster(1, d_gath, 0, 2)
+        ctx.sync()
+        parts = np.tile(ctx.download_i32(d_gath, n), 2).astype(np.int32)
+        parts[bad_part * n + 7] = n + 5
+        ctx.upload_i32(parts, d_gath)
+        ctx.merge_labels(d_gath, 2, d_out)
+        with pytest.raises(_lib.BfkError):
+            ctx.sync()
+        ctx.close()
+
+
 @pytest.mark.exact_edges
 @pytest.mark.parametrize("seed,d", [(1, 1), (2, 2), (3, 4), (4, 6)])
 def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
