@@ -131,6 +131,49 @@ def test_pruned_queue_overflow_is_recovered(monkeypatch):
     _invariants(st, got)
 
 
+@pytest.mark.parametrize("d,exact", [(4, False), (3, True), (2, True)])
+def test_sharded_queue_overflow_is_recovered(d, exact, monkeypatch):
+    """recovery slices of a SHARD: the walk's row blocks are the rank's blocks inside [t_begin, t_end), numbered through —
+    every slice boundary and every shard offset must still cover each of the rank's rows exactly once"""
+    rows = generate_profiles(20_000, p_del=0.05, p_ins=0.01)
+    uf = list(dict.fromkeys(rows))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    n = len(uf)
+    ctx0 = _lib.Context(0)
+    ctx0.set_candidate_path("prefix")
+    ctx0.set_exact_edges(exact)
+    ctx0.upload_csr(indptr, indices)
+    d_ref = ctx0.alloc(4 * n)
+    ctx0.cluster(d, d_ref)
+    st0 = ctx0.sync()
+    want = ctx0.download_i32(d_ref, n).copy()
+    ctx0.close()
+    monkeypatch.setenv("BFK_CAND_CAP_SHARD", "64")
+    n_shards = 3
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path("prefix")
+    ctx.set_exact_edges(exact)
+    ctx.upload_csr(indptr, indices)
+    d_gath = ctx.alloc(4 * n * n_shards)
+    d_out = ctx.alloc(4 * n)
+    edges = cands = retries = 0
+    for s in range(n_shards):
+        ctx.cluster(d, d_gath + 4 * n * s, s, n_shards)
+        st = ctx.sync()
+        assert st["path"] == 2
+        edges += st["n_edges"]
+        cands += st["n_candidates"]
+        retries += st["n_retry_slices"]
+    ctx.merge_labels(d_gath, n_shards, d_out)
+    ctx.sync()
+    got = ctx.download_i32(d_out, n)
+    ctx.close()
+    assert retries > 0
+    assert np.array_equal(got, want)
+    if exact:  # every pair queued once, by exactly one shard, in exactly one slice
+        assert cands == st0["n_candidates"] and edges == st0["n_edges"]
+
+
 def test_edge_capture_and_neighbour_lists_are_never_pruned():
     """bfk_neighbours_csr (the cache path's lists) needs every edge: capture switches the pruning off"""
     g = load_stage("indel200_d5")
