@@ -20,6 +20,7 @@ constexpr int LONG_TABLE = 4096;        // hash-table slots in LDS per block of 
 constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long (each owns a slice of the global scratch table)
 constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-join table {tag : row}
 constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wave of k_join
+constexpr int JOIN_INLINE_ROW = 128;    // longest row k_join's own exact check takes (two tokens per lane); beyond: k_verify's queue
 constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
 constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
@@ -60,6 +61,7 @@ struct JoinArgs {
     int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
     uint32_t mask, bmask;
     int dup_cap;
+    int inline_exact;  // no row of the bound CSR is longer than JOIN_INLINE_ROW: k_join decides every match itself, no k_verify launch
     int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no queueing of
               // bitmap hits, 8 no table insert, 16 no clearing, 32 no unions, 128 no scattered bitmap loads, 256 no bitmap atomicOr
 };

@@ -873,10 +873,14 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.bits = (uint32_t *)(cur ? bits1 : bits0);
         pl.ja.bits_next = (uint32_t *)(cur ? bits0 : bits1);
         pl.ja.rowhash = (uint2 *)(bits1 + c->join_bits / 8);
-        // k_verify is launched in every step, also when the queue will turn out empty (ordered profiles): a step never
-        // relies on what an earlier step on this CSR found (round 2 skipped the launch after a synced step with an empty
-        // queue: ~5 us per step that only a second step on the same CSR ever saw)
-        pl.join_skip_verify = 0;
+        // While no row of the bound CSR is longer than JOIN_INLINE_ROW tokens, k_join decides every match itself — the
+        // positional certificate, and for what that cannot decide the exact count by the wave — and the step has no
+        // k_verify launch: a property of the CSR, not of an earlier step (round 2 skipped the launch after a synced step
+        // on the same CSR had left the queue empty; round 3 first launched it always: 4.7 us of an empty kernel).
+        // k_flatten checks that the queue stayed empty; BFK_JOIN_INLINE=0: queue + k_verify as for longer rows
+        pl.ja.inline_exact = c->kcap <= JOIN_INLINE_ROW ? 1 : 0;
+        if (const char *e = getenv("BFK_JOIN_INLINE")) pl.ja.inline_exact = pl.ja.inline_exact && atoi(e) != 0;
+        pl.join_skip_verify = pl.ja.inline_exact;
         // k_verify only sees what k_join could not certify itself (rows in no common order, rows over 64 tokens)
         if (!getenv("BFK_VERIFY_GRID")) pl.verify_grid = 256;
         pl.ja.dups = (int2 *)((char *)pl.ja.rowhash + (c->n + 16) * 8);

@@ -1604,6 +1604,49 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
 //     certified pair is hooked into the union-find at once, one edge per lane.  A token that occurs several times
 //     in B is looked up at every occurrence: the pair counts at the first one only.  Whatever fails the test
 //     (another token order, a hash collision) goes to the candidate queue and k_verify's exact count.
+// Exact multiset distance of two rows of at most JOIN_INLINE_ROW tokens each, by a whole wave: every lane holds two tokens of A
+// and two of B, the rows pass by once (64 rotations), and a token counts |cnt_A - cnt_B| at its first occurrence (a token of B
+// that A does not have: at its first occurrence in B).  ~500 cross-lane reads per pair — for the matches the positional
+// certificate cannot decide (another token order, equal multisets, hash collisions): none at all on ordered profiles.
+// Returns (wave-uniform) whether the distance is <= d.  0xFFFFFFFF is not a token (k_verify's tables reserve it too).
+__device__ __forceinline__ bool wave_rows_within(const uint32_t *__restrict__ indices, int ba, int ka, int bb, int kb, int d, int lane) {
+    constexpr uint32_t NA = 0xFFFFFFFFu;
+    uint32_t a[2], b[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        a[r] = r * 64 + lane < ka ? indices[ba + r * 64 + lane] : NA;
+        b[r] = r * 64 + lane < kb ? indices[bb + r * 64 + lane] : NA;
+    }
+    int ca[2] = {0, 0}, cb[2] = {0, 0}, ca_b[2] = {0, 0}, cb_b[2] = {0, 0};
+    bool first_a[2] = {true, true}, first_b[2] = {true, true};
+    for (int s = 0; s < 64; s++) {
+        const int src = (lane + s) & 63;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t xa = (uint32_t)__shfl((int)a[q], src), xb = (uint32_t)__shfl((int)b[q], src);
+            const int pos = q * 64 + src;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int mine = r * 64 + lane;
+                ca[r] += xa == a[r] ? 1 : 0;
+                cb[r] += xb == a[r] ? 1 : 0;
+                first_a[r] = first_a[r] && !(xa == a[r] && pos < mine);
+                ca_b[r] += xa == b[r] ? 1 : 0;
+                cb_b[r] += xb == b[r] ? 1 : 0;
+                first_b[r] = first_b[r] && !(xb == b[r] && pos < mine);
+            }
+        }
+    }
+    int dist = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (a[r] != NA && first_a[r]) dist += abs(ca[r] - cb[r]);
+        if (b[r] != NA && first_b[r] && ca_b[r] == 0) dist += cb_b[r];
+    }
+    for (int o = 32; o > 0; o >>= 1) dist += __shfl_xor(dist, o);
+    return dist <= d;
+}
+
 __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n,
                                                    int nnz, JoinArgs ja, PairArgs pa, int shard0, int nshards, int2 *edges,
                                                    int edge_cap) {
@@ -1639,6 +1682,29 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
         }
     };
 
+    unsigned my_edges = 0, my_cands = 0;
+    // what the certificate cannot decide: to k_verify's queue — or, while no row is longer than JOIN_INLINE_ROW tokens
+    // (ja.inline_exact: a property of the bound CSR), decided right here by the exact count, pair after pair; the step
+    // then has no k_verify launch at all (k_flatten checks that the queue stayed empty)
+    auto resolve = [&](bool want, int A, int B, int ba, int bb, int ka, int kb) {
+        if (!ja.inline_exact) {
+            enqueue(want, A, B, ba, bb, ka, kb);
+            return;
+        }
+        bool is_edge = false;
+        for (unsigned long long m = __builtin_amdgcn_ballot_w64(want); m != 0ull; m &= m - 1ull) {
+            const int src = (int)__builtin_ctzll(m);
+            const bool e = wave_rows_within(indices, __shfl(ba, src), __shfl(ka, src), __shfl(bb, src), __shfl(kb, src), pa.d, lane);
+            if (lane == src) is_edge = e;
+        }
+        if (is_edge) {
+            uf_link(pa.parent, A, B);
+            if (edges) record_edge(pa, edges, edge_cap, A, B);
+        }
+        my_edges += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(is_edge));
+        my_cands += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(want));
+    };
+
     {   // rows k_jhash found to share one H: the rank (later row) % nshards owns the pair (the same on every rank)
         const int ndup = (int)min(pa.ctr->n_dup, (unsigned)ja.dup_cap);
         const int per = (int)gridDim.x * 1024;
@@ -1658,13 +1724,12 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
                     eb = indptr[B + 1];
                 }
             }
-            enqueue(mine, A, B, ba, bb, ea - ba, eb - bb);
+            resolve(mine, A, B, ba, bb, ea - ba, eb - bb);
         }
     }
     // multi-GPU: the blocks (16 x 512 tokens, i.e. their lookups) are dealt round-robin
     const int gw = blockIdx.x * 16 + wave;
     const int T0 = gw * JOIN_TPW;  // (the host keeps nnz + JOIN_TPW below 2^31)
-    unsigned my_edges = 0, my_cands = 0;
     if ((int)(blockIdx.x % (unsigned)nshards) == shard0 && T0 < nnz) {
         int4 *qr = q_rec[wave], *mr = m_rec[wave];
         int nq = 0, nm = 0;  // wave-uniform
@@ -1736,7 +1801,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
             const int nc = __popcll(__builtin_amdgcn_ballot_w64(cert));
             my_edges += (unsigned)nc;
             my_cands += (unsigned)nc;
-            enqueue(live && !cert && !dup, A, B, ba, bb, ka, kb);
+            resolve(live && !cert && !dup, A, B, ba, bb, ka, kb);
             __builtin_amdgcn_wave_barrier();
             nm = 0;
         };

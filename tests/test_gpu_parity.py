@@ -628,14 +628,19 @@ def _join_cases():
 
 
 @pytest.mark.exact_edges
+@pytest.mark.parametrize("inline", ["default", "0"])
 @pytest.mark.parametrize("name", ["small_alphabet", "medium", "long_rows", "perms100", "perms400", "profiles30k",
                                   "tiny_rows"])
-def test_variant_join_equals_the_all_pairs_path(name, monkeypatch):
+def test_variant_join_equals_the_all_pairs_path(name, inline, monkeypatch):
     """max_dist 1 is served by the hash join (H(B) - h(t) lookups): labels, edge count and neighbour
     lists must equal those of the all-pairs kernels and of the oracle — repeated tokens (a pair must be found once),
     equal multisets in other orders, rows over several 64-token chunks, and the give-up path (probe chain beyond the
-    limit -> the step is redone by the all-pairs kernels)"""
+    limit -> the step is redone by the all-pairs kernels).  What the positional certificate cannot decide is counted
+    exactly by k_join itself while no row has more than 128 tokens (no k_verify launch), and queued for k_verify beyond
+    (`inline` = "0" forces the queue)"""
     indptr, indices = _join_cases()[name]
+    if inline != "default":
+        monkeypatch.setenv("BFK_JOIN_INLINE", inline)
     monkeypatch.setenv("BFK_JOIN", "0")
     want, st0 = _lib.cluster_csr(indptr, indices, 1)
     ptr0, idx0 = _lib.neighbours_csr(indptr, indices, 1)
@@ -694,6 +699,48 @@ def test_variant_join_fuzz_vs_oracle(seed):
             dist = np.abs(dense[:, None, :] - dense[None, :, :]).sum(axis=2)
             assert st["n_edges"] == int(np.triu(dist <= 1, 1).sum()), (seed, it)
     assert by_join >= 15, by_join
+
+
+@pytest.mark.exact_edges
+@pytest.mark.parametrize("seed", range(4))
+def test_variant_join_inline_exact_count_vs_brute_force(seed):
+    """k_join's own exact count (wave_rows_within): rows of 0 .. 128 tokens over a small alphabet, shuffled — the
+    certificate fails for nearly every match, equal multisets and repeats are everywhere — labels vs the oracle, the edge
+    count vs brute force on the count matrix; the same input with one row of 129 tokens goes through k_verify's queue"""
+    rng = np.random.default_rng(4200 + seed)
+    alphabet = 12
+    for longest in (128, 129):
+        rows = []
+        for _ in range(300):
+            k = int(rng.choice([0, 1, 2, 5, 40, 63, 64, 65, 127, 128]))
+            base = np.sort(rng.integers(0, alphabet, size=k))
+            for _ in range(int(rng.integers(1, 4))):
+                r = list(base)
+                if rng.random() < 0.5 and len(r) < 128:
+                    r.append(int(rng.integers(0, alphabet)))
+                rng.shuffle(r)
+                rows.append(np.array(r, dtype=np.int32))
+        rows.append(rng.integers(0, alphabet, size=longest).astype(np.int32))
+        indptr = np.zeros(len(rows) + 1, np.int32)
+        indptr[1:] = np.cumsum([len(r) for r in rows])
+        indices = np.concatenate(rows).astype(np.int32)
+        ctx = _lib.Context(0)
+        ctx.set_candidate_path("join")
+        ctx.upload_csr(indptr, indices)
+        d_out = ctx.alloc(4 * len(rows))
+        ctx.cluster(1, d_out)
+        st = ctx.sync()
+        got = ctx.download_i32(d_out, len(rows))
+        ctx.close()
+        want = orc.cluster_csr(indptr, indices, 1, n_threads=4, want_neigh=False)["labels"]
+        assert np.array_equal(got, want), (seed, longest)
+        if st["n_retry_slices"] == 0:  # (the join did it: no give-up on a long chain of equal multisets)
+            assert st["path"] == 1
+            dense = np.zeros((len(rows), alphabet), np.int32)
+            for i, r in enumerate(rows):
+                np.add.at(dense[i], r, 1)
+            dist = np.abs(dense[:, None, :] - dense[None, :, :]).sum(axis=2)
+            assert st["n_edges"] == int(np.triu(dist <= 1, 1).sum()), (seed, longest)
 
 
 def fuzz_case(rng):
@@ -780,6 +827,7 @@ def test_variant_join_queue_overflow_falls_back(monkeypatch):
     """rows in no common order: the join cannot certify its matches itself and queues them for k_verify; a queue
     that is too small makes bfk_ctx_sync redo the step on the all-pairs path (which has the sliced recovery)"""
     indptr, indices = _join_cases()["medium"]
+    monkeypatch.setenv("BFK_JOIN_INLINE", "0")  # (rows of at most 128 tokens are otherwise decided by k_join itself: no queue)
     want, st0 = _lib.cluster_csr(indptr, indices, 1)
     assert st0["n_retry_slices"] == 0
     monkeypatch.setenv("BFK_CAND_CAP_SHARD", "1")
