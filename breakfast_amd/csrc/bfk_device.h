@@ -26,7 +26,7 @@ constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant jo
 constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
 constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
 constexpr int PG_GIVE_UP = 4096;        // group members behind a row's records, per row (sampled), beyond which the band path is used
-constexpr int PGK_ROWS = 4;             // rows per 16-lane group of k_pgkeys
+constexpr int PGK_ROWS = 1;             // rows per 16-lane group of k_pgkeys (4: all loads of four rows in flight, 82 VGPRs, 5 waves per SIMD — 26 us slower at 1M rows than 1)
 constexpr int PG_EST_STRIDE = 1024;     // every so many positions of the sorted records measure their walk (power of two)
 
 enum : int { ERR_ROWLEN = 1, ERR_WORKCAP = 2, ERR_LABEL = 4 };

@@ -6,7 +6,8 @@
 // benchmark vocabulary, ~200 us for 7M records).  The key bits that matter are few and known (bits of the largest token
 // id + 2), so the digits are made as wide as they need to be for FEWER passes: ceil(bits / 11) passes of ceil(bits / passes)
 // bits — two 9-bit passes for 18 bits.  Per pass:
-//   k_rs_count    a block = 4096 consecutive records (a wave = 1024 of them, 64 at a time: coalesced); digit histogram of
+//   k_rs_count    a block = 4096 consecutive records (8 waves of 512, 64 at a time: coalesced — 4 waves of 1024 left the scatter
+//                 kernel, whose LDS allows 3 blocks per CU, at 12 waves per CU: 72 -> 58 us per pass with 24); digit histogram of
 //                 the block in LDS -> hist[digit][block]
 //   k_rs_rowscan  one wave per digit: exclusive prefix over the blocks, in place; the digit's total -> tot[digit]
 //   k_rs_scatter  digit bases = exclusive scan of tot[] (in LDS, every block for itself); position of a record = digit base +
@@ -26,8 +27,8 @@ namespace bfk {
 
 namespace {
 
-constexpr int RS_THREADS = 256, RS_WAVES = 4, RS_KPL = 16;  // records per lane
-constexpr int RS_WAVE_KEYS = 64 * RS_KPL;                    // 1024 consecutive records per wave
+constexpr int RS_THREADS = 512, RS_WAVES = 8, RS_KPL = 8;    // records per lane
+constexpr int RS_WAVE_KEYS = 64 * RS_KPL;                    // 512 consecutive records per wave
 constexpr int RS_TILE = RS_WAVES * RS_WAVE_KEYS;             // 4096 per block
 constexpr int RS_MAX_BITS = 11;                              // widest digit: 2048 bins (2 x 32 KiB of LDS in the scatter kernel)
 
@@ -63,12 +64,21 @@ __global__ __launch_bounds__(64) void k_rs_rowscan(uint32_t *__restrict__ hist, 
     uint32_t *row = hist + (size_t)blockIdx.x * n_blk;
     const int lane = threadIdx.x;
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < n_blk; b0 += 64) {
-        const uint32_t b = b0 + lane;
-        const int v = b < n_blk ? (int)row[b] : 0;
-        const int inc = rs_wave_incl_scan(v);
-        if (b < n_blk) row[b] = run + (uint32_t)(inc - v);
-        run += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+    // (four chunks of 64 requested together: the row is one dependent chain of loads otherwise — 27 round trips at 1M rows)
+    for (uint32_t b0 = 0; b0 < n_blk; b0 += 256) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = b0 + u * 64 + lane;
+            v[u] = b < n_blk ? (int)row[b] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = b0 + u * 64 + lane;
+            const int inc = rs_wave_incl_scan(v[u]);
+            if (b < n_blk) row[b] = run + (uint32_t)(inc - v[u]);
+            run += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+        }
     }
     if (lane == 0) tot[blockIdx.x] = run;
 }
