@@ -2152,6 +2152,12 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
     }
 }
 
+// can the record in this slot of a row walk at all?  (slot recs - 1: the SHORT record; slot i < recs - 1: prefix position i, which
+// with the positional filter walks sub-groups i .. d - i: none when d - i < i)
+__device__ __forceinline__ bool pg_slot_walks(int slot, int recs, int pb, int max_dist) {
+    return slot == recs - 1 || !pb || max_dist - slot >= slot;
+}
+
 // one thread per position of the sorted records: for every record of a row where it went and how many positions behind it
 // the row has to walk.
 //
@@ -2203,7 +2209,10 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
         }
     }
     srec[p] = make_int4(row, ri.x, ri.y, ri.z);
-    recpos[v] = make_int2(p, behind);
+    // (7M scattered 8-byte stores were 88 us of this kernel at 1M rows, max_dist 5: the records of positions i > d - i never
+    // walk — pg_slot_walks, the walk does not read their entries — and are not stored)
+    const int slot = v - row * recs;
+    if (pg_slot_walks(slot, recs, pb, max_dist)) recpos[v] = make_int2(p, behind);
     // every PG_EST_STRIDE-th position reports what k_pgjoin will walk from it, so that the walk can be called off when the
     // groups are too big
     if ((p & (PG_EST_STRIDE - 1)) == 0 && behind > 0) atomicAdd(&ctr->pg_est, (unsigned long long)behind);
@@ -2329,7 +2338,7 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
         const uint32_t key_j = __shfl(hd.key, slot_j);
         const int pos_j = __shfl(hd.pos.x, slot_j);
         const int beh_all = __shfl(hd.pos.y, slot_j);  // (unconditional: a lane that sits this out cannot be read from)
-        const int beh_j = (lane < recs && key_j != PG_NONE) ? beh_all : 0;
+        const int beh_j = (lane < recs && key_j != PG_NONE && pg_slot_walks(slot_j, recs, pb, d)) ? beh_all : 0;  // (other slots: no entry)
         const int incl_j = wave_incl_scan_add(beh_j);
         const int T = __builtin_amdgcn_readlane(incl_j, 63);
         if (T == 0) continue;
@@ -2513,7 +2522,7 @@ __device__ __forceinline__ int row16_incl_scan(int x) {  // inclusive prefix sum
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
                                                   const int4 *__restrict__ rowinfo, const uint32_t *__restrict__ keys, int n, int recs,
-                                                  int shard0, int nshards, int t_begin, int t_end, PairArgs pa) {
+                                                  int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb) {
     constexpr int WAVES = 4, GSET = 64, U = 4;
     if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
         if (blockIdx.x == 0 && threadIdx.x == 0) pa.ctr->pg_fail = 1;  // (groups too big to pay: the host redoes the step on the band kernels)
@@ -2597,11 +2606,12 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
     bool active = at < v_end, fresh_row = active;
     // the head of the group's next row {its records' positions and counts, length, signature, offset} is asked for one row ahead
     const int slot = l16 == 0 ? recs - 1 : l16 - 1;
+    const bool walks = l16 < recs && pg_slot_walks(slot, recs, pb, pa.d);  // (k_pgplace stores only these records' entries)
     int2 h_rp = make_int2(0, 0);
     int4 h_ri = make_int4(0, 0, 0, 0);
     uint32_t h_key = PG_NONE;
     if (active) {
-        if (l16 < recs) h_rp = recpos[(size_t)A * recs + slot];
+        if (walks) h_rp = recpos[(size_t)A * recs + slot];
         if (EXACT && l16 < recs) h_key = keys[(size_t)A * recs + slot];
         h_ri = rowinfo[A];
     }
@@ -2619,7 +2629,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
             h_key = PG_NONE;
             if (nat < v_end) {
                 const int nx = row_of(nat);
-                if (l16 < recs) h_rp = recpos[(size_t)nx * recs + slot];
+                if (walks) h_rp = recpos[(size_t)nx * recs + slot];
                 if (EXACT && l16 < recs) h_key = keys[(size_t)nx * recs + slot];
                 h_ri = rowinfo[nx];
             }
@@ -2982,10 +2992,10 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
             const int wblocks = std::max(1, std::min(pl.pf_blocks / 256 * wper, (int)std::min<long long>((long long)own_items * 4, 1 << 20)));
             if (pa.skip_connected)
                 hipLaunchKernelGGL(k_pgwalk16<false>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
-                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
             else
                 hipLaunchKernelGGL(k_pgwalk16<true>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
-                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa);
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
         } else {
             hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
                                n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
