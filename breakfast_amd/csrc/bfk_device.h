@@ -39,7 +39,7 @@ struct Counters {
     unsigned int ticket;   // arrival order of the k_cells blocks
     unsigned int n_dup;    // variant join: entries of the dup list (k_jhash fills, k_join reads, k_flatten resets)
     int join_fail;         // variant join gave up (probe chain too long): the host re-runs on the all-pairs path
-    int pg_fail;           // prefix groups gave up (the groups are too big to pay: k_pgjoin did nothing): the host re-runs on the band path
+    int pg_fail;           // prefix groups gave up (the groups are too big to pay: the walk did nothing): the host re-runs on the band path
     unsigned long long pg_est;  // members behind every PG_EST_STRIDE-th position of the sorted records in its group (k_pgplace)
     int overflow;
     unsigned long long pairs_in_band;
@@ -101,7 +101,7 @@ struct Plan {
     uint32_t *pg_keys, *pg_keys_s;            // [n][recs] record keys, row-major; sorted
     int pg_tb;                                // key bits of a token: bits of (largest token id + 2)
     int pg_dense;                             // the token counters are indexed by the token id (largest id < 2^PG_CNT_BITS)
-    int pg_walk16;                            // labels-only steps walk with k_pgwalk16 (16 lanes per row, no de-duplication set)
+    int pg_walk16;                            // the groups are walked by k_pgwalk16 (16 lanes per row); 0: k_pgjoin, a wave per row
     int pg_pb;                                // position bits of the composite key k_pgplace bisects on (3; 0 = positional filter off)
     uint32_t *pg_keys_pm;                     // [recs][n] record keys position-major (the sort's input)
     int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along
@@ -110,7 +110,7 @@ struct Plan {
     int4 *pg_srec;       // {row, length, second-level signature} in group order
     int4 *pg_rowinfo;    // [n]: {length, second-level signature, first token}
     int2 *pg_recpos;     // [n][recs]: {position of the record in the group order, members of its group behind it}
-    int join_skip_verify;  // the last synced join step on this CSR queued nothing for k_verify: it is not launched
+    int join_skip_verify;  // k_join decides every match itself (JoinArgs::inline_exact: no row over JOIN_INLINE_ROW tokens): no k_verify launch
     int join;  // 1: candidates come from the variant join (k_jhash + k_join) instead of k_sig .. k_prefilter
     JoinArgs ja;
 };

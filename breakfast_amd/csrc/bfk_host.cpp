@@ -114,7 +114,6 @@ struct bfk_ctx {
     int64_t pg_rec_cap = 0, pg_temp_cap = 0, pg_rowinfo_cap = 0;
     // (shard, n_shards) of a synced join step on this CSR that left the queue of k_verify empty: the queued set is a
     // function of the CSR and the sharding only, so later steps skip that launch (k_flatten re-checks)
-    int join_empty_shard = -1, join_empty_shards = 0;
     // device tokeniser (bfk_ctx_build_csr, bfk_text.hip): text, bit arrays, vocabulary table, per-token scratch
     uint8_t *tk_text = nullptr;
     long long *tk_rowoff = nullptr;
@@ -242,7 +241,6 @@ extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
     if (mode != c->path_mode) {  // the other path's per-step invariants (clean histogram / cleared table sets) are void
         c->need_zero = true;
         c->join_clear = true;
-        c->join_empty_shard = -1;
         c->last_tiles = 0;
     }
     c->path_mode = mode;
@@ -382,7 +380,6 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->join_clear = true;
     c->join_off = false;
     c->pg_off = false;
-    c->join_empty_shard = -1;
     return ctx_size_workspace(c, 0);
 }
 
@@ -1067,7 +1064,6 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             // or its candidates did not fit the queue: the step is redone on the all-pairs path, which has its own
             // recovery; a give-up also turns the join off for this CSR
             if (h.join_fail) c->join_off = true;
-            c->join_empty_shard = -1;
             c->need_zero = true;
             c->join_clear = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
@@ -1077,7 +1073,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             retry_slices = 1;
         }
         if (c->plan.pg && h.pg_fail) {
-            // the prefix groups are too big to pay (k_pgjoin did nothing): the step is redone on the band kernels
+            // the prefix groups are too big to pay (the walk did nothing): the step is redone on the band kernels
             c->pg_off = true;
             c->need_zero = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
@@ -1085,16 +1081,6 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
             c->last_tiles = (int64_t)h.n_work;
             retry_slices = 1;
-        }
-        if (c->plan.join && !h.overflow && !h.join_fail) {
-            unsigned long long queued = 0;
-            for (unsigned v : h.ncand) queued += v;
-            if (queued == 0) {
-                c->join_empty_shard = c->plan.shard;
-                c->join_empty_shards = c->plan.n_shards;
-            } else {
-                c->join_empty_shard = -1;
-            }
         }
         if (!h.overflow)
             if (int rc = ctx_pair_stats(c, &h)) return rc;

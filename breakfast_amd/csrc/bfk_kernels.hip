@@ -19,8 +19,16 @@
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
 //   max_dist == 1 (up to 800k rows) replaces k_sig .. k_verify by the VARIANT JOIN: k_jhash (additive multiset hash
 //                of every row -> hash table + bitmap), k_join (one lookup per token occurrence: H(B) - h(t); matches
-//                certified by a 64-lane compare and hooked at once; the rest to k_verify) — O(nnz), no pairs formed
-//   k_merge      multi-GPU: unite (i, gathered[g][i]) pseudo-edges;  k_union_lists: cache path
+//                certified by a 64-lane compare and hooked at once; what the compare cannot decide: counted exactly by
+//                the wave while no row has more than 128 tokens — no k_verify launch then —, to k_verify's queue
+//                otherwise) — O(nnz), no pairs formed
+//   max_dist 2 .. 7 on inputs beyond PG_MIN_ROWS (bfk_host.cpp) replaces k_sig .. k_prefilter by the PREFIX GROUPS:
+//                k_pgfreq (sampled token counts), k_pgkeys (the row's d + 1 rarest distinct tokens -> records), the radix
+//                sort of bfk_sort.hip, k_pgplace (members of a group as one stream; where each record's walk ends:
+//                positional filter), k_pgwalk16 (16 lanes per row walk the members behind the row's records; a 64-bit
+//                signature level; queue), then k_verify (max_dist 2, exact steps) or k_verify_connected (labels-only
+//                steps: candidates of rows that are connected already are dropped unchecked)
+//   k_merge      multi-GPU: unite (own root, label in another rank's part) pseudo-edges;  k_union_lists: cache path
 //
 // What it replaces in the reference: the band loop + get_neighbours_batch + sklearn _sparse_manhattan +
 // _reduce_func + networkx components (src/breakfast/breakfast.py:223-276, 287-326).
@@ -2122,7 +2130,7 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
 #pragma unroll
     for (int q = 0; q < R; q++) {
         const int r = r0 + q;
-        // {length, second-level signature, offset} of the row in one 16-byte record: what k_pgcomp gathers per position and
+        // {length, second-level signature, offset} of the row in one 16-byte record: what k_pgplace gathers per position and
         // the walk per row
         const uint32_t sa = row16_allxor(s2all[q]), sh = row16_allxor(s2hi[q]);
         if (r >= n) continue;
@@ -2758,7 +2766,8 @@ __global__ void k_compress(int *parent, int n) {
 __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && ctr) ctr->n_dup = 0;  // the dup list of the variant join: consumed, empty for the next step
-    // k_verify was not launched because this CSR queued nothing the last time: if it did now, the step is redone
+    // k_verify was not launched because k_join decides every match of this CSR itself: a queue that is not empty all the
+    // same means the step is redone on the all-pairs path
     if (expect_empty_queue && i < CAND_SHARDS && ctr->ncand[i] != 0u) ctr->join_fail = 1;
     if (i >= n) return;
     int cur = parent[i], next;
@@ -3066,7 +3075,7 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
                            pl.n_shards, pl.edges, pl.edge_cap);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
-        if (pl.join_skip_verify) {  // nothing was queued the last time (k_flatten checks that this still holds)
+        if (pl.join_skip_verify) {  // k_join decided every match itself: nothing is queued (k_flatten checks that)
             if (ev) (void)hipEventRecord(ev[3], st);
         } else if (int e = launch_verify(pl, pa, st, ev)) {
             return e;
