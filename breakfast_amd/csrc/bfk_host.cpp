@@ -1342,14 +1342,13 @@ static int cluster_multi(const int32_t *indptr, const int32_t *indices, int64_t 
 }
 
 // Is a one-shot call worth several devices?  Every device needs the whole CSR (an upload each, in parallel), the shards'
-// labels have to meet on one device (peer copies) and be merged there: (n_gpus - 1) * N pseudo-edges into one forest — 0.11 ms
-// at 1M rows and max-dist 1, 0.2 ms at max-dist 2, but ~1 ms from max-dist 3 on (dense graphs: every rank's forest is one big
-// tree with a root of its own).  What the extra devices take off is the SHARDED part of the step (pair kernel + verify; the
-// prep is replicated).  One-device rehearsal of the split, each shard alone on the GPU (profiles/r03_rehearsal_shard_tables.json,
-// 1M rows, kernels of the slowest shard at 1 / 8 ranks): max-dist 1: 0.48 / 0.25 ms (+ 0.11 merge: break-even), max-dist 2:
-// 1.47 / 0.49 (+ 0.22: a 2x win), max-dist 3 on the band kernels: 4.4 / 1.5 (+ 0.9: slower than one device on the prefix
-// groups, 1.9), prefix groups: the verify of a shard gets SLOWER the fewer edges its forest sees.  So: several devices at
-// max-dist 2 from 300k rows and at max-dist 1 from 2M; everything else runs on one device whatever n_gpus says
+// labels have to meet on one device (peer copies) and be merged there (k_merge: 0.07 - 0.2 ms at 1M rows).  What the extra
+// devices take off is the SHARDED part of the step (pair kernel / walk + verify; the prep is replicated).  One-device rehearsal
+// of the split, each shard alone on the GPU (profiles/r03_rehearsal_shard_tables.json, 1M rows, kernels of the slowest shard at
+// 1 / 8 ranks): max-dist 1: 0.48 / 0.25 ms (+ 0.11 merge: break-even); max-dist 2: 1.09 on the groups / 0.50 on the band
+// kernels the shards run (+ 0.2: a win); max-dist 5 on the prefix groups: 1.81 / 1.26 at 4 ranks / 1.16 at 8 (+ 0.2 merge + the
+// exchange: a win from 4 ranks, nothing at 2).  So: several devices at max-dist 2 from 300k rows, at max-dist >= 3 from 500k
+// rows on at least 4 devices, at max-dist 1 from 2M; everything else runs on one device whatever n_gpus says
 // (bfk_stats.n_gpus_used tells).  BFK_MULTI_FORCE=1 (and the one-device rehearsal mode of the tests) shards regardless.
 static bool multi_worth(int64_t n_rows, int32_t max_dist, int32_t n_gpus) {
     if (getenv("BFK_MULTI_FORCE") && atoi(getenv("BFK_MULTI_FORCE")) != 0) return true;

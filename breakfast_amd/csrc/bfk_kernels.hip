@@ -2554,7 +2554,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
     int cshard = (blockIdx.x * WAVES + wave) & (CAND_SHARDS - 1);
     const int d = pa.d;
     int nq = 0;  // pairs waiting in sq (wave-uniform)
-    unsigned long long visits = 0;
+    unsigned int my_visits = 0;  // members this lane looked at (summed over the wave at the end: no ballot per chunk)
     auto flush64 = [&]() {  // the first 64 waiting pairs go to the queue (full lines, one returning atomic), the rest moves to the front
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2674,7 +2674,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
         for (int u = 0; u < U; u++) {
             bool pass = have[u] && abs(rec[u].y - len_a) <= d && __popc((uint32_t)rec[u].z ^ sa0) + __popc((uint32_t)rec[u].w ^ sa1) <= d;
             if (pa.dbg & 64) pass = have[u] && rec[u].x == -7;  // (BFK_PF_DEBUG=64: the walk alone; timing experiments, results invalid)
-            visits += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have[u]));
+            my_visits += have[u] ? 1u : 0u;
             if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
             bool ins = false;
             if (EXACT) {
@@ -2740,7 +2740,9 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
         }
     }
     while (nq > 0) flush64();
-    if (lane == 0) s_vis[wave] = visits;
+    // (a wave's members fit 32 bits by far: its rows x PG_GIVE_UP members per row on average at most)
+    for (int o = 32; o > 0; o >>= 1) my_visits += (unsigned)__shfl_xor((int)my_visits, o);
+    if (lane == 0) s_vis[wave] = my_visits;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long sum = 0ull;
