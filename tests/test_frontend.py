@@ -170,6 +170,52 @@ def test_reader_declines(text, chunk_bytes, tmp_path, monkeypatch):
         _lib.Table.open(p, "\t", "id", "f")
 
 
+@pytest.mark.parametrize("threads", ["1", "7"])
+@pytest.mark.parametrize("dup_at", [None, (3, 39_990), (20_000, 20_001), (0, 16_384)])
+def test_reader_checks_ids_in_parallel(dup_at, threads, tmp_path, monkeypatch):
+    """the id check is row-parallel from 16k rows on (an insert-only table filled by compare-and-swap): a duplicate is found
+    wherever its two rows lie — one thread's slice, two slices, the first and a late row — and distinct ids pass"""
+    monkeypatch.setenv("BFK_THREADS", threads)
+    n = 40_000
+    ids = [f"seq{i:07d}" for i in range(n)]
+    if dup_at:
+        ids[dup_at[1]] = ids[dup_at[0]]
+    p = tmp_path / "in.tsv"
+    p.write_text("id\tf\n" + "".join(f"{x}\tA{i % 97}T C{i % 13}G\n" for i, x in enumerate(ids)))
+    if dup_at:
+        with pytest.raises(_lib.Unsupported, match="duplicate sequence identifiers"):
+            _lib.Table.open(p, "\t", "id", "f")
+    else:
+        t = _lib.Table.open(p, "\t", "id", "f")
+        assert len(t) == n
+        t.close()
+
+
+@pytest.mark.parametrize("bad,at", [("\x00", 5_000_000), ("\"", 9_000_001), ("\xc3\xa9", 123_457), ("\r", 7_654_321)])
+def test_reader_byte_check_finds_a_bad_byte_anywhere(bad, at, tmp_path, monkeypatch):
+    """the byte check looks at eight bytes at a time in parallel slices of a file read in parallel slices: a NUL, a quote,
+    a non-ASCII byte or a lone CR is found at any offset (word-aligned or not), and the clean file is accepted"""
+    monkeypatch.setenv("BFK_THREADS", "5")
+    monkeypatch.setenv("BFK_CHUNK_BYTES", "1000000")
+    line = "s{:07d}\tA1T C22G del:333:4\n"
+    body = "".join(line.format(i) for i in range(400_000))
+    text = ("id\tf\n" + body).encode()
+    p = tmp_path / "in.tsv"
+    p.write_bytes(text)
+    t = _lib.Table.open(p, "\t", "id", "f")
+    assert len(t) == 400_000
+    t.close()
+    at = min(at, len(text) - 10)
+    p.write_bytes(text[:at] + bad.encode("latin-1") + text[at + len(bad.encode("latin-1")):])
+    with pytest.raises(_lib.Unsupported):
+        _lib.Table.open(p, "\t", "id", "f")
+
+
+def test_reader_declines_what_is_not_a_regular_file(tmp_path):
+    with pytest.raises(_lib.Unsupported):
+        _lib.Table.open(tmp_path, "\t", "id", "f")  # a directory
+
+
 @pytest.mark.parametrize("fixture,idc,fc", [("testfile.tsv", "accession", "dna_profile"),
                                             ("testfile_nextclade.tsv", "seqName", "substitutions")])
 def test_reader_on_reference_fixtures(fixture, idc, fc):
