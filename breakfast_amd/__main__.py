@@ -24,5 +24,40 @@ _early_preload()
 
 from .console import main  # noqa: E402
 
+
+def _fast_exit_wanted():
+    """not under rocprofv3 or coverage (they write their results in exit handlers), not with BFK_FAST_EXIT=0"""
+    import os
+
+    if os.environ.get("BFK_FAST_EXIT", "1") == "0":
+        return False
+    return not any(k.startswith(("ROCP", "ROCPROF", "COVERAGE", "COV_CORE")) for k in os.environ)
+
+
+def _run():
+    """The command, then the end of the process WITHOUT the interpreter's and the HIP runtime's teardown (75 ms of a 0.23 s
+    run at 100k rows): everything a successful run produces is written and closed by then (clusters.tsv and the cache by
+    the native writer or pandas, the prints flushed here) and a CLI process has nothing left to hand back.  Failures, runs
+    under rocprofv3 / coverage and BFK_FAST_EXIT=0 end the ordinary way."""
+    import os
+
+    try:
+        main()
+        code = 0
+    except SystemExit as e:  # click ends every run this way
+        code = e.code
+    if code in (0, None) and _fast_exit_wanted():
+        try:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            from . import _front
+
+            _front.preload_join()
+        except Exception:
+            raise SystemExit(code)
+        os._exit(0)
+    raise SystemExit(code)
+
+
 if __name__ == "__main__":
-    main()
+    _run()

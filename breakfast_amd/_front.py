@@ -66,6 +66,12 @@ def _err(lib):
     return lib.bfk_last_error().decode(errors="replace")
 
 
+def preload_join():
+    """wait for the preload thread, if one was started (a no-op otherwise)"""
+    if _lib is not None:
+        _lib.bfk_preload_join()
+
+
 def preload(input_file=None, device: int = 0):
     """Start loading libbfk.so (HIP runtime, device context, code object, workspace sized from the input file's size) on a
     native thread.  Idempotent; errors surface at cluster time."""

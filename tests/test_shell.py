@@ -186,6 +186,25 @@ def test_cli_process_never_aborts(tmp_path, args, ok):
     assert (res.returncode == 0) == ok, (res.returncode, res.stderr[-500:])
 
 
+def test_cli_process_fast_exit_loses_nothing(tmp_path):
+    """a successful run ends by os._exit after flushing (no interpreter / HIP teardown): the prints a pipe receives and the
+    files are those of an ordinary exit (BFK_FAST_EXIT=0), the status is 0; a failing run ends the ordinary way"""
+    import subprocess
+    import sys
+
+    outs = {}
+    for mode in ("1", "0"):
+        o = tmp_path / f"o{mode}"
+        res = subprocess.run([sys.executable, "-m", "breakfast_amd", "--input-file", "testfile.tsv", "--max-dist", "0", "--outdir", str(o)],
+                             cwd=str(FIX), capture_output=True, text=True, env={**os.environ, "PYTHONPATH": str(ROOT), "BFK_FAST_EXIT": mode})
+        assert res.returncode == 0, res.stderr[-500:]
+        outs[mode] = (res.stdout.replace(str(o), "OUT"), (o / "clusters.tsv").read_bytes())
+    assert outs["1"] == outs["0"]
+    assert "Number of clusters found" in outs["1"][0]
+    res = _cli_process(["--input-file", "testfile.tsv", "--id-col", "nope", "--max-dist", "0", "--outdir", str(tmp_path / "x")], FIX)
+    assert res.returncode != 0
+
+
 def test_cli_process_max_dist_1_without_a_gpu_fails_loudly_not_by_abort(tmp_path):
     """with the preload thread running (max-dist 1): on a box without a GPU the run reports BFK_ENODEV and exits non-zero;
     on a GPU box it succeeds — either way through a normal exit"""
