@@ -184,13 +184,16 @@ struct Classifier {
     }
 };
 
+// 32 bytes: a probe touches one line, and a token of up to 8 bytes — nearly all of them — is compared by its inline copy
+// (following `p` to the token's first occurrence, somewhere in 330 MB of text, was a second cache miss per token)
 struct TokSlot {
-    const char *p;
+    uint64_t h;
+    uint64_t k8;    // the first min(len, 8) bytes, zero-padded
+    const char *p;  // first occurrence (NULL: free slot)
     uint32_t len;
-    int32_t id;  // vocabulary id, -1 until the token is first kept
-    int8_t verdict;
-    uint8_t used;
+    int32_t id;     // >= 0: vocabulary id; TOK_FRESH: kept, not numbered yet; TOK_DROP / TOK_INVALID: the classifier's verdict
 };
+constexpr int32_t TOK_FRESH = -1, TOK_DROP = -2, TOK_INVALID = -3;
 
 // ---- host threads ----------------------------------------------------------------------------------
 // The text stages are row-parallel: contiguous row chunks, one std::thread each (BFK_THREADS overrides the count;
@@ -229,6 +232,7 @@ struct TokChunk {
     std::vector<int64_t> row_end;   // per row: end offset into ids
     std::vector<Span> vocab;        // local id -> token bytes
     std::vector<uint64_t> vhash;    // ... and their hashes (reused by the merge)
+    std::vector<uint64_t> vk8;      // ... and their first 8 bytes, zero-padded (the merge compares short tokens without touching the text)
     std::vector<Span> invalid;      // token occurrences that matched no pattern, in order
     std::vector<int32_t> to_global;
 };
@@ -237,9 +241,13 @@ void tokenize_chunk(const char *base, const std::function<Span(int64_t)> &row_sp
                     const Classifier *cls, TokChunk &ck) {
     const char s0 = sep[0];
     size_t tcap = 1u << 12, tcount = 0;
-    std::vector<TokSlot> tab(tcap, TokSlot{nullptr, 0, -1, 0, 0});
-    std::vector<uint64_t> hs(tcap, 0);
+    std::vector<TokSlot> tab(tcap, TokSlot{0, 0, nullptr, 0, TOK_FRESH});
     ck.row_end.reserve((size_t)(ck.r1 - ck.r0));
+    if (ck.r1 > ck.r0) {  // (one token per ~7 bytes of profile text: no regrowth of the id array on the way)
+        const Span a = row_span(ck.r0), z = row_span(ck.r1 - 1);
+        const int64_t span_bytes = z.off + z.len - a.off;
+        if (span_bytes > 0) ck.ids.reserve((size_t)(span_bytes / 5 + 64));
+    }
     for (int64_t r = ck.r0; r < ck.r1; r++) {
         const Span sp = row_span(r);
         const char *s = base + sp.off;
@@ -248,8 +256,10 @@ void tokenize_chunk(const char *base, const std::function<Span(int64_t)> &row_sp
         while (pos <= len) {
             int64_t nx = -1;  // next separator at or after pos
             if (sep_len == 1) {
-                const void *f = pos < len ? memchr(s + pos, s0, (size_t)(len - pos)) : nullptr;
-                if (f) nx = (const char *)f - s;
+                // (tokens are a handful of bytes: a plain loop beats the call into memchr)
+                int64_t i = pos;
+                while (i < len && s[i] != s0) i++;
+                if (i < len) nx = i;
             } else {
                 for (int64_t i = pos; i + sep_len <= len; i++)
                     if (s[i] == s0 && memcmp(s + i, sep, (size_t)sep_len) == 0) {
@@ -265,36 +275,38 @@ void tokenize_chunk(const char *base, const std::function<Span(int64_t)> &row_sp
                 if (cls && (*cls)(tk, 0) == INVALID) ck.invalid.push_back(Span{tk - base, 0});
             } else {
                 const uint64_t h = bytes_hash(tk, (size_t)tl);
+                uint64_t k8 = 0;
+                memcpy(&k8, tk, (size_t)std::min<int64_t>(tl, 8));
                 size_t i = h & (tcap - 1);
-                while (tab[i].used && !(hs[i] == h && tab[i].len == (uint32_t)tl && memcmp(tab[i].p, tk, (size_t)tl) == 0)) i = (i + 1) & (tcap - 1);
-                if (!tab[i].used) {
-                    tab[i] = TokSlot{tk, (uint32_t)tl, -1, (int8_t)(cls ? (*cls)(tk, tl) : KEEP), 1};
-                    hs[i] = h;
+                while (tab[i].p && !(tab[i].h == h && tab[i].len == (uint32_t)tl && tab[i].k8 == k8 &&
+                                     (tl <= 8 || memcmp(tab[i].p + 8, tk + 8, (size_t)(tl - 8)) == 0)))
+                    i = (i + 1) & (tcap - 1);
+                if (!tab[i].p) {
+                    const int v = cls ? (*cls)(tk, tl) : KEEP;
+                    tab[i] = TokSlot{h, k8, tk, (uint32_t)tl, v == KEEP ? TOK_FRESH : (v == DROP ? TOK_DROP : TOK_INVALID)};
                     tcount++;
                 }
                 TokSlot &sl = tab[i];
-                if (sl.verdict == KEEP) {
+                if (sl.id >= TOK_FRESH) {
                     if (sl.id < 0) {
                         sl.id = (int32_t)ck.vocab.size();
                         ck.vocab.push_back(Span{tk - base, (int32_t)tl});
                         ck.vhash.push_back(h);
+                        ck.vk8.push_back(k8);
                     }
                     ck.ids.push_back(sl.id);
-                } else if (sl.verdict == INVALID) {
+                } else if (sl.id == TOK_INVALID) {
                     ck.invalid.push_back(Span{tk - base, (int32_t)tl});
                 }
                 if (tcount * 2 > tcap) {
-                    std::vector<TokSlot> nt(tcap * 2, TokSlot{nullptr, 0, -1, 0, 0});
-                    std::vector<uint64_t> nh(tcap * 2, 0);
+                    std::vector<TokSlot> nt(tcap * 2, TokSlot{0, 0, nullptr, 0, TOK_FRESH});
                     for (size_t o = 0; o < tcap; o++)
-                        if (tab[o].used) {
-                            size_t j = hs[o] & (tcap * 2 - 1);
-                            while (nt[j].used) j = (j + 1) & (tcap * 2 - 1);
+                        if (tab[o].p) {
+                            size_t j = tab[o].h & (tcap * 2 - 1);
+                            while (nt[j].p) j = (j + 1) & (tcap * 2 - 1);
                             nt[j] = tab[o];
-                            nh[j] = hs[o];
                         }
                     tab.swap(nt);
-                    hs.swap(nh);
                     tcap *= 2;
                 }
             }
@@ -312,26 +324,30 @@ void merge_vocab(const char *base, std::vector<TokChunk> &cks, std::vector<Span>
     for (const TokChunk &c : cks) total += c.vocab.size();
     size_t cap = 1u << 10;
     while (cap < total * 2 + 16) cap <<= 1;
-    std::vector<int32_t> slot(cap, -1);
-    std::vector<uint64_t> sh(cap, 0);
+    struct MSlot {  // one line per probe; tokens of up to 8 bytes are compared by their inline copy
+        uint64_t h, k8;
+        int32_t id, len;
+    };
+    std::vector<MSlot> slot(cap, MSlot{0, 0, -1, 0});
     vocab_out.clear();
     for (TokChunk &c : cks) {
         c.to_global.resize(c.vocab.size());
         for (size_t l = 0; l < c.vocab.size(); l++) {
             const Span v = c.vocab[l];
-            const uint64_t h = c.vhash[l];
+            const uint64_t h = c.vhash[l], k8 = c.vk8[l];
             size_t i = h & (cap - 1);
-            while (slot[i] >= 0) {
-                const Span o = vocab_out[(size_t)slot[i]];
-                if (sh[i] == h && o.len == v.len && memcmp(base + o.off, base + v.off, (size_t)v.len) == 0) break;
+            while (slot[i].id >= 0) {
+                const MSlot &m = slot[i];
+                if (m.h == h && m.len == v.len && m.k8 == k8 &&
+                    (v.len <= 8 || memcmp(base + vocab_out[(size_t)m.id].off + 8, base + v.off + 8, (size_t)(v.len - 8)) == 0))
+                    break;
                 i = (i + 1) & (cap - 1);
             }
-            if (slot[i] < 0) {
-                slot[i] = (int32_t)vocab_out.size();
-                sh[i] = h;
+            if (slot[i].id < 0) {
+                slot[i] = MSlot{h, k8, (int32_t)vocab_out.size(), v.len};
                 vocab_out.push_back(v);
             }
-            c.to_global[l] = slot[i];
+            c.to_global[l] = slot[i].id;
         }
     }
     parallel_chunks((int)cks.size(), [&](int q) {
