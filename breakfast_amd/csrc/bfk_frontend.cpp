@@ -901,32 +901,48 @@ extern "C" int bfk_table_write(const bfk_table *t, const char *path, const int32
     }
     std::vector<int32_t> remap((size_t)mx + 1, 0);  // first appearance in input order -> 1.. (:51-60)
     int32_t next = 0;
-    std::string out;
-    out.reserve(t->ids.size() * 24 + 64);
-    out += "id\tcluster_id\n";
-    char num[16];
-    const char *b = t->bytes.data();
-    for (size_t r = 0; r < t->ids.size(); r++) {
-        const Span id = t->ids[r];
-        // csv.QUOTE_MINIMAL: only a field holding the output delimiter needs quotes here (quote, CR and LF
-        // never reach a table)
-        const bool q = memchr(b + id.off, '\t', (size_t)id.len) != nullptr;
-        if (q) out += '"';
-        out.append(b + id.off, (size_t)id.len);
-        if (q) out += '"';
-        out += '\t';
+    const size_t n = t->ids.size();
+    for (size_t r = 0; r < n; r++) {  // (the numbering is the one thing that depends on the order: a pass of its own, then the
+                                      // lines are formatted in parallel slices — one serial loop with snprintf was 70 ms at 1M rows)
         const int32_t c = cluster_of_unique[(size_t)t->group[r]];
-        if (c) {
-            if (!remap[(size_t)c]) remap[(size_t)c] = ++next;
-            const int m = snprintf(num, sizeof num, "%d", remap[(size_t)c]);
-            out.append(num, (size_t)m);
-        }
-        out += '\n';
+        if (c && !remap[(size_t)c]) remap[(size_t)c] = ++next;
     }
+    const char *b = t->bytes.data();
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), n / 32768 + 1));
+    std::vector<std::string> piece((size_t)parts);
+    parallel_chunks(parts, [&](int q) {
+        std::string &out = piece[(size_t)q];
+        const size_t r0 = n * (size_t)q / (size_t)parts, r1 = n * ((size_t)q + 1) / (size_t)parts;
+        out.reserve((r1 - r0) * 24 + 64);
+        if (q == 0) out += "id\tcluster_id\n";
+        char num[16];
+        for (size_t r = r0; r < r1; r++) {
+            const Span id = t->ids[r];
+            // csv.QUOTE_MINIMAL: only a field holding the output delimiter needs quotes here (quote, CR and LF
+            // never reach a table)
+            const bool q2 = memchr(b + id.off, '\t', (size_t)id.len) != nullptr;
+            if (q2) out += '"';
+            out.append(b + id.off, (size_t)id.len);
+            if (q2) out += '"';
+            out += '\t';
+            const int32_t c = cluster_of_unique[(size_t)t->group[r]];
+            if (c) {
+                uint32_t v = (uint32_t)remap[(size_t)c];
+                int m = 0;
+                do {
+                    num[sizeof num - 1 - (size_t)m++] = (char)('0' + v % 10);
+                    v /= 10;
+                } while (v);
+                out.append(num + sizeof num - (size_t)m, (size_t)m);
+            }
+            out += '\n';
+        }
+    });
     FILE *f = fopen(path, "wb");
     if (!f) return bfk_fail(BFK_EIO, std::string("cannot write ") + path);
-    const size_t w = fwrite(out.data(), 1, out.size(), f);
-    if (fclose(f) != 0 || w != out.size()) return bfk_fail(BFK_EIO, std::string("short write on ") + path);
+    bool ok = true;
+    for (const std::string &out : piece) ok = ok && fwrite(out.data(), 1, out.size(), f) == out.size();
+    if (fclose(f) != 0 || !ok) return bfk_fail(BFK_EIO, std::string("short write on ") + path);
     if (n_clusters_out) *n_clusters_out = next;
     return BFK_OK;
 }
