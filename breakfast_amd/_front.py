@@ -141,7 +141,7 @@ class Table:
         rc = self.lib.bfk_table_invalid(self.h, int(i), C.byref(p), C.byref(n))
         if rc:
             raise FrontError(rc, _err(self.lib))
-        return C.string_at(p, n.value).decode("ascii")
+        return C.string_at(p, n.value).decode("utf-8")
 
     def cluster_write(self, max_dist: int, min_cluster_size: int, path, n_gpus: int = 1) -> int:
         n = C.c_int64()

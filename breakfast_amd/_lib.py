@@ -334,12 +334,12 @@ class Table:
 
     @classmethod
     def from_lists(cls, ids, features):
-        """table from Python strings (tests, API callers); non-ASCII content raises Unsupported"""
+        """table from Python strings (tests, API callers); what UTF-8 cannot encode (lone surrogates) raises Unsupported"""
         lib = load()
 
         def pack(strs):
             try:
-                rows = [s.encode("ascii") for s in strs]
+                rows = [s.encode("utf-8") for s in strs]
             except UnicodeEncodeError as e:
                 raise Unsupported(str(e))
             off = np.zeros(len(rows) + 1, dtype=np.int64)
@@ -407,7 +407,7 @@ class Table:
     def _str(self, fn, i, owned):
         p, n = C.c_void_p(), C.c_int64()
         _check(fn(self.h, int(i), C.byref(p), C.byref(n)))
-        s = C.string_at(p, n.value).decode("ascii")
+        s = C.string_at(p, n.value).decode("utf-8")
         if owned:
             self.lib.bfk_free(p)
         return s
@@ -426,10 +426,13 @@ class Table:
         p, o = C.c_void_p(), c_i64p()
         _check(fn(self.h, C.byref(p), C.byref(o)))
         off = np.ctypeslib.as_array(o, shape=(int(n) + 1,)).tolist()
-        blob = C.string_at(p, off[-1]).decode("ascii")
+        raw = C.string_at(p, off[-1])
         self.lib.bfk_free(p)
         self.lib.bfk_free(o)
-        return [blob[off[i]: off[i + 1]] for i in range(int(n))]
+        if raw.isascii():  # one decode, n slices (byte offsets are character offsets)
+            blob = raw.decode("ascii")
+            return [blob[off[i]: off[i + 1]] for i in range(int(n))]
+        return [raw[off[i]: off[i + 1]].decode("utf-8") for i in range(int(n))]
 
     def features(self):
         """filtered feature strings of the unique rows (collapse_duplicates order)"""
@@ -466,6 +469,7 @@ class Context:
         self.h = h
         self.n_rows = 0
         self._owned = []
+        self.config_epoch = 0  # bumped by every setter that changes WHICH kernels a step runs (distributed.py keys on it)
 
     def close(self):
         if self.h:
@@ -491,9 +495,15 @@ class Context:
         """on: every candidate pair is checked, `n_edges` is the number of edges of the graph; off (default): labels-only
         steps at max_dist >= 3 drop candidates whose rows are already in one component (`n_connected`)."""
         _check(self.lib.bfk_ctx_set_exact_edges(self.h, 1 if on else 0))
+        self.config_epoch += 1
 
     def set_candidate_path(self, mode: str = "auto"):
         _check(self.lib.bfk_ctx_set_candidate_path(self.h, {"auto": 0, "allpairs": 1, "join": 2, "prefix": 3}[mode]))
+        self.config_epoch += 1
+
+    def set_edge_capture(self, on: bool = True):
+        _check(self.lib.bfk_ctx_set_edge_capture(self.h, 1 if on else 0))
+        self.config_epoch += 1
 
     def upload_csr(self, indptr, indices):
         indptr = np.ascontiguousarray(indptr, dtype=np.int32)

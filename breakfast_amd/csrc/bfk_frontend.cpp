@@ -418,6 +418,7 @@ struct bfk_table {
     std::vector<Span> invalid;  // into `bytes`
     std::string sep2;
     bool filtered = false, prepared = false;
+    bool any_high = false;  // the bytes hold non-ASCII (valid UTF-8) somewhere: prepare() looks at the feature column when it filters
     int32_t n_vocab = 0;
     std::vector<Span> vocab;  // token bytes of every vocabulary id (for bfk_table_feature)
 };
@@ -430,6 +431,56 @@ inline bool is_na(const char *p, int64_t n) {
     if (n > 8) return false;
     for (const char *s : NA_STRINGS)
         if ((int64_t)strlen(s) == n && memcmp(s, p, (size_t)n) == 0) return true;
+    return false;
+}
+
+// Bytes >= 0x80 are opaque to an unquoted, ASCII-separated table as long as they are VALID UTF-8: pandas decodes the file as
+// UTF-8 (read_table's default) and raises UnicodeDecodeError otherwise, compares ids and features as code-point strings —
+// which for valid UTF-8 is byte equality — and to_csv encodes them back unchanged.  The validator is Python's: no overlong
+// forms, no surrogates (U+D800..DFFF), nothing beyond U+10FFFF.  Checks the sequences that START in [i, e); a sequence may
+// end behind e (the buffer has a sentinel byte); stray continuation bytes at i are left to the slice in front (which
+// reads them as the tail of its last sequence, or flags them).
+bool utf8_valid_from(const char *b, int64_t i, int64_t e, int64_t n_total, bool first_slice) {
+    const unsigned char *u = (const unsigned char *)b;
+    if (!first_slice)  // a slice that starts inside a sequence: its head belongs to the slice in front
+        for (int k = 0; k < 3 && i < e && (u[i] & 0xC0) == 0x80; k++) i++;
+    while (i < e) {
+        const unsigned char c = u[i];
+        if (c < 0x80) {
+            i++;
+            continue;
+        }
+        int need;
+        unsigned lo = 0x80, hi = 0xBF;
+        if (c >= 0xC2 && c <= 0xDF) need = 1;
+        else if (c >= 0xE0 && c <= 0xEF) {
+            need = 2;
+            if (c == 0xE0) lo = 0xA0;  // no overlong three-byte forms
+            if (c == 0xED) hi = 0x9F;  // no surrogates
+        } else if (c >= 0xF0 && c <= 0xF4) {
+            need = 3;
+            if (c == 0xF0) lo = 0x90;  // no overlong four-byte forms
+            if (c == 0xF4) hi = 0x8F;  // nothing beyond U+10FFFF
+        } else
+            return false;  // a continuation byte where a sequence must start, 0xC0 / 0xC1, 0xF5..0xFF
+        if (i + need >= n_total + 1) return false;
+        if (u[i + 1] < lo || u[i + 1] > hi) return false;
+        for (int k = 2; k <= need; k++)
+            if ((u[i + k] & 0xC0) != 0x80) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
+bool has_high_byte(const char *p, int64_t n) {
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        if (v & 0x8080808080808080ull) return true;
+    }
+    for (; i < n; i++)
+        if ((unsigned char)p[i] >= 0x80) return true;
     return false;
 }
 
@@ -529,16 +580,19 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     tm.lap("open: read");
     const char *b = t->bytes.data();
     const int64_t n = sz;
+    bool any_high = false;
     {   // byte checks, in parallel slices
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / chunk_bytes(1 << 20) + 1));
-        std::atomic<int> bad{0};
+        std::atomic<int> bad{0}, high{0};
         parallel_chunks(parts, [&](int q) {
             int64_t i = n * q / parts;
             const int64_t e = n * (q + 1) / parts;
+            bool seen_high = false;
             auto bad_byte = [&](int64_t j) {
                 const unsigned char c = (unsigned char)b[j];
+                seen_high = seen_high || c >= 0x80;
                 // CR is accepted only as part of a CRLF line end (the reference's own fixtures are CRLF files)
-                return c >= 0x80 || c == '"' || c == 0 || (c == '\r' && b[j + 1] != '\n');
+                return c == '"' || c == 0 || (c == '\r' && b[j + 1] != '\n');
             };
             // eight bytes at a time: a word without a high bit, a zero byte, a quote or a CR needs no second look
             constexpr uint64_t L = 0x0101010101010101ull, H = 0x8080808080808080ull;
@@ -559,12 +613,32 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
                     bad.store(1);
                     return;
                 }
+            if (seen_high) high.store(1);
         });
         if (bad.load()) {
             delete t;
-            return unsupported("quote, lone CR, NUL or non-ASCII byte");
+            return unsupported("quote, lone CR or NUL byte");
+        }
+        any_high = high.load() != 0;
+        if (any_high) {
+            // bytes >= 0x80 (accession names with accents, say) are opaque to an unquoted table with an ASCII separator — if
+            // the file is valid UTF-8 (pandas raises UnicodeDecodeError otherwise) and does not start with a byte-order mark
+            // (pandas strips it from the first column name)
+            if (n >= 3 && (unsigned char)b[0] == 0xEF && (unsigned char)b[1] == 0xBB && (unsigned char)b[2] == 0xBF) {
+                delete t;
+                return unsupported("byte-order mark");
+            }
+            std::atomic<int> inval{0};
+            parallel_chunks(parts, [&](int q) {
+                if (!utf8_valid_from(b, n * q / parts, n * (q + 1) / parts, n, q == 0)) inval.store(1);
+            });
+            if (inval.load()) {
+                delete t;
+                return unsupported("bytes that are not valid UTF-8");
+            }
         }
     }
+    t->any_high = any_high;
     tm.lap("open: byte check");
     // end of the line starting at p: index of its LF, and the end of its content (CR of a CRLF stripped)
     auto line_end = [&](int64_t p, int64_t *content_end) {
@@ -712,9 +786,22 @@ extern "C" int bfk_table_from_buffers(const char *id_buf, const int64_t *id_off,
     if (nf) memcpy(t->bytes.data() + ni, feat_buf, (size_t)nf);
     for (int64_t i = 0; i < ni + nf; i++) {
         const unsigned char c = (unsigned char)t->bytes[(size_t)i];
-        if (c >= 0x80 || c == '\r' || c == '\n' || c == 0) {
+        if (c == '\r' || c == '\n' || c == 0) {
             delete t;
-            return unsupported("CR, LF, NUL or non-ASCII byte");
+            return unsupported("CR, LF or NUL byte");
+        }
+    }
+    t->bytes[(size_t)(ni + nf)] = '\n';
+    t->any_high = has_high_byte(t->bytes.data(), ni + nf);
+    if (t->any_high) {  // every id and every feature has to be valid UTF-8 by itself (they were Python strings)
+        bool ok = true;
+        for (int64_t r = 0; ok && r < n_rows; r++) {
+            ok = utf8_valid_from(t->bytes.data(), id_off[r], id_off[r + 1], id_off[r + 1] - 1, true) &&
+                 utf8_valid_from(t->bytes.data(), ni + feat_off[r], ni + feat_off[r + 1], ni + feat_off[r + 1] - 1, true);
+        }
+        if (!ok) {
+            delete t;
+            return unsupported("bytes that are not valid UTF-8");
         }
     }
     t->ids.resize((size_t)n_rows);
@@ -748,6 +835,18 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
     Classifier cls{*opts, opts->reference_length - opts->trim_end};
     // nothing to filter: features are taken verbatim, identity = the raw string (:128-129)
     const bool filtering = opts->skip_del || opts->skip_ins || opts->trim_start > 0 || opts->trim_end > 0;
+    if (filtering && t->any_high && opts->var_type != BFK_VAR_RAW) {
+        // the reference's patterns (:135-155) are str patterns: \d also matches the decimal digits of other scripts, which the
+        // ASCII matchers here do not restate — a FEATURE with non-ASCII bytes under a grammar is the general path's (ids and
+        // other columns may hold what they like)
+        std::atomic<int> high{0};
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 16384 + 1));
+        parallel_chunks(parts, [&](int q) {
+            for (int64_t r = n * q / parts, e = n * (q + 1) / parts; r < e && !high.load(std::memory_order_relaxed); r++)
+                if (has_high_byte(b + t->feats[(size_t)r].off, t->feats[(size_t)r].len)) high.store(1);
+        });
+        if (high.load()) return unsupported("non-ASCII bytes in a feature that is matched against the token patterns");
+    }
     t->filtered = filtering;
     t->sep2.assign(sep2, (size_t)sep2_len);
     t->group.assign((size_t)n, 0);

@@ -467,6 +467,17 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
             for (auto &e : c->tk_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
     }
+    // whatever way this function is left — also by an early return further down (an allocation that fails, a launch error)
+    // — the caller's buffers are no longer being read when it returns: the text and the offsets were enqueued from the
+    // caller's pageable memory on the launch stream (one piece) or on the copy stream (pieces).  On the success path the
+    // launch stream is idle by then (ctx_after_bind has synchronised it): the second wait costs nothing.
+    struct CopyGuard {
+        hipStream_t copy, launch;
+        ~CopyGuard() {
+            if (copy) (void)hipStreamSynchronize(copy);
+            if (launch) (void)hipStreamSynchronize(launch);
+        }
+    } copy_guard{n_pieces > 1 ? c->tk_copy_stream : nullptr, c->stream};
     if (ev) HIP_TRY(hipEventRecord(ev[4], c->stream));
     HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->tk_text + T, (unsigned char)sep[0], (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
@@ -483,13 +494,6 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         }
     }
     if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
-    // whatever way this function is left, the caller's buffer is no longer being read when it returns
-    struct CopyGuard {
-        hipStream_t s;
-        ~CopyGuard() {
-            if (s) (void)hipStreamSynchronize(s);
-        }
-    } copy_guard{n_pieces > 1 ? c->tk_copy_stream : nullptr};
     TokCounters tc{};
     int rc_bind = BFK_OK;
     for (int attempt = 0;; attempt++) {

@@ -80,18 +80,22 @@ class GpuEngine:
 
 
 class ShardedClusterer:
-    def __init__(self, engine, rank: int = 0, world: int = 1, merge: str = "allgather", group=None):
+    def __init__(self, engine, rank: int = 0, world: int = 1, merge: str = "allgather", group=None, force_exchange: bool = False):
+        """force_exchange: also a world of ONE rank goes through the exchange + merge branch (the collective on the engine's
+        stream, k_merge behind it) instead of the one-rank shortcut — how a one-GPU box executes the code an N-GPU node runs
+        (tests/test_gpu_scale.py::test_world_1_over_rccl_runs_the_exchange_and_merge)"""
         if merge not in ("allgather", "allreduce"):
             raise ValueError("merge must be 'allgather' or 'allreduce'")
         self.e, self.rank, self.world, self.merge, self.group = engine, rank, world, merge, group
+        self.force_exchange = force_exchange
         self.rounds = 0
-        self._settled = set()  # max_dist values whose first step on the bound CSR has been synced (see step)
+        self._settled = set()  # (max_dist, kernel configuration) whose first step on the bound CSR has been synced (see step)
 
     def bind(self, indptr, indices):
         self.e.bind(indptr, indices)
         self.local = self.e.new_labels(1)
         self.labels = self.e.new_labels(1)
-        self.gathered = self.e.new_labels(self.world) if self.world > 1 else None
+        self.gathered = self.e.new_labels(self.world) if (self.world > 1 or self.force_exchange) else None
         self.flag = self.e.new_flag()
         self._settled = set()
 
@@ -103,15 +107,22 @@ class ShardedClusterer:
         if run is None:
             return self._step(max_dist)
         with run():
-            return self._step(max_dist)
+            out = self._step(max_dist)
+        # the engine's stream is non-blocking: whatever the CALLER's stream does with the labels next (a .cpu(), a kernel of
+        # its own) has to be ordered behind the step — one event wait on the device, no host sync
+        torch.cuda.current_stream(self.e.device).wait_stream(self.e.stream)
+        return out
 
     def _step(self, max_dist: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             self.e.cluster_shard(max_dist, 0, 1, self.labels)
             return self.labels[0]
         self.e.cluster_shard(max_dist, self.rank, self.world, self.local)
-        if max_dist not in self._settled:
-            # The FIRST step on a CSR at this max_dist is synced before its labels are exchanged: a candidate generator
+        # which kernels a step runs depends on the candidate generator, the exact-edges switch and edge capture as well: a
+        # change of any of them through the context's setters starts over (Context.config_epoch)
+        key = (max_dist, getattr(getattr(self.e, "ctx", None), "config_epoch", 0))
+        if key not in self._settled:
+            # The FIRST step on a CSR at this max_dist and kernel configuration is synced before its labels are exchanged: a candidate generator
             # that gives up on the input (variant join: probe chains; prefix groups: groups too big) or a candidate queue
             # that overflows is repaired inside sync() — the shard is redone on the band kernels / in slices, `local` is
             # rewritten — and what is merged below is the repaired shard.  The context remembers the give-up and the grown
@@ -119,7 +130,7 @@ class ShardedClusterer:
             # would leave every rank with labels that miss this shard's edges: stats `n_retry_slices != 0` after an
             # UNSYNCED exchange means exactly that.)
             self.e.sync()
-            self._settled.add(max_dist)
+            self._settled.add(key)
         if self.merge == "allgather":
             dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
             self.e.merge(self.gathered, self.world, self.labels)

@@ -57,19 +57,30 @@ def save(path, max_dist: int, hashes, list_indptr, list_indices):
 
 
 def load(path, max_dist: int):
-    """-> (hashes uint64[n, 2], list offsets int64[L + 1], list members int32[total]); CacheMismatch on another max_dist"""
+    """-> (hashes uint64[n, 2], list offsets int64[L + 1], list members int32[total]); CacheMismatch on another max_dist;
+    ValueError on a file that is short, whose counts are negative, whose offsets are not a non-decreasing run from 0 to
+    `total` or whose members are not rows of the cached input (a damaged file must never turn into wrong clusters)"""
     with open(path, "rb") as f:
         if f.read(len(MAGIC)) != MAGIC:
             raise ValueError(f"{path} is not a side-car cache")
         print("Import from side-car cache")
-        d, n, n_lists, total = _HEAD.unpack(f.read(_HEAD.size))
+        head = f.read(_HEAD.size)
+        if len(head) != _HEAD.size:
+            raise ValueError(f"{path}: truncated side-car cache (header)")
+        d, n, n_lists, total = _HEAD.unpack(head)
+        if n < 0 or n_lists < 0 or total < 0:
+            raise ValueError(f"{path}: corrupted side-car cache (negative counts)")
         ca.validate({"max_dist": d, "version": ca.__version__}, max_dist, ca.__version__)
-        hashes = np.fromfile(f, dtype="<u8", count=2 * n).reshape(n, 2)
+        hashes = np.fromfile(f, dtype="<u8", count=2 * n)
         off = np.fromfile(f, dtype="<i8", count=n_lists + 1)
         flat = np.fromfile(f, dtype="<i4", count=total)
-    if len(hashes) != n or len(off) != n_lists + 1 or len(flat) != total or (n_lists and off[-1] != total):
+    if len(hashes) != 2 * n or len(off) != n_lists + 1 or len(flat) != total:
         raise ValueError(f"{path}: truncated side-car cache")
-    return hashes, off, flat
+    if off[0] != 0 or off[-1] != total or (n_lists and bool(np.any(np.diff(off) < 0))):
+        raise ValueError(f"{path}: corrupted side-car cache (list offsets)")
+    if total and (int(flat.min()) < 0 or int(flat.max()) >= n):
+        raise ValueError(f"{path}: corrupted side-car cache (list member out of range)")
+    return hashes.reshape(n, 2), off, flat
 
 
 def _load_any(path, max_dist):

@@ -55,10 +55,13 @@ def cli_runs():
 
 
 def set_generator(monkeypatch, generator):
-    """force the candidate generator of the max-dist >= 2 kernels for a test: the band kernels, the prefix groups as small
-    inputs get them (whole-group walk), or the prefix groups with the positional filter that large inputs (>= 60k rows) get"""
+    """force the candidate generator of the max-dist >= 2 kernels for a test: "band" = the band kernels; "prefix" = the prefix
+    groups with round 2's WHOLE-GROUP walk (records row-major, BFK_PG_POS=0 — what token ids beyond 28 bits still get);
+    "prefix_pos" = the prefix groups with the positional filter, the default at every size since round 3"""
     monkeypatch.setenv("BFK_PG", "0" if generator == "band" else "1")
     if generator == "prefix_pos":
         monkeypatch.setenv("BFK_PG_POS", "1")
+    elif generator == "prefix":
+        monkeypatch.setenv("BFK_PG_POS", "0")
     else:
         monkeypatch.delenv("BFK_PG_POS", raising=False)

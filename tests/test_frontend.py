@@ -132,6 +132,9 @@ def _both_readers(path, sep="\t", id_col="id", feat="f"):
     ("id\tf\n a \t X \n", "\t"),                # spaces are data
     ("id\tf\r\na\tX\r\n\r\nb\tY Z\r\n", "\t"),   # CRLF file (the reference's fixtures are)
     ("id\tf\r\na\tX\r", "\t"),                 # CR at end of file
+    ("id\tf\nhCoV-19/Cote d\u2019Ivoire/\u00e9\u00e8/2021\tX Y\nM\u00fcnchen-7\tX\n\u6771\u4eac\U0001f9ec\tZ\n", "\t"),  # UTF-8 ids (2-, 3-, 4-byte forms)
+    ("id\tf\na\tX\u00e9 Y\nb\tY X\u00e9\nc\tX\u00e9 Y\n", "\t"),   # UTF-8 in the feature column, nothing filtered: opaque bytes
+    ("n\u00e4me\tid\tf\n\u00e9\ta\tX\n\u00e8\tb\tY\n", "\t"),     # UTF-8 in a column that is not used, and in its name
 ])
 @pytest.mark.parametrize("chunk_bytes", [None, "1", "5"])
 def test_reader_accepts_and_matches_pandas(text, sep, chunk_bytes, tmp_path, monkeypatch):
@@ -156,7 +159,7 @@ def test_reader_accepts_and_matches_pandas(text, sep, chunk_bytes, tmp_path, mon
     "id\tf\tf\na\tX\tY\n",            # duplicate column names
     "id\tf\n",                        # no rows
     "",                               # empty
-    "id\tf\na\tXé\n",            # non-ASCII
+    "\ufeffid\tf\na\tX\n",             # byte-order mark (pandas strips it from the first column name)
     "id\tf\n   \nc\td\n",             # whitespace-only line
 ])
 @pytest.mark.parametrize("chunk_bytes", [None, "3"])
@@ -191,10 +194,14 @@ def test_reader_checks_ids_in_parallel(dup_at, threads, tmp_path, monkeypatch):
         t.close()
 
 
-@pytest.mark.parametrize("bad,at", [("\x00", 5_000_000), ("\"", 9_000_001), ("\xc3\xa9", 123_457), ("\r", 7_654_321)])
+@pytest.mark.parametrize("bad,at", [("\x00", 5_000_000), ("\"", 9_000_001), ("\xe9", 123_457), ("\xc3", 999_999), ("\xa9", 1_000_000),
+                                    ("\xed\xa0\x80", 2_000_003), ("\xc0\xaf", 3_000_001), ("\xf4\x90\x80\x80", 4_000_002),
+                                    ("\r", 7_654_321)])
 def test_reader_byte_check_finds_a_bad_byte_anywhere(bad, at, tmp_path, monkeypatch):
     """the byte check looks at eight bytes at a time in parallel slices of a file read in parallel slices: a NUL, a quote,
-    a non-ASCII byte or a lone CR is found at any offset (word-aligned or not), and the clean file is accepted"""
+    a lone CR or bytes that are not valid UTF-8 (a Latin-1 byte, a lead byte without its tail — also right at a slice cut —, a
+    stray continuation byte, a surrogate, an overlong form, a code point beyond U+10FFFF) are found at any offset
+    (word-aligned or not), and the clean file is accepted"""
     monkeypatch.setenv("BFK_THREADS", "5")
     monkeypatch.setenv("BFK_CHUNK_BYTES", "1000000")
     line = "s{:07d}\tA1T C22G del:333:4\n"
@@ -209,6 +216,42 @@ def test_reader_byte_check_finds_a_bad_byte_anywhere(bad, at, tmp_path, monkeypa
     p.write_bytes(text[:at] + bad.encode("latin-1") + text[at + len(bad.encode("latin-1")):])
     with pytest.raises(_lib.Unsupported):
         _lib.Table.open(p, "\t", "id", "f")
+
+
+def test_reader_takes_utf8_at_any_offset_and_across_slice_cuts(tmp_path, monkeypatch):
+    """valid multi-byte sequences wherever the parallel slices are cut (a slice that starts inside a sequence leaves its head
+    to the slice in front): accepted, ids and clusters.tsv bytes equal to the pandas mirror's"""
+    monkeypatch.setenv("BFK_THREADS", "7")
+    names = ["s\u00e9q", "M\u00fcnchen", "\u6771\u4eac", "\U0001f9ec", "plain"]
+    text = "id\tf\n" + "".join(f"{names[i % 5]}{i}\tA{i % 11}T C{i % 7}G\n" for i in range(3000))
+    p = tmp_path / "in.tsv"
+    p.write_text(text, encoding="utf-8")
+    for cb in ("1", "7", "64", "1000"):
+        monkeypatch.setenv("BFK_CHUNK_BYTES", cb)
+        t, meta, info = _both_readers(p)
+        cid = (np.arange(info.n_unique) % 3).astype(np.int32)
+        t.write(tmp_path / "native.tsv", cid)
+        t.close()
+    raw = (tmp_path / "native.tsv").read_bytes()
+    assert raw.decode("utf-8").split("\n")[1].startswith("s\u00e9q0\t")
+
+
+def test_prepare_declines_non_ascii_features_under_a_grammar(tmp_path):
+    """the reference's token patterns are str patterns (\\d matches the digits of every script): a feature with non-ASCII
+    bytes is the pandas path's whenever a grammar is applied; ids may hold anything; raw / unfiltered runs take the bytes as
+    they are"""
+    t = _lib.Table.from_lists(["\u00e9a", "b"], ["A1T C\uff12G", "A1T"])
+    with pytest.raises(_lib.Unsupported):
+        t.prepare(" ", "covsonar_dna", True, True, 0, 0, 29903)
+    info = t.prepare(" ", "covsonar_dna", False, False, 0, 0, 29903)   # nothing to filter: verbatim
+    assert info.n_unique == 2 and t.feature(0) == "A1T C\uff12G"
+    info = t.prepare(" ", "raw", True, True, 5, 5, 29903)
+    assert info.n_unique == 2
+    t.close()
+    t = _lib.Table.from_lists(["\u00e9a", "b\u00fc"], ["A1T C2G", "A1T"])   # non-ASCII ids only: the grammar runs
+    info = t.prepare(" ", "covsonar_dna", True, True, 0, 0, 29903)
+    assert info.n_unique == 2 and t.id(0) == "\u00e9a" and t.id(1) == "b\u00fc"
+    t.close()
 
 
 def test_reader_declines_what_is_not_a_regular_file(tmp_path):

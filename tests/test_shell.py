@@ -113,6 +113,36 @@ def test_cli_dist0_bytes(runner, tmp_path, monkeypatch, cli_runs, scenario):
     assert exp.equals(pd.read_table(tmp_path / "clusters.tsv", sep="\t"))
 
 
+def test_cli_utf8_ids_take_the_native_path(runner, tmp_path, monkeypatch):
+    """accession names with accents / CJK / emoji no longer push a run to the pandas reader — the native
+    path reads, collapses and writes them (stdout and clusters.tsv byte-equal to the mirror's); invalid UTF-8 still goes to
+    pandas, which raises the reference's UnicodeDecodeError"""
+    from breakfast_amd import fastpath
+
+    names = ["hCoV-19/C\u00f4te d\u2019Ivoire/{}", "M\u00fcnchen-{}", "\u6771\u4eac-{}", "\U0001f9ec{}", "plain{}"]
+    rows = [(names[i % 5].format(i), f"A{300 + i % 4}T C{400 + i % 3}G del:5:3") for i in range(200)]
+    inp = tmp_path / "in.tsv"
+    inp.write_text("accession\tdna_profile\n" + "".join(f"{a}\t{f}\n" for a, f in rows), encoding="utf-8")
+    calls = []
+    real = fastpath.run
+    monkeypatch.setattr(fastpath, "run", lambda *a, **k: calls.append(real(*a, **k)) or calls[-1])
+    res = runner.invoke(console.main, ["--input-file", str(inp), "--max-dist", "0", "--outdir", str(tmp_path / "native")])
+    assert res.exit_code == 0, (res.output, res.exception)
+    assert calls == [True]                       # the fast path took the run
+    monkeypatch.setenv("BFK_NO_FASTPATH", "1")
+    ref = runner.invoke(console.main, ["--input-file", str(inp), "--max-dist", "0", "--outdir", str(tmp_path / "mirror")])
+    assert ref.exit_code == 0, (ref.output, ref.exception)
+    a, b = (tmp_path / "native" / "clusters.tsv").read_bytes(), (tmp_path / "mirror" / "clusters.tsv").read_bytes()
+    assert a == b and "M\u00fcnchen-1\t".encode() in a
+    strip = lambda out: [ln for ln in out.splitlines() if "outdir" not in ln.lower()]
+    assert strip(res.output) == strip(ref.output)
+    monkeypatch.delenv("BFK_NO_FASTPATH")
+    inp.write_bytes(inp.read_bytes().replace("M\u00fcnchen-1\t".encode(), b"M\xfcnchen-1\t"))   # Latin-1: not UTF-8
+    calls.clear()
+    bad = runner.invoke(console.main, ["--input-file", str(inp), "--max-dist", "0", "--outdir", str(tmp_path / "bad")])
+    assert calls == [False] and bad.exit_code != 0 and isinstance(bad.exception, UnicodeDecodeError)
+
+
 def test_cli_errors(runner, tmp_path, monkeypatch):
     monkeypatch.chdir(FIX)
     base = ["--outdir", str(tmp_path), "--max-dist", "0"]

@@ -62,6 +62,39 @@ def test_file_round_trip_and_magic(tmp_path, capsys):
     assert sidecar.wants_sidecar(None, tmp_path / "x.bfkc") and not sidecar.wants_sidecar(None, tmp_path / "x.pkl.gz")
 
 
+def test_damaged_sidecar_files_are_refused(tmp_path):
+    """a short header, negative counts, offsets that are not a non-decreasing run from 0 to `total`, members that are no rows
+    of the cached input: ValueError every time, never a clustering from wrapped indices"""
+    h = _lib.hash_rows(["a", "b", "c"])
+    good_off, good_flat = np.array([0, 2, 3], dtype=np.int64), np.array([0, 1, 2], dtype=np.int32)
+
+    def write(name, head, off, flat):
+        p = tmp_path / name
+        with open(p, "wb") as f:
+            f.write(sidecar.MAGIC)
+            f.write(head)
+            np.ascontiguousarray(h, dtype="<u8").tofile(f)
+            np.ascontiguousarray(off, dtype="<i8").tofile(f)
+            np.ascontiguousarray(flat, dtype="<i4").tofile(f)
+        return p
+
+    head = sidecar._HEAD.pack(1, 3, 2, 3)
+    assert sidecar.load(write("ok.bfkc", head, good_off, good_flat), 1)[2].tolist() == [0, 1, 2]
+    cases = {
+        "short_header.bfkc": (head[:10], good_off, good_flat),
+        "negative_rows.bfkc": (sidecar._HEAD.pack(1, -3, 2, 3), good_off, good_flat),
+        "negative_total.bfkc": (sidecar._HEAD.pack(1, 3, 2, -1), good_off, good_flat),
+        "off_not_from_zero.bfkc": (head, np.array([1, 2, 3]), good_flat),
+        "off_decreasing.bfkc": (sidecar._HEAD.pack(1, 3, 3, 3), np.array([0, 2, 1, 3]), good_flat),
+        "off_short_of_total.bfkc": (head, np.array([0, 1, 2]), good_flat),
+        "member_negative.bfkc": (head, good_off, np.array([0, -1, 2])),
+        "member_too_large.bfkc": (head, good_off, np.array([0, 1, 3])),
+    }
+    for name, (hd, off, flat) in cases.items():
+        with pytest.raises(ValueError):
+            sidecar.load(write(name, hd, off, flat), 1)
+
+
 def test_reference_pickle_reads_as_flat_arrays(cli_runs):
     """a cache written by the reference itself (tests/golden/ref_cache_testfile_d1.pkl.gz), loaded as the side-car's arrays"""
     h, off, flat = sidecar._load_any(GOLD / "ref_cache_testfile_d1.pkl.gz", 1)
