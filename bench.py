@@ -11,26 +11,30 @@ with the children's status; under a launcher (WORLD_SIZE set) it is one rank.
 
 What the ONE JSON line holds (every number is measured in this run unless it says otherwise):
 
-  value / ms_per_step    a step = one pass of the hot path over the batch, CSR of the unique profiles RESIDENT IN
-                         HBM -> canonical labels in HBM (+ RCCL label merge for N > 1); EXACTLY --steps steps timed
-                         between barrier + synchronize; value = N_u(N_u-1)/2 pairs resolved per step / time.
-  sustained              the same steps for >= 1 s (so that an outside sampler sees the GPU busy)
-  ms_per_step_cold       first step after a bind, host-timed single step incl. its launch (median of 5 re-binds); the same
-                         kernels as a timed step (no step depends on an earlier one)
-  t_cluster_host_ms      metric (1) as SURVEY 8(d) defines it: N_u profile strings in host memory -> labels in host
-                         memory through ONE C-ABI call (bfk_cluster_text: text H2D, device tokeniser + vocabulary + CSR,
-                         kernels, labels D2H): first call, steady state, and with a text buffer the driver has never
-                         seen; value_host_inclusive = pairs / steady time (PCIe-inclusive; never `value`).
-                         `tokeniser`: phase times and the text-bytes-once roofline of the tokenising kernels;
-                         `host_tokeniser_path`: round 2's route (bfk_build_csr on the host cores + bfk_cluster_csr)
+  value / ms_per_step    a step = one pass of the WHOLE hot path over the batch with its input resident in HBM: the N_u profile
+                         strings (one byte buffer + offsets, in device memory; the steps rotate over enough distinct copies
+                         that the text does not come out of the Infinity Cache) -> separator scan, vocabulary table,
+                         first-appearance ids, CSR (bfk_text.hip) -> clustering kernels -> canonical labels in HBM (+ RCCL label
+                         merge for N > 1).  EXACTLY --steps steps timed between barrier + synchronize;
+                         value = N_u(N_u-1)/2 pairs resolved per step / time.  (Rounds 1-3 timed the clustering kernels on a
+                         resident CSR here; that figure is now value_resident_csr.)
+  value_resident_csr     the second half of the step alone: CSR resident in HBM -> labels (asynchronous launches)
+  t_cluster_host_ms      the PCIe-inclusive figures (never `value`): N_u strings in HOST memory -> labels in HOST memory through
+                         ONE C-ABI call (bfk_cluster_text): first call; a fresh pageable buffer per call (median of 9);
+                         the same pageable buffer again; a pinned buffer from bfk_host_alloc.
+                         value_host_inclusive = pairs / fresh-pageable-buffer time.
+  sustained              the same steps as `value` for >= 1 s (so that an outside sampler sees the GPU busy)
   clusters_tsv_wall_s    metric (2): a fresh subprocess of the CLI, input file -> clusters.tsv, sha256 of the output
-                         checked against tests/golden/sha256.json (the digest of the reference's own output)
-  all_pairs              the same step with the all-pairs kernels forced (k_sig .. k_prefilter .. k_verify): the
+                         checked against tests/golden/sha256.json (the digest of the reference's own output); with the CLI's
+                         default fast exit and with an ordinary process exit (clusters_tsv_wall_ordinary_exit_s)
+  all_pairs              the resident-CSR step with the all-pairs kernels forced (k_sig .. k_prefilter .. k_verify): the
                          design north_star describes; the default at max-dist 1 is the variant join
-  roofline               dominant kernel of the default step: bytes the executed algorithm must move (compulsory
-                         reads + writes of that kernel) / its mean duration (HIP events on the launch stream) vs the
-                         8 TB/s HBM peak.  `reference_equivalent` keeps SURVEY 8(d)'s untiled operand-stream figure
-                         (what the reference's CPU kernel touches) for comparison only — it is never `achieved`.
+  roofline               the step's dominant kernel (longest measured duration — at 100k rows the tokeniser's k_tok_hash):
+                         bytes the executed algorithm must move (compulsory reads + writes of that kernel) / its duration
+                         (HIP events on the launch stream, inside libbfk) vs the 8 TB/s HBM peak; `second_kernel` = the
+                         dominant kernel of the other half (k_join / k_prefilter / k_pgwalk16 / k_verify_connected).
+                         `reference_equivalent` keeps SURVEY 8(d)'s untiled operand-stream figure (what the reference's CPU
+                         kernel touches) for comparison only — it is never `achieved`.
   cpu_baseline           the scikit-learn kernel the reference calls, timed on this host's cores on a bounded sample
                          (oracle/sk_port.py); the C oracle leg beside it.  bench-only use of oracle/.
 """
@@ -192,7 +196,9 @@ def self_launch(n: int) -> int:
 
 def cli_wall(n_rows: int, d: int, indels: bool):
     """metric (2): input file -> clusters.tsv through the CLI in a FRESH process (imports, library load, context,
-    module load all inside), twice (the second run has the input in the page cache and the code object cache warm)."""
+    module load all inside), five times with each way of ending the process: the CLI's default (a successful run flushes,
+    joins its preload thread and ends by os._exit: no interpreter / HIP-runtime teardown) and an ordinary exit
+    (BFK_FAST_EXIT=0).  Both walls go into the line."""
     from breakfast_amd import synth
 
     tmp = Path(tempfile.mkdtemp(prefix="bfk_bench_"))
@@ -200,23 +206,29 @@ def cli_wall(n_rows: int, d: int, indels: bool):
     kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
     synth.generate_tsv(inp, n_rows, **kw)
     args = ["--input-file", str(inp), "--max-dist", str(d)] + (["--no-skip-del", "--no-skip-ins"] if indels else [])
-    runs = []
+    res = {"rows": n_rows}
     digest = None
-    for i in range(5):
-        out = tmp / f"out{i}"
-        t0 = time.perf_counter()
-        r = subprocess.run([sys.executable, "-m", "breakfast_amd", *args, "--outdir", str(out)], cwd=str(ROOT),
-                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        dt = time.perf_counter() - t0
-        if r.returncode != 0:
-            return {"error": r.stderr.decode(errors="replace")[-400:]}
-        runs.append(round(dt, 4))
-        digest = hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest()
-    res = {"seconds": min(runs), "median_s": sorted(runs)[len(runs) // 2], "runs_s": runs,
-           "what": "python -m breakfast_amd --input-file <tsv> --outdir <dir>, fresh process each (interpreter start, imports, "
-                   "libbfk + HIP runtime load, context, kernels, writer); min of 5 (the HIP runtime's device open varies by "
-                   "0.1-0.2 s between runs on one box)",
-           "rows": n_rows, "clusters_sha256": digest}
+    for mode, fast in (("fast_exit", "1"), ("ordinary_exit", "0")):
+        runs = []
+        for i in range(5):
+            out = tmp / f"out_{mode}{i}"
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "breakfast_amd", *args, "--outdir", str(out)], cwd=str(ROOT),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env={**os.environ, "BFK_FAST_EXIT": fast})
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr.decode(errors="replace")[-400:]}
+            runs.append(round(dt, 4))
+            dg = hashlib.sha256((out / "clusters.tsv").read_bytes()).hexdigest()
+            if digest is not None and dg != digest:
+                return {"error": "clusters.tsv differs between runs"}
+            digest = dg
+        res[mode] = {"seconds": min(runs), "median_s": sorted(runs)[len(runs) // 2], "runs_s": runs}
+    res.update(seconds=res["fast_exit"]["seconds"], median_s=res["fast_exit"]["median_s"], clusters_sha256=digest,
+               what="python -m breakfast_amd --input-file <tsv> --outdir <dir>, fresh process each (interpreter start, imports, "
+                    "libbfk + HIP runtime load, context, kernels, writer); min and median of 5 per exit mode (the HIP runtime's "
+                    "device open varies by 0.1-0.2 s between runs on one box); fast_exit = the CLI's default (os._exit after "
+                    "flushing), ordinary_exit = BFK_FAST_EXIT=0")
     gold = json.loads((ROOT / "tests" / "golden" / "sha256.json").read_text())
     key = f"syn{n_rows}_d{d}"
     if not indels and key in gold:
@@ -228,8 +240,8 @@ def cli_wall(n_rows: int, d: int, indels: bool):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=0, help="input sequences (default: 100000 on one GPU, 1000000 on several)")
     ap.add_argument("--max-dist", type=int, default=1)
     ap.add_argument("--indels", action="store_true", help="config 5 generator: p_del=0.05 p_ins=0.01, indels kept")
@@ -237,9 +249,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="only the timed steps + roofline (no host / CLI / CPU legs)")
     ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join", "prefix"], help="candidate generator of the main leg")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="experiment (not the contract's default): P independent contexts on P streams take the steps "
-                         "round-robin, so that the label exchange of one step overlaps the kernels of the next")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -254,7 +263,7 @@ def main():
     # row-sharded across the ranks — the same input for every N (strong scaling)
     n_rows = a.rows or (100000 if world == 1 else 1000000)
     d = a.max_dist
-    full = world == 1 and not a.quick and a.pipeline == 1
+    full = world == 1 and not a.quick
 
     # metric (2) first: a fresh CLI process, before this process initialises the GPU
     cli = cli_wall(n_rows, d, a.indels) if (full and rank == 0) else None
@@ -286,27 +295,38 @@ def main():
     kw = dict(p_del=0.05, p_ins=0.01) if a.indels else {}
     rows = list(dict.fromkeys(generate_profiles(n_rows, **kw)))  # collapse_duplicates: unique profiles
     n_u = len(rows)
+    # the hot path's input as the C-ABI takes it: the N_u profile strings as ONE byte buffer + int64 offsets
+    buf, off = _lib.pack_rows(rows)
+    T = len(buf)
 
-    # ---- metric (1), host-inclusive: strings in host memory -> labels in host memory through ONE C-ABI call
+    # ---- metric (1), host-inclusive (PCIe inside; never `value`): strings in HOST memory -> labels in HOST memory through
+    # ONE C-ABI call, bfk_cluster_text
     host = None
     if full:
-        raw = [r.encode() for r in rows]
-        off = np.zeros(n_u + 1, dtype=np.int64)
-        np.cumsum(np.fromiter((len(r) for r in raw), dtype=np.int64, count=n_u), out=off[1:])
-        buf = b"".join(raw)
-        del raw
+        lab_out = np.empty(n_u, dtype=np.int32)
 
-        def one_shot(b=buf):
+        def one_shot(b):
             t0 = time.perf_counter()
-            lab, _, nnz_, nv_ = _lib.cluster_text(b, off, " ", d, want_stats=False)
+            lab, _, nnz_, nv_ = _lib.cluster_text(b, off, " ", d, want_stats=False, labels_out=lab_out)
             return (time.perf_counter() - t0) * 1e3, lab, nnz_, nv_
 
-        t_first, lab_first, nnz_t, nv_t = one_shot()
-        reps = sorted(one_shot()[0] for _ in range(9))
+        t_first, lab_first, nnz_t, nv_t = one_shot(buf)
+        lab_first = lab_first.copy()
+        reps = sorted(one_shot(buf)[0] for _ in range(9))
         fresh = []
-        for _ in range(3):  # a buffer the driver has never seen: its pages are pinned on the fly during the copy
+        for _ in range(9):  # a pageable buffer the driver has never seen, a new one per call: its pages are pinned on the way
             b2 = bytes(bytearray(buf))
             fresh.append(one_shot(b2)[0])
+            del b2
+        pins = []
+        for _ in range(4):  # the caller owns pinned memory (bfk_host_alloc) and builds its text there: four buffers in turn
+            pb = _lib.PinnedBuffer(T)
+            pb.view[:] = np.frombuffer(buf, dtype=np.uint8)
+            pins.append(pb)
+        one_shot(pins[0])
+        pinned = sorted(one_shot(pins[i % 4])[0] for i in range(12))
+        for pb in pins:
+            pb.free()
 
         def old_route():
             t0 = time.perf_counter()
@@ -316,77 +336,60 @@ def main():
             return (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
 
         old = [old_route() for _ in range(3)]
-        # the tokeniser by itself: phase times (HIP events) of bfk_ctx_build_csr on a context of its own
+        # the H2D copy by itself (HIP events around it, a context of its own)
         tctx = _lib.Context(0)
         tctx.set_profiling(True)
-        tph = []
-        for _ in range(7):
+        h2d = []
+        for _ in range(5):
             tctx.build_csr(buf, off, " ")
-            tph.append(tctx.text_stats())
+            h2d.append(tctx.text_stats()["ms_h2d"])
         tctx.close()
-        tmed = {kk: sorted(x[kk] for x in tph)[len(tph) // 2] for kk in ("ms_h2d", "ms_scan", "ms_hash", "ms_head", "ms_ids", "ms_total")}
-        t_kern = tmed["ms_scan"] + tmed["ms_hash"] + tmed["ms_ids"]
-        t_hash = max(tmed["ms_hash"] - tmed["ms_head"], 1e-6)  # k_tok_hash itself (the event bracket; ~3 us more than the kernel)
-        tok_tr = measured_traffic("bfk::k_tok_hash", f"tok_{n_rows}")
-        host = {"first_call": round(t_first, 3), "steady": round(reps[len(reps) // 2], 3), "steady_min": round(reps[0], 3),
-                "fresh_text_buffer": [round(x, 3) for x in fresh],
-                "what": "N_u profile strings as one byte buffer + offsets (the C-ABI's input) -> bfk_cluster_text: text + offsets "
-                        "H2D from the caller's pageable buffer, device tokeniser + first-appearance vocabulary + CSR "
-                        "(bfk_text.hip), clustering kernels, labels D2H; first_call includes context creation, code-object "
-                        "load and allocations; steady = median of 9 further calls on the same buffer (the driver keeps its "
-                        "pages pinned); fresh_text_buffer = calls on a new copy of the text each",
-                "text_bytes": len(buf), "nnz": nnz_t, "n_vocab": nv_t,
-                "tokeniser": {
-                    "phases_ms": tmed, "kernels_ms": t_kern,
-                    "roofline": {"bound": "hbm", "kernel": "k_tok_hash (dominant of the tokenising kernels)",
-                                 "algorithmic_bytes_per_launch": len(buf) + 4 * nnz_t,
-                                 "algorithmic_bytes_what": "every text byte once + one 4-byte slot per token written",
-                                 "kernel_ms": t_hash,
-                                 "achieved": (len(buf) + 4 * nnz_t) / (t_hash * 1e-3) / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": (len(buf) + 4 * nnz_t) / (t_hash * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": tok_tr["bytes"] if tok_tr else None, "traffic_detail": tok_tr,
-                                 "all_tokenising_kernels": {
-                                     "bytes": 2 * len(buf) + 12 * nnz_t + 4 * n_u,
-                                     "what": "text twice (scan, hash) + slot written, read, id written per token + indptr",
-                                     "GBps": (2 * len(buf) + 12 * nnz_t + 4 * n_u) / (t_kern * 1e-3) / 1e9 if t_kern > 0 else None},
-                                 "pcie": {"GBps": len(buf) / (tmed["ms_h2d"] * 1e-3) / 1e9 if tmed["ms_h2d"] > 0 else None,
-                                          "note": "the text crosses PCIe once; that copy, not a kernel, is most of the call"}}},
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        host = {"first_call": round(t_first, 3), "steady_same_pageable_buffer": round(reps[len(reps) // 2], 3),
+                "fresh_pageable_buffer": round(med(fresh), 3), "fresh_pageable_buffer_runs": [round(x, 3) for x in fresh],
+                "pinned_buffer": round(pinned[len(pinned) // 2], 3), "pinned_buffer_min": round(pinned[0], 3),
+                "h2d_ms": round(med(h2d), 3), "h2d_GBps": T / (med(h2d) * 1e-3) / 1e9 if med(h2d) > 0 else None,
+                "what": "N_u profile strings as one byte buffer + offsets (the C-ABI's input) in HOST memory -> bfk_cluster_text: "
+                        "text + offsets H2D, device tokeniser + first-appearance vocabulary + CSR (bfk_text.hip), clustering "
+                        "kernels, labels D2H into the caller's array.  first_call includes context creation, code-object load "
+                        "and allocations; fresh_pageable_buffer = median of 9 calls, EACH on a newly allocated pageable copy of "
+                        "the text (the driver pins its pages on the way); steady_same_pageable_buffer = 9 further calls on one "
+                        "buffer (the driver keeps its pages pinned); pinned_buffer = the text built in memory from "
+                        "bfk_host_alloc (four buffers in turn, median of 12)",
+                "text_bytes": T, "nnz": nnz_t, "n_vocab": nv_t,
                 "host_tokeniser_path": {"build_csr_ms": round(sorted(x[0] for x in old)[1], 3),
                                         "cluster_csr_ms": round(sorted(x[1] for x in old)[1], 3),
                                         "what": "round 2's route: bfk_build_csr on the host cores, then bfk_cluster_csr (CSR H2D)"}}
 
-    indptr, indices, n_vocab = _lib.build_csr(rows, " ")
+    indptr, indices, n_vocab = _lib.build_csr(rows, " ")  # (host tokeniser: the CSR of the resident-CSR leg and of the CPU baseline)
     nnz = int(indptr[-1])
     k = np.diff(indptr)
 
-    # one context on torch's current stream; with --pipeline P, P of them, each on a stream of its own
-    pipe = max(1, a.pipeline)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(pipe - 1)]
-    engs, scs = [], []
-    for s_ in streams:
-        with torch.cuda.stream(s_):
-            e_ = GpuEngine(local_rank)
-            e_.ctx.set_candidate_path(a.path)
-            c_ = ShardedClusterer(e_, rank, world, a.merge)
-            c_.bind(indptr, indices)
-        engs.append(e_)
-        scs.append(c_)
-    eng, sc = engs[0], scs[0]
+    # ---- the profile text RESIDENT IN HBM: enough distinct device copies that a step's text does not come out of the 256 MiB
+    # Infinity Cache (the steps take them in turn), each in a buffer of bfk_text_device_bytes (the library pads the tail)
+    need = _lib.text_device_bytes(T)
+    n_copies = int(max(4, min(16, math.ceil(320e6 / max(T, 1)))))
+    h_text = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+    d_texts = []
+    for _ in range(n_copies):
+        t_ = torch.empty(need, dtype=torch.uint8, device="cuda")
+        t_[:T].copy_(h_text)
+        d_texts.append(t_)
+    d_off = torch.from_numpy(off).cuda()
+    torch.cuda.synchronize()
 
-    def run_steps(count):
-        for i in range(count):
-            if pipe == 1:
-                sc.step(d)
-            else:
-                with torch.cuda.stream(streams[i % pipe]):
-                    scs[i % pipe].step(d)
+    eng = GpuEngine(local_rank)
+    eng.ctx.set_candidate_path(a.path)
+    sc = ShardedClusterer(eng, rank, world, a.merge)
+    step_no = [0]
 
-    def sync_all():
-        sts = [e_.sync() for e_ in engs]
-        worst = dict(sts[0])
-        worst["n_retry_slices"] = max(x["n_retry_slices"] for x in sts)
-        return worst
+    def text_step():
+        t_ = d_texts[step_no[0] % n_copies]
+        step_no[0] += 1
+        return sc.step_text(t_.data_ptr(), T, d_off.data_ptr(), n_u, " ", d)
+
+    def csr_step():
+        return sc.step(d)
 
     def barrier():
         torch.cuda.synchronize()
@@ -394,13 +397,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def warm(count):
+    def warm(step, count):
         # a candidate-queue overflow (dense inputs) is repaired inside sync() and grows the queue, so repeat until a
         # step runs clean: the timed steps must be complete single-pass steps
         for _ in range(6):
-            run_steps(max(count, pipe))
-            st0 = sync_all()
-            again = int(st0["n_retry_slices"] != 0)
+            for _ in range(max(count, 1)):
+                step()
+            again = int(eng.sync()["n_retry_slices"] != 0)
             if world > 1:  # every rank must run the same number of steps (each step holds a collective)
                 tt = torch.tensor([again], dtype=torch.int32, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -408,24 +411,40 @@ def main():
             if not again:
                 return
 
-    def timed(count):
+    def timed(step, count):
         barrier()
         t0 = time.perf_counter()
-        run_steps(count)
+        for _ in range(count):
+            step()
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        st_ = sync_all()  # checks the device-side overflow / error flags of the last timed step(s)
+        st_ = eng.sync()  # checks the device-side overflow / error flags of the last timed step(s)
         if st_["n_retry_slices"] != 0:
             raise SystemExit("bench invalid: a timed step overflowed the candidate queue")
         return elapsed, st_
 
-    def profiled(count=64):
-        # per-phase durations: HIP events on the launch stream, recorded inside libbfk around each phase of each
-        # step (ring of 64 event sets), over a separate pass of the same steps
+    def profiled_text(count=16):
+        # per-phase durations of whole steps: HIP events on the launch stream, recorded inside libbfk around the tokeniser's
+        # phases and around each phase of the clustering kernels, over a separate pass of the same steps
+        eng.ctx.set_profiling(True)
+        sts, tks = [], []
+        for _ in range(count):
+            text_step()
+            sts.append(eng.sync())
+            tks.append(eng.ctx.text_stats())
+        eng.ctx.set_profiling(False)
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        st_ = dict(sts[-1])
+        for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total"):
+            st_[kk] = med([x[kk] for x in sts])
+        tk_ = {kk: med([x[kk] for x in tks]) for kk in ("ms_scan", "ms_hash", "ms_head", "ms_ids", "ms_total")}
+        return st_, tk_
+
+    def profiled_csr(count=64):
         eng.ctx.set_profiling(True)
         for _ in range(min(count, 64)):
             sc.step(d)
@@ -433,19 +452,19 @@ def main():
         eng.ctx.set_profiling(False)
         return st_
 
-    # ---- the contract's timed region: W warm-up steps, EXACTLY K steps
-    warm(a.warmup)
-    elapsed, st_timed = timed(a.steps)
+    # ---- the contract's timed region: W warm-up steps, EXACTLY K steps; a step = profile strings in HBM -> labels in HBM
+    warm(text_step, a.warmup)
+    elapsed, st_timed = timed(text_step, a.steps)
     labels = sc.labels[0][:n_u].cpu().numpy()
     ms_step = elapsed / a.steps * 1e3
 
     # ---- the same steps for >= 1 s (long enough for an outside sampler of GPU utilisation to see the device busy)
     sustained = None
-    if world == 1:
-        n_sus = int(min(400000, max(a.steps, math.ceil(1.0 / max(ms_step * 1e-3, 1e-6)))))
-        e2, _ = timed(n_sus)
+    if world == 1 and not a.quick:
+        n_sus = int(min(100000, max(a.steps, math.ceil(1.0 / max(ms_step * 1e-3, 1e-6)))))
+        e2, _ = timed(text_step, n_sus)
         sustained = {"steps": n_sus, "seconds": round(e2, 4), "ms_per_step": e2 / n_sus * 1e3}
-    st = profiled()
+    st, tk = profiled_text()
     edges_per_rank = None
     if world > 1:
         ne = torch.tensor([st["n_edges"]], dtype=torch.int64, device="cuda")
@@ -453,11 +472,24 @@ def main():
         dist.all_gather(allne, ne)
         edges_per_rank = [int(x.item()) for x in allne]
 
+    # ---- the second half of the step by itself: the CSR RESIDENT in HBM -> labels in HBM (what rounds 1-3 printed as `value`)
+    sc.bind(indptr, indices)
+    warm(csr_step, a.warmup)
+    n_res = a.steps if a.quick else int(max(a.steps, min(20000, math.ceil(0.2 / max(ms_step * 1e-3, 1e-6)))))
+    e_res, _ = timed(csr_step, n_res)
+    lab_res = sc.labels[0][:n_u].cpu().numpy()
+    st_res = profiled_csr()
+    resident = {"ms_per_step": e_res / n_res * 1e3, "steps": n_res, "value": n_u * (n_u - 1) / 2 * n_res / e_res,
+                "labels_equal_text_steps": bool(np.array_equal(lab_res, labels)),
+                "phases_ms": {kk: st_res[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
+                "what": "the clustering kernels alone on a CSR that stays bound (no tokeniser, no bind): asynchronous launches, "
+                        "the same barriers around the timed steps"}
+
     # ---- N > 1: where a step's time goes on this rank (torch events on the launch stream, a separate pass of 16 steps:
     # the rank's shard of the kernels, the label exchange, the merge) and — rank 0 alone, the others idle — the SAME
     # workload on one GPU in the same run
     exchange = one_gpu = None
-    if world > 1 and a.merge == "allgather" and pipe == 1:
+    if world > 1 and a.merge == "allgather":
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(16)]
         with eng.run():  # (the engine's stream: where a step's kernels and collectives go)
             for e4 in evs:
@@ -477,37 +509,45 @@ def main():
         dist.all_gather(allt, tt)
         exchange = {"per_rank_ms": [{"shard_kernels": round(float(x[0]), 4), "all_gather": round(float(x[1]), 4),
                                      "merge_flatten": round(float(x[2]), 4)} for x in allt],
+                    "tokeniser_ms_every_rank": tk,
                     "payload_bytes_per_rank": 4 * n_u,
-                    "what": "median of 16 steps, events on the launch stream of each rank; all_gather includes waiting for the "
-                            "slowest rank's shard"}
+                    "what": "median of 16 steps on the bound CSR, events on the launch stream of each rank; all_gather includes "
+                            "waiting for the slowest rank's shard; the tokeniser (replicated: every rank builds the whole CSR) "
+                            "is listed apart"}
     if world > 1:
         dist.barrier()
         if rank == 0:
             sc1 = ShardedClusterer(eng, 0, 1, a.merge)
-            sc1.bind(indptr, indices)
+
+            def text_step1():
+                t_ = d_texts[step_no[0] % n_copies]
+                step_no[0] += 1
+                return sc1.step_text(t_.data_ptr(), T, d_off.data_ptr(), n_u, " ", d)
+
             for _ in range(3):
-                for _ in range(max(5, min(a.warmup, 20))):
-                    sc1.step(d)
+                for _ in range(max(3, min(a.warmup, 10))):
+                    text_step1()
                 if eng.sync()["n_retry_slices"] == 0:
                     break
-            k1 = max(20, min(a.steps, 200))
+            k1 = max(10, min(a.steps, 100))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(k1):
-                sc1.step(d)
+                text_step1()
             torch.cuda.synchronize()
             e1 = time.perf_counter() - t0
             st1 = eng.sync()
             lab1 = sc1.labels[0][:n_u].cpu().numpy()
             one_gpu = {"ms_per_step": e1 / k1 * 1e3, "steps": k1, "value": n_u * (n_u - 1) / 2 * k1 / e1,
                        "labels_equal_n_gpu_run": bool(np.array_equal(lab1, labels)), "path": st1["path"],
-                       "what": "the same input clustered by rank 0's GPU alone (world 1), timed after the N-rank steps while "
-                               "the other ranks wait: ms_per_step of this line / this = the speed-up the N GPUs gave"}
+                       "what": "the same steps (text in HBM -> labels) by rank 0's GPU alone (world 1), timed after the N-rank "
+                               "steps while the other ranks wait: ms_per_step of this line / this = the speed-up the N GPUs gave"}
+            sc.bind(indptr, indices)
         dist.barrier()
 
-    # ---- first step after a bind: k_verify launched, nothing memoised about this CSR
+    # ---- first step after a bind of a CSR, ONE step host-timed incl. its launch and the sync
     cold = None
-    if world == 1 and pipe == 1:
+    if world == 1:
         ts = []
         for _ in range(5):
             sc.bind(indptr, indices)
@@ -518,25 +558,26 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
             eng.sync()
         cold = sorted(ts)[len(ts) // 2]
-        warm(5)
+        warm(csr_step, 5)
 
-    # ---- the all-pairs kernels on the same workload (north_star's design), when the main leg ran the join
+    # ---- the all-pairs kernels on the same CSR (north_star's design), when the main leg ran the join
     join = st.get("path", 0) == 1 and n_u > 0
     prefix = st.get("path", 0) == 2
     allpairs = None
     if full and join:
         eng.ctx.set_candidate_path("allpairs")
-        warm(a.warmup)
-        n_ap = int(min(50000, max(200, math.ceil(0.2 / max(ms_step * 1.5e-3, 1e-6)))))
-        e3, _ = timed(n_ap)
+        warm(csr_step, a.warmup)
+        n_ap = int(min(50000, max(200, math.ceil(0.2 / max(resident["ms_per_step"] * 1.5e-3, 1e-6)))))
+        e3, _ = timed(csr_step, n_ap)
         lab_ap = sc.labels[0][:n_u].cpu().numpy()
-        st_ap = profiled()
+        st_ap = profiled_csr()
         w = st_ap["sig_words"]
         t_pf = st_ap["ms_prefilter"] * 1e-3
         cyc_per_slot = w * (2.6 + 4.3) + 4.3  # measured issue cost per pair slot (tools/ubench/valu_rate.hip)
         ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
         allpairs = {
             "ms_per_step": e3 / n_ap * 1e3, "steps": n_ap, "value": n_u * (n_u - 1) / 2 * n_ap / e3,
+            "what": "CSR resident -> labels with the band kernels forced (compare with value_resident_csr)",
             "labels_equal_default_path": bool(np.array_equal(lab_ap, labels)),
             "phases_ms": {kk: st_ap[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
             "counters": {kk: st_ap[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges", "n_work_items")},
@@ -549,7 +590,6 @@ def main():
                                  "note": "sorted signatures + row records once; the tile loop re-reads them from L2"}},
         }
         eng.ctx.set_candidate_path(a.path)
-        warm(5)
 
     if rank == 0:
         b_ref, merged_pairs, resolved = reference_equivalent_bytes(k, d, nnz)
@@ -562,7 +602,7 @@ def main():
             # lookups and the rows of the few matches are algorithm-internal traffic, not compulsory
             comp = (4 * nnz + 12 * n_u) / world
             comp_what = "4*nnz tokens + 4*N_u extents + 8*N_u row hashes, read once"
-            step_bytes = (8 * nnz + 44 * n_u) / world
+            clus_bytes = (8 * nnz + 44 * n_u) / world
             # the exact certificate of a match compares the row with its PARTNER row, which another wave — on another XCD's
             # L2 seven times out of eight — streamed: those tokens cross the fabric a second time whatever the layout
             join_partner_bytes = st["n_candidates"] * (4 * k_mean + 8)
@@ -598,19 +638,19 @@ def main():
                 comp_what = ("read / written once: the group order (16 B record + 8 B position/count per record, (d+2) records "
                              "per row), 16 B of length / signature / offset per row, 24 B per queued pair")
                 visits_what = "16 B per group member visited (a member is visited once by every row in front of it in its group)"
-            # whole step: tokens twice (k_pgfreq sample + k_pgkeys), 8 B per record out, three radix passes (8 B in and
+            # clustering kernels: tokens twice (k_pgfreq sample + k_pgkeys), 8 B per record out, three radix passes (8 B in and
             # out each), k_pgplace (8 B in, 16 B gathered, 24 B out), then the two kernels above, flatten
-            step_bytes = (4 * nnz + 20 * n_u) / world + 8 * R + 3 * 16 * R + 48 * R + once_pgjoin + once_verify + 8 * n_u
+            clus_bytes = (4 * nnz + 20 * n_u) / world + 8 * R + 3 * 16 * R + 48 * R + once_pgjoin + once_verify + 8 * n_u
         else:
             dom = f"k_prefilter<W={w}>"
             comp = (4 * w * n_u + 16 * n_u) / world
             comp_what = "sorted first-level signatures (4*W*N_u) + row records (16*N_u), read once"
-            step_bytes = (4 * nnz + (84 + 16 * w) * n_u) / world
+            clus_bytes = (4 * nnz + (84 + 16 * w) * n_u) / world
         achieved = comp / t_dom / 1e9 if t_dom > 0 else None
         wl_key = f"{n_rows}_d{d}{'_indels' if a.indels else ''}_{'join' if join else 'prefix' if prefix else 'allpairs'}"
         tr = measured_traffic("bfk::k_join" if join else ("void bfk::" + dom) if (prefix and dom.startswith("k_verify")) else
                               "void bfk::k_pgwalk16" if prefix else "void bfk::k_prefilter", wl_key) if world == 1 else None
-        roof = {
+        roof_cluster = {
             "bound": "hbm", "kernel": dom,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS if achieved else None,
@@ -622,44 +662,56 @@ def main():
                                        "note": "re-reads served by L2 / Infinity Cache: work the kernel does, not bytes it must "
                                                "move once; never part of `frac`"}} if prefix else {}),
             "kernel_ms": t_dom * 1e3,
-            "kernel_ms_source": "HIP events on the launch stream around the kernel, mean of 64 steps (includes the "
-                                "launch gap, ~3 us more than rocprofv3's kernel time: profiles/)",
-            "whole_step": {"bytes": step_bytes, "GBps": step_bytes / (ms_step * 1e-3) / 1e9,
-                           "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "compulsory bytes of every kernel of the step / ms_per_step"},
-            "reference_equivalent": {
-                "bytes": b_ref / world, "pairs_in_reference_band": merged_pairs,
-                "equivalent_GBps": b_ref / world / (ms_step * 1e-3) / 1e9,
-                "note": "SURVEY 8(d) untiled operand-stream bytes, 4(k_i+k_j) per pair of the reference's length band + "
-                        "8 B per pruned pair: what an untiled all-pairs merge touches.  These kernels never stream those "
-                        "operands, so this is an algorithmic-speedup figure, not a bandwidth claim"},
         }
         if not join and not prefix:
             t_pf = t_dom
             cyc_per_slot = w * (2.6 + 4.3) + 4.3
             ceiling = 64 * 1024 * 2.4e9 / cyc_per_slot
-            roof["valu"] = {"pair_slots": st["pairs_filtered"], "pair_slots_per_s": st["pairs_filtered"] / t_pf if t_pf > 0 else None,
-                            "measured_issue_ceiling_slots_per_s": ceiling,
-                            "frac_of_measured_ceiling": st["pairs_filtered"] / t_pf / ceiling if t_pf > 0 else None,
-                            "note": "the pair kernel is VALU-issue-bound (xor + popcount + min per 32-bit signature "
-                                    "word per pair slot), its working set lives in L2; this is the binding roofline"}
+            roof_cluster["valu"] = {"pair_slots": st["pairs_filtered"], "pair_slots_per_s": st["pairs_filtered"] / t_pf if t_pf > 0 else None,
+                                    "measured_issue_ceiling_slots_per_s": ceiling,
+                                    "frac_of_measured_ceiling": st["pairs_filtered"] / t_pf / ceiling if t_pf > 0 else None,
+                                    "note": "the pair kernel is VALU-issue-bound (xor + popcount + min per 32-bit signature "
+                                            "word per pair slot), its working set lives in L2; this is the binding roofline"}
         elif join:
-            roof["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
-            roof["traffic_breakdown"] = {
+            roof_cluster["lookups"] = {"count": st["pairs_filtered"], "per_s": st["pairs_filtered"] / t_dom if t_dom > 0 else None}
+            roof_cluster["traffic_breakdown"] = {
                 "matches": st["n_candidates"], "partner_row_bytes": join_partner_bytes,
                 "algorithmic_bytes_incl_partner_rows": comp + join_partner_bytes,
                 "frac_incl_partner_rows": (comp + join_partner_bytes) / t_dom / 1e9 / HBM_PEAK_GBS if t_dom > 0 else None,
-                "measured": "FETCH_SIZE of k_join, separate --pmc passes with parts of the kernel switched off (BFK_JOIN_DEBUG, "
-                            "100k rows, builder-run, DESIGN 6c): 34.8 MB as shipped; 19.2 MB without the certificate (its reads: "
-                            "15.6 MB = the partner rows of ~1e5 matches); 10.8 MB without certificate and table probes (probes: "
-                            "8.4 MB of 64-byte lines for 16-byte slot pairs)",
-                "note": "`frac` above prices the kernel against the bytes read ONCE (tokens, extents, hashes); the partner rows "
-                        "are a second trip of bytes already counted there, served by the Infinity Cache (the counter includes its hits)"}
+                "note": "`frac` prices the kernel against the bytes read ONCE (tokens, extents, hashes); the partner rows of the "
+                        "matches are a second trip of bytes already counted there (DESIGN 6c)"}
         else:
-            roof["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges_checked": st["n_edges"],
-                              "dropped_as_connected": st.get("n_connected", 0),
-                              "note": "prefix groups: candidates come from the groups of the rows' rarest tokens (no band scan); the "
-                                      "step is bound by the exact verify of the candidates and by round trips, not by VALU or HBM"}
+            roof_cluster["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges_checked": st["n_edges"],
+                                      "dropped_as_connected": st.get("n_connected", 0)}
+        # the tokeniser's dominant kernel: every text byte once + one 4-byte slot per token written
+        t_hash = max(tk["ms_hash"] - tk["ms_head"], 1e-6)
+        tok_bytes = T + 4 * nnz
+        tok_tr = measured_traffic("bfk::k_tok_hash", wl_key) if world == 1 else None
+        roof_tok = {"bound": "hbm", "kernel": "k_tok_hash",
+                    "achieved": tok_bytes / (t_hash * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": tok_bytes / (t_hash * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": tok_tr["bytes"] if tok_tr else None, "traffic_detail": tok_tr,
+                    "algorithmic_bytes_per_launch": tok_bytes,
+                    "algorithmic_bytes_what": "every text byte once + one 4-byte slot per token written",
+                    "kernel_ms": t_hash}
+        tok_all_bytes = 2 * T + 12 * nnz + 4 * n_u  # text twice (scan, hash) + slot written, read, id written per token + indptr
+        step_bytes = tok_all_bytes + clus_bytes
+        # the step's dominant kernel is the one with the longest measured duration
+        roof, other = (roof_tok, roof_cluster) if t_hash >= t_dom * 1e3 else (roof_cluster, roof_tok)
+        roof = dict(roof)
+        roof["kernel_ms_source"] = ("HIP events on the launch stream around the kernel inside libbfk, median of 16 whole steps "
+                                    "(includes the launch gap, ~3 us more than rocprofv3's kernel time: profiles/)")
+        roof["second_kernel"] = other
+        roof["whole_step"] = {"bytes": step_bytes, "GBps": step_bytes / (ms_step * 1e-3) / 1e9,
+                              "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "compulsory bytes of every kernel of the step (tokeniser: text twice + 12 B per token + "
+                                      "indptr; clustering kernels as listed in DESIGN 8) / ms_per_step"}
+        roof["reference_equivalent"] = {
+            "bytes": b_ref / world, "pairs_in_reference_band": merged_pairs,
+            "equivalent_GBps": b_ref / world / (ms_step * 1e-3) / 1e9,
+            "note": "SURVEY 8(d) untiled operand-stream bytes, 4(k_i+k_j) per pair of the reference's length band + "
+                    "8 B per pruned pair: what an untiled all-pairs merge touches.  These kernels never stream those "
+                    "operands, so this is an algorithmic-speedup figure, not a bandwidth claim"}
         out = {
             "metric": "genome-pair dists/sec (pairs resolved/s, N_u(N_u-1)/2 per step) + clusters.tsv wall-clock",
             "value": resolved * a.steps / elapsed,
@@ -678,37 +730,49 @@ def main():
                             f"{', indels kept' if a.indels else ''}), N_u={n_u} unique, k_mean={nnz / n_u:.1f}, "
                             f"max-dist {d}",
                 "workload_key": wl_key, "kernel_source_digest": kernel_source_digest(),
-                "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d,
+                "n_unique": n_u, "nnz": nnz, "n_vocab": n_vocab, "max_dist": d, "text_bytes": T,
+                "step": "the whole hot path of SURVEY 8(d) minus PCIe: N_u profile strings RESIDENT IN HBM (one byte buffer + int64 "
+                        "offsets) -> separator scan, vocabulary table, first-appearance ids, CSR (bfk_text.hip) -> one wait for "
+                        "the token count / longest row -> clustering kernels -> canonical labels in HBM; through "
+                        "bfk_ctx_build_csr_device + bfk_ctx_cluster (= bfk_ctx_cluster_text_device)",
+                "input": f"text resident in HBM, {n_copies} distinct device copies taken in turn ({n_copies * T / 1e6:.0f} MB: more "
+                         "than the 256 MiB Infinity Cache holds); PCIe-inclusive figures: t_cluster_host_ms / "
+                         "value_host_inclusive; the clustering kernels alone on a resident CSR: value_resident_csr",
                 "candidate_path": ("variant join (k_jhash + k_join, DESIGN 6b)" if join else
                                    "prefix groups (k_pgkeys .. radix sort .. k_pgplace .. k_pgwalk16 .. k_verify_connected, DESIGN 6d/6e)" if prefix else
                                    "all-pairs band kernels (k_sig .. k_prefilter .. k_verify)"),
-                "sharding": (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
+                "sharding": ("every rank tokenises the whole text (CSR replicated); " if world > 1 else "") +
+                            (f"blocks of 8192 tokens (their table lookups) round-robin over {world} rank(s)" if join else
                              f"blocks of 64 rows (the walks of their groups) round-robin over {world} rank(s)" if prefix else
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
-                "input": "CSR resident in HBM (host-inclusive figures: t_cluster_host_ms)",
                 **({"collective_backend": backend, "world_size": world, "n_edges_per_rank": edges_per_rank,
                     "step_phases": exchange, "one_gpu_same_workload": one_gpu} if world > 1 else {}),
-                **({"pipeline": f"{pipe} contexts on {pipe} streams, steps round-robin (opt-in experiment)"} if pipe > 1 else {}),
             },
             "roofline": roof,
-            "phases_ms": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
+            "phases_ms": {"tokeniser": tk, "clustering": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
+                          "note": "HIP events inside libbfk, median of 16 profiled steps; ms_hash includes k_tok_head (ms_head); the "
+                                  "rest of ms_per_step is the bind between the halves (one 64-byte D2H + wait) and launch gaps"},
             "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges", "n_connected",
                                                "n_retry_slices", "n_work_items", "max_row_len")},
             "result": {"components": int(len(np.unique(labels))), "labels_crc": int(np.bitwise_xor.reduce(
                 (labels.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(13)))},
+            "value_resident_csr": resident["value"],
+            "resident_csr": resident,
         }
         if sustained:
             out["sustained"] = sustained
         if cold is not None:
-            out["ms_per_step_cold"] = cold
+            out["resident_csr"]["ms_per_step_cold"] = cold
         if host:
             host["labels_equal_resident_path"] = bool(np.array_equal(lab_first, labels))
             out["t_cluster_host_ms"] = host
-            out["value_host_inclusive"] = resolved / (host["steady"] * 1e-3)
+            out["value_host_inclusive"] = resolved / (host["fresh_pageable_buffer"] * 1e-3)
+            out["value_host_inclusive_pinned"] = resolved / (host["pinned_buffer"] * 1e-3)
         if cli:
             out["clusters_tsv_wall_s"] = cli.get("seconds")
             out["clusters_tsv_wall_median_s"] = cli.get("median_s")
+            out["clusters_tsv_wall_ordinary_exit_s"] = (cli.get("ordinary_exit") or {}).get("seconds")
             out["clusters_tsv"] = cli
         if allpairs:
             out["all_pairs"] = allpairs

@@ -12,7 +12,7 @@ _HERE = Path(__file__).resolve().parent
 FRONT_PATH = _HERE / "libbfk_front.so"
 LIB_PATH = Path(os.environ["BFK_LIB"]) if os.environ.get("BFK_LIB") else _HERE / "libbfk.so"
 EUNSUPPORTED = -7
-ABI_VERSION = 2  # BFK_ABI_VERSION of include/bfk.h (same number as _lib.ABI_VERSION)
+ABI_VERSION = 3  # BFK_ABI_VERSION of include/bfk.h (same number as _lib.ABI_VERSION)
 VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
 _lib = None
 _preloading = False

@@ -59,7 +59,7 @@ class PrepInfo(C.Structure):
 
 VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
 EUNSUPPORTED = -7
-ABI_VERSION = 2  # BFK_ABI_VERSION of include/bfk.h this binding (struct layouts, EXPORTS) was written against
+ABI_VERSION = 3  # BFK_ABI_VERSION of include/bfk.h this binding (struct layouts, EXPORTS) was written against
 
 EXPORTS = {
     "bfk_abi_version": (C.c_int, []),
@@ -74,6 +74,13 @@ EXPORTS = {
                                    c_i64p, c_i32p, c_i32p]),
     "bfk_ctx_build_csr": (C.c_int, [C.c_void_p, C.c_char_p, c_i64p, C.c_int64, C.c_char_p, C.c_int64, c_i64p, c_i32p]),
     "bfk_ctx_download_csr": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
+    "bfk_text_device_bytes": (C.c_int64, [C.c_int64]),
+    "bfk_ctx_build_csr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, c_i64p,
+                                           c_i32p]),
+    "bfk_ctx_cluster_text_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64,
+                                              C.c_int32, C.c_void_p]),
+    "bfk_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "bfk_host_free": (C.c_int, [C.c_void_p]),
     "bfk_ctx_text_stats": (C.c_int, [C.c_void_p, C.POINTER(TextStats)]),
     "bfk_cluster_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_i32p, C.POINTER(Stats)]),
     "bfk_neighbours_csr": (C.c_int, [c_i32p, c_i32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, C.POINTER(c_i64p),
@@ -217,17 +224,44 @@ def build_csr_device(features, sep: str):
     return build_csr_bytes(buf, off, sep, device=True)
 
 
-def cluster_text(buf: bytes, row_off, sep: str, max_dist: int, want_stats: bool = True, indptr_out=None):
+class PinnedBuffer:
+    """bfk_host_alloc / bfk_host_free: page-locked host memory a caller builds its profile text in (copies from it run at the
+    PCIe rate from the first byte).  `.view` is a writable uint8 numpy view; pass the object itself as `buf` to cluster_text."""
+
+    def __init__(self, nbytes: int):
+        self.lib = load()
+        p = C.c_void_p()
+        _check(self.lib.bfk_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p, int(nbytes)
+        self.view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[: int(nbytes)]
+
+    def free(self):
+        if self.ptr:
+            self.view = None
+            self.lib.bfk_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def cluster_text(buf, row_off, sep: str, max_dist: int, want_stats: bool = True, indptr_out=None, labels_out=None):
     """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device.
-    want_stats=False passes stats_out = NULL (the counters that need host-side sums are then not gathered);
-    indptr_out: optional int32[N+1] array that receives the CSR's row pointer."""
+    buf: bytes, or a PinnedBuffer (bfk_host_alloc).  want_stats=False passes stats_out = NULL (the counters that need
+    host-side sums are then not gathered); indptr_out: optional int32[N+1] array that receives the CSR's row pointer;
+    labels_out: optional int32[N] array to write the labels into (no allocation per call)."""
     lib = load()
     off = np.ascontiguousarray(row_off, dtype=np.int64)
     n = len(off) - 1
     sepb = sep.encode()
-    labels = np.empty(max(n, 1), dtype=np.int32)
+    labels = np.empty(max(n, 1), dtype=np.int32) if labels_out is None else labels_out
     st = Stats()
     nnz, nv = C.c_int64(), C.c_int32()
+    if isinstance(buf, PinnedBuffer):
+        buf = C.cast(buf.ptr, C.c_char_p)
     rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels),
                               C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv),
                               None if indptr_out is None else _p32(indptr_out))
@@ -307,6 +341,11 @@ def labels_from_lists(n_rows: int, lists):
     labels = np.empty(max(n_rows, 1), dtype=np.int32)
     _check(lib.bfk_labels_from_lists(int(n_rows), _p64(off), _p32(flat), len(lists), _p32(labels)))
     return labels[:n_rows]
+
+
+def text_device_bytes(text_bytes: int) -> int:
+    """bytes a device text buffer handed to Context.build_csr_device / cluster_text_device must have"""
+    return int(load().bfk_text_device_bytes(int(text_bytes)))
 
 
 class Unsupported(Exception):
@@ -527,6 +566,29 @@ class Context:
         self.n_rows = len(off) - 1
         self.nnz = int(nnz.value)
         return int(nnz.value), int(nv.value)
+
+    def build_csr_device(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str):
+        """bfk_ctx_build_csr_device: the tokeniser on text resident in HBM (device pointers as ints) -> (nnz, n_vocab)"""
+        sepb = sep.encode()
+        nnz, nv = C.c_int64(), C.c_int32()
+        rc = self.lib.bfk_ctx_build_csr_device(self.h, C.c_void_p(d_text), int(text_bytes), C.c_void_p(d_row_off), int(n_rows), sepb,
+                                               len(sepb), C.byref(nnz), C.byref(nv))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        self.n_rows = int(n_rows)
+        self.nnz = int(nnz.value)
+        return int(nnz.value), int(nv.value)
+
+    def cluster_text_device(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str, max_dist: int, d_labels: int):
+        """bfk_ctx_cluster_text_device: profile strings in HBM -> labels in HBM (asynchronous behind the one wait inside)"""
+        sepb = sep.encode()
+        rc = self.lib.bfk_ctx_cluster_text_device(self.h, C.c_void_p(d_text), int(text_bytes), C.c_void_p(d_row_off), int(n_rows),
+                                                  sepb, len(sepb), int(max_dist), C.c_void_p(d_labels))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        self.n_rows = int(n_rows)
 
     def download_csr(self):
         indptr = np.empty(self.n_rows + 1, dtype=np.int32)

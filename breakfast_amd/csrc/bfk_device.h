@@ -141,6 +141,7 @@ struct TokArgs {
     uint32_t T, T_pad;         // text bytes; rounded up to TOK_BLOCK_BYTES with at least one byte of padding
     int n_rows;
     uint8_t sep;
+    int strict;                // 1: also check row_off[0] == base and row_off[n_rows] == base + T (offsets from a caller's device memory)
     uint32_t *rowbits, *startbits, *boundbits;  // one bit per byte position: row start / token start / separator or row start
     uint32_t *firstbits;       // ... / a token's first occurrence starts here
     uint32_t *winbase, *vocwin; // [T_pad / TOK_WIN]: tokens / vocabulary entries in front of every window inside its scan block

@@ -415,16 +415,21 @@ extern "C" int bfk_ctx_upload_csr(bfk_ctx *c, const int32_t *indptr, const int32
 // ================================================================================================
 static int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
-                          int64_t *nnz_out, int32_t *n_vocab_out) {
-    if (!row_off || n_rows < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: null argument");
-    if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
-    if (n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
-    if (sep_len != 1) return fail(BFK_EUNSUPPORTED, "device tokeniser: one-byte separators only (the host tokeniser takes the rest)");
-    const int64_t base = row_off[0], T = row_off[n_rows] - base;
-    if (T < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
-    if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
-    if (T > (int64_t)0xFFF00000ll) return fail(BFK_EUNSUPPORTED, "device tokeniser: 32-bit byte offsets (text of 4 GiB or more)");
+// bytes a DEVICE text buffer handed to bfk_ctx_cluster_text_device / bfk_ctx_build_csr_device must have: the text, separator
+// padding up to a multiple of 64 KiB, and a slack for unaligned 8-byte reads of a token's tail (the library writes the padding)
+extern "C" int64_t bfk_text_device_bytes(int64_t text_bytes) {
+    if (text_bytes < 0) return -1;
+    return round_up(text_bytes + 1, TOK_PAD_BYTES) + TOK_TEXT_SLACK;
+}
+
+// The tokeniser on text that is RESIDENT IN HBM: d_text holds T bytes of rows and has room for bfk_text_device_bytes(T);
+// d_rowoff = int64[n_rows + 1] on the device, offsets relative to `base`.  `pieces` > 1: the text is still arriving on the copy
+// stream, piece by piece (host wrapper below).  `strict`: the offsets come from the caller's device memory, the kernels also
+// check row_off[0] == base and row_off[n_rows] == base + T (the host wrapper has checked its own).  Leaves the CSR bound.
+// ONE wait for the device inside: nnz, the longest row and the tokeniser's counters come back in one small copy (the
+// clustering kernels' grids and workspace are sized from them).
+static int ctx_tokenize(bfk_ctx *c, uint8_t *d_text, const long long *d_rowoff, int64_t base, int64_t T, int64_t n_rows, char sep,
+                        bool strict, int n_pieces, const unsigned *piece_blk, int64_t *nnz_out, int32_t *n_vocab_out) {
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     // every token but the last of a row is followed by a separator: at most T/2 + n_rows + 1 tokens
     const int64_t nnz_cap = T / 2 + n_rows + 1;
@@ -434,66 +439,14 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     // zeroed region: rowbits | firstbits (the counters live in d_small[8..15] and travel with the bind's copy)
     const int64_t bit_words = T_pad / 32 + 16;
     const int64_t z_rowbits = 0, z_firstbits = z_rowbits + bit_words * 4, z_bytes = z_firstbits + bit_words * 4;
-    if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
-    if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n_rows + 1, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_zero, &c->tk_zero_cap, z_bytes, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 2 * bit_words, 1.05)) return rc;
     const int64_t n_blk = round_up(T_pad / TOK_PAD_BYTES + 1, 4) + 4;  // (+ the total behind the last block; 16-byte pieces)
     if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, 2 * (n_win + n_blk), 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
-    if (c->profiling && !c->tk_ev_ready) {
-        for (auto &e : c->tk_ev)
-            if (hipEventCreate(&e) != hipSuccess) return fail(BFK_EHIP, "hipEventCreate failed");
-        c->tk_ev_ready = true;
-    }
     hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
-    // The text and the row offsets: the caller's (pageable) buffers, borrowed until the copies are done.  ONE copy of the
-    // whole text, then the kernels.  BFK_TOK_PIECES=n (2..8, texts from 8 MB) sends the text in n pieces on a copy stream of
-    // its own and tokenises piece k under the copy of piece k + 1 — measured and left off: every copy from pageable memory
-    // costs ~60 us of driver work before it moves a byte, which is more than the ~30 us of kernels a piece hides
-    // (bfk_cluster_text, 100k rows / 31 MB: 1.10 ms in one piece, 1.20-1.28 in two, 1.24 in four, 1.43 in eight; 1M rows /
-    // 333 MB: 7.8 against 8.0-8.4).  (With profiling on everything runs on the one stream, the phases one after the other.)
-    int n_pieces = 1;
-    unsigned piece_blk[bfk_ctx::TK_PIECES + 1] = {0};
-    const int64_t scan_blocks = T_pad / TOK_PAD_BYTES;
-    if (!c->profiling && T >= ((int64_t)8 << 20) && getenv("BFK_TOK_PIECES") && atoi(getenv("BFK_TOK_PIECES")) >= 2) {
-        n_pieces = std::min((int)bfk_ctx::TK_PIECES, atoi(getenv("BFK_TOK_PIECES")));
-        for (int k = 0; k <= n_pieces; k++)  // boundaries at multiples of 4 scan blocks (256 KiB: 16-byte pieces of blkbase)
-            piece_blk[k] = k == n_pieces ? (unsigned)scan_blocks : (unsigned)(scan_blocks * k / n_pieces / 4 * 4);
-        if (!c->tk_copy_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&c->tk_copy_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&c->tk_start_ev, hipEventDisableTiming));
-            for (auto &e : c->tk_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-    }
-    // whatever way this function is left — also by an early return further down (an allocation that fails, a launch error)
-    // — the caller's buffers are no longer being read when it returns: the text and the offsets were enqueued from the
-    // caller's pageable memory on the launch stream (one piece) or on the copy stream (pieces).  On the success path the
-    // launch stream is idle by then (ctx_after_bind has synchronised it): the second wait costs nothing.
-    struct CopyGuard {
-        hipStream_t copy, launch;
-        ~CopyGuard() {
-            if (copy) (void)hipStreamSynchronize(copy);
-            if (launch) (void)hipStreamSynchronize(launch);
-        }
-    } copy_guard{n_pieces > 1 ? c->tk_copy_stream : nullptr, c->stream};
-    if (ev) HIP_TRY(hipEventRecord(ev[4], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->tk_text + T, (unsigned char)sep[0], (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
-    if (n_pieces == 1) {
-        if (T > 0) HIP_TRY(hipMemcpyAsync(c->tk_text, buf + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
-    } else {
-        // the copy stream may not write the text before the launch stream is done with what it holds (an earlier build)
-        HIP_TRY(hipEventRecord(c->tk_start_ev, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->tk_copy_stream, c->tk_start_ev, 0));
-        for (int k = 0; k < n_pieces; k++) {
-            const int64_t o0 = (int64_t)piece_blk[k] * TOK_PAD_BYTES, o1 = std::min<int64_t>(T, (int64_t)piece_blk[k + 1] * TOK_PAD_BYTES);
-            if (o1 > o0) HIP_TRY(hipMemcpyAsync(c->tk_text + o0, buf + base + o0, (size_t)(o1 - o0), hipMemcpyHostToDevice, c->tk_copy_stream));
-            HIP_TRY(hipEventRecord(c->tk_piece_ev[k], c->tk_copy_stream));
-        }
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
+    HIP_TRY(hipMemsetAsync(d_text + T, (unsigned char)sep, (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
     TokCounters tc{};
     int rc_bind = BFK_OK;
     for (int attempt = 0;; attempt++) {
@@ -511,13 +464,14 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         HIP_TRY(hipMemsetAsync(c->d_small + 8, 0, 32, c->stream));
         HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * 8, c->stream));
         TokArgs a{};
-        a.text = c->tk_text;
-        a.row_off = c->tk_rowoff;
+        a.text = d_text;
+        a.row_off = d_rowoff;
         a.base = base;
         a.T = (uint32_t)T;
         a.T_pad = (uint32_t)T_pad;
         a.n_rows = (int)n_rows;
-        a.sep = (uint8_t)sep[0];
+        a.sep = (uint8_t)sep;
+        a.strict = strict ? 1 : 0;
         a.tc = (TokCounters *)(c->d_small + 8);
         a.rowbits = (uint32_t *)(c->tk_zero + z_rowbits);
         a.firstbits = (uint32_t *)(c->tk_zero + z_firstbits);
@@ -570,15 +524,140 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     c->tk_stats.n_vocab = (int32_t)tc.n_vocab;
     if (ev) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->tk_stats.ms_h2d = ms;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
         if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->tk_stats.ms_hash = ms;
         if (hipEventElapsedTime(&ms, ev[1], ev[6]) == hipSuccess) c->tk_stats.ms_head = ms;
         if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->tk_stats.ms_ids = ms;
-        if (hipEventElapsedTime(&ms, ev[4], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
+        if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
     }
     if (nnz_out) *nnz_out = tc.nnz;
     if (n_vocab_out) *n_vocab_out = (int32_t)tc.n_vocab;
+    return BFK_OK;
+}
+
+static int ctx_text_events(bfk_ctx *c) {
+    if (c->profiling && !c->tk_ev_ready) {
+        for (auto &e : c->tk_ev)
+            if (hipEventCreate(&e) != hipSuccess) return fail(BFK_EHIP, "hipEventCreate failed");
+        c->tk_ev_ready = true;
+    }
+    return BFK_OK;
+}
+
+static int ctx_check_text_args(const int64_t n_rows, const char *sep, int64_t sep_len, int64_t T) {
+    if (n_rows < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: negative n_rows");
+    if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
+    if (n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
+    if (sep_len != 1) return fail(BFK_EUNSUPPORTED, "device tokeniser: one-byte separators only (the host tokeniser takes the rest)");
+    if (T < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: row_off not monotone");
+    if (T > (int64_t)0xFFF00000ll) return fail(BFK_EUNSUPPORTED, "device tokeniser: 32-bit byte offsets (text of 4 GiB or more)");
+    return BFK_OK;
+}
+
+// host buffers: the text and the offsets cross PCIe once into context-owned device buffers, then ctx_tokenize
+static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
+                          int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (!row_off) return fail(BFK_EARG, "bfk_ctx_build_csr: null argument");
+    const int64_t base = n_rows >= 0 ? row_off[0] : 0, T = n_rows >= 0 ? row_off[n_rows] - base : -1;
+    if (int rc = ctx_check_text_args(n_rows, sep, sep_len, T)) return rc;
+    if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
+    const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
+    if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n_rows + 1, 1.05)) return rc;
+    if (int rc = ctx_text_events(c)) return rc;
+    hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
+    // The text and the row offsets: the caller's buffers (pageable, or pinned: bfk_host_alloc), borrowed until the copies are
+    // done.  ONE copy of the whole text, then the kernels.  BFK_TOK_PIECES=n (2..8, texts from 8 MB) sends the text in n pieces on a copy stream of
+    // its own and tokenises piece k under the copy of piece k + 1 — measured and left off: every copy from pageable memory
+    // costs ~60 us of driver work before it moves a byte, which is more than the ~30 us of kernels a piece hides
+    // (bfk_cluster_text, 100k rows / 31 MB: 1.10 ms in one piece, 1.20-1.28 in two, 1.24 in four, 1.43 in eight; 1M rows /
+    // 333 MB: 7.8 against 8.0-8.4).  (With profiling on everything runs on the one stream, the phases one after the other.)
+    int n_pieces = 1;
+    unsigned piece_blk[bfk_ctx::TK_PIECES + 1] = {0};
+    const int64_t scan_blocks = T_pad / TOK_PAD_BYTES;
+    if (!c->profiling && T >= ((int64_t)8 << 20) && getenv("BFK_TOK_PIECES") && atoi(getenv("BFK_TOK_PIECES")) >= 2) {
+        n_pieces = std::min((int)bfk_ctx::TK_PIECES, atoi(getenv("BFK_TOK_PIECES")));
+        for (int k = 0; k <= n_pieces; k++)  // boundaries at multiples of 4 scan blocks (256 KiB: 16-byte pieces of blkbase)
+            piece_blk[k] = k == n_pieces ? (unsigned)scan_blocks : (unsigned)(scan_blocks * k / n_pieces / 4 * 4);
+        if (!c->tk_copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->tk_copy_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->tk_start_ev, hipEventDisableTiming));
+            for (auto &e : c->tk_piece_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+    // whatever way this function is left — also by an early return further down (an allocation that fails, a launch error)
+    // — the caller's buffers are no longer being read when it returns: the text and the offsets were enqueued from the
+    // caller's memory on the launch stream (one piece) or on the copy stream (pieces).  On the success path the launch
+    // stream is idle by then (ctx_after_bind has synchronised it): the second wait costs nothing.
+    struct CopyGuard {
+        hipStream_t copy, launch;
+        ~CopyGuard() {
+            if (copy) (void)hipStreamSynchronize(copy);
+            if (launch) (void)hipStreamSynchronize(launch);
+        }
+    } copy_guard{n_pieces > 1 ? c->tk_copy_stream : nullptr, c->stream};
+    if (ev) HIP_TRY(hipEventRecord(ev[4], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_pieces == 1) {
+        if (T > 0) HIP_TRY(hipMemcpyAsync(c->tk_text, buf + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // the copy stream may not write the text before the launch stream is done with what it holds (an earlier build)
+        HIP_TRY(hipEventRecord(c->tk_start_ev, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->tk_copy_stream, c->tk_start_ev, 0));
+        for (int k = 0; k < n_pieces; k++) {
+            const int64_t o0 = (int64_t)piece_blk[k] * TOK_PAD_BYTES, o1 = std::min<int64_t>(T, (int64_t)piece_blk[k + 1] * TOK_PAD_BYTES);
+            if (o1 > o0) HIP_TRY(hipMemcpyAsync(c->tk_text + o0, buf + base + o0, (size_t)(o1 - o0), hipMemcpyHostToDevice, c->tk_copy_stream));
+            HIP_TRY(hipEventRecord(c->tk_piece_ev[k], c->tk_copy_stream));
+        }
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
+    const int rc = ctx_tokenize(c, c->tk_text, c->tk_rowoff, base, T, n_rows, sep[0], false, n_pieces, piece_blk, nnz_out, n_vocab_out);
+    if (!rc && ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->tk_stats.ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, ev[4], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
+    }
+    return rc;
+}
+
+// a1 on text that already lives in device memory (include/bfk.h): no copy — the kernels read the caller's buffer
+extern "C" int bfk_ctx_build_csr_device(bfk_ctx *c, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
+                                        const char *sep, int64_t sep_len, int64_t *nnz_out, int32_t *n_vocab_out) {
+    if (int rc = ctx_enter(c)) return rc;
+    if (int rc = ctx_check_text_args(n_rows, sep, sep_len, text_bytes)) return rc;
+    if (!d_text || !d_row_off) return fail(BFK_EARG, "bfk_ctx_build_csr_device: null device pointer");
+    if (n_rows == 0 && text_bytes != 0) return fail(BFK_EARG, "bfk_ctx_build_csr_device: text without rows");
+    if (int rc = ctx_text_events(c)) return rc;
+    return ctx_tokenize(c, (uint8_t *)d_text, (const long long *)d_row_off, 0, text_bytes, n_rows, sep[0], true, 1, nullptr, nnz_out,
+                        n_vocab_out);
+}
+
+// a1 .. a8 with the text RESIDENT IN HBM and the labels left in HBM: what bench.py times as one step
+extern "C" int bfk_ctx_cluster_text_device(bfk_ctx *c, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
+                                           const char *sep, int64_t sep_len, int32_t max_dist, void *d_labels_out) {
+    if (max_dist < 0) return fail(BFK_EARG, "max_dist must be >= 0");
+    if (n_rows > 0 && !d_labels_out) return fail(BFK_EARG, "null labels");
+    if (int rc = bfk_ctx_build_csr_device(c, d_text, text_bytes, d_row_off, n_rows, sep, sep_len, nullptr, nullptr)) return rc;
+    return bfk_ctx_cluster(c, max_dist, 0, 1, d_labels_out);
+}
+
+// pinned host memory for a caller's text (and anything else it hands over often): copies from it run at the PCIe rate from the
+// first byte — a pageable buffer the driver has never seen is pinned page by page on the way (bench.py: t_cluster_host_ms)
+extern "C" int bfk_host_alloc(int64_t bytes, void **out) {
+    if (!out || bytes < 0) return fail(BFK_EARG, "bfk_host_alloc: bad argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? BFK_ENODEV : BFK_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    return BFK_OK;
+}
+
+extern "C" int bfk_host_free(void *p) {
+    if (!p) return BFK_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(BFK_EARG, std::string("hipHostFree: ") + hipGetErrorString(e));
     return BFK_OK;
 }
 

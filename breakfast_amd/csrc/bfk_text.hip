@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_tok_rowbits(TokArgs a) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= a.n_rows) return;
     const long long o = a.row_off[r] - a.base, e = a.row_off[r + 1] - a.base;
-    if (o < 0 || e < o || e > (long long)a.T) {
+    if (o < 0 || e < o || e > (long long)a.T || (a.strict && ((r == 0 && o != 0) || (r == a.n_rows - 1 && e != (long long)a.T)))) {
         atomicOr(&a.tc->fail, TOK_FAIL_ROWOFF);
         return;
     }

@@ -58,6 +58,13 @@ class GpuEngine:
         self.n = ip.numel() - 1
         self.ctx.bind_csr_device(ip.data_ptr(), ix.data_ptr(), self.n)
 
+    def bind_text(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str):
+        """the tokeniser on profile text that is resident in HBM (device pointers): first-appearance vocabulary + CSR built and
+        bound on the engine's stream (bfk_ctx_build_csr_device; one wait for the device inside)"""
+        self.ctx.build_csr_device(d_text, text_bytes, d_row_off, n_rows, sep)
+        self.n = int(n_rows)
+        self._keep = None
+
     def run(self):
         """context manager: what is enqueued inside goes to the engine's stream"""
         return torch.cuda.stream(self.stream)
@@ -98,6 +105,24 @@ class ShardedClusterer:
         self.gathered = self.e.new_labels(self.world) if (self.world > 1 or self.force_exchange) else None
         self.flag = self.e.new_flag()
         self._settled = set()
+
+    def step_text(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str, max_dist: int):
+        """the whole hot path as ONE step: profile strings resident in HBM -> first-appearance vocabulary + CSR (every rank
+        tokenises the whole text: the CSR is replicated) -> this rank's shard of the pair work -> label exchange
+        -> global canonical labels in HBM on every rank.  A step binds a new CSR, so its shard is synced before the exchange
+        (see _step) every time."""
+        run = getattr(self.e, "run", None)
+        with run():
+            self.e.bind_text(d_text, text_bytes, d_row_off, n_rows, sep)
+            if getattr(self, "labels", None) is None or self.labels.shape[1] != max(self.e.n, 1):
+                self.local = self.e.new_labels(1)
+                self.labels = self.e.new_labels(1)
+                self.gathered = self.e.new_labels(self.world) if (self.world > 1 or self.force_exchange) else None
+                self.flag = self.e.new_flag()
+            self._settled = set()
+            out = self._step(max_dist)
+        torch.cuda.current_stream(self.e.device).wait_stream(self.e.stream)
+        return out
 
     def step(self, max_dist: int):
         """CSR (resident) -> global canonical labels on every rank.  Asynchronous on the GPU engine except

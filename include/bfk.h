@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BFK_ABI_VERSION 2 /* 2: bfk_stats grew (path, n_connected); bfk_preload_join, device tokeniser entries */
+#define BFK_ABI_VERSION 3 /* 3: device-resident text entries, bfk_host_alloc / bfk_host_free; 2: bfk_stats grew (path, n_connected) */
 
 #define BFK_OK 0
 #define BFK_EARG -1      /* bad argument (NULL pointer, negative size, malformed indptr, ...) */
@@ -73,6 +73,12 @@ int bfk_abi_version(void);
 int bfk_device_count(void); /* number of visible gfx950 devices; 0 if none / no HIP runtime */
 const char *bfk_last_error(void);
 void bfk_free(void *p);
+
+/* Pinned (page-locked) host memory for buffers a caller hands over — the profile text of bfk_cluster_text above all: a copy
+ * from it runs at the PCIe rate from its first byte, while a pageable buffer the driver has not seen before is pinned page
+ * by page on the way (100k profiles, 31 MB: ~0.6 ms against 1.5 ms; bench.py t_cluster_host_ms).  Needs a device.       */
+int bfk_host_alloc(int64_t bytes, void **out);
+int bfk_host_free(void *p);
 
 /* Pay what a first call pays and that does not depend on the input — device context, stream, code-object load, and with
  * size hints (> 0) the workspace allocations — e.g. on a thread while the input is read (bfk_preload_start). */
@@ -160,6 +166,22 @@ int bfk_ctx_bind_csr_device(bfk_ctx *ctx, const void *d_indptr, const void *d_in
  * buffers, borrowed until the call returns (synchronous: the longest row and nnz come back for the workspace). */
 int bfk_ctx_build_csr(bfk_ctx *ctx, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
                       int64_t *nnz_out, int32_t *n_vocab_out);
+
+/* ---- the same stages on text that is RESIDENT IN HBM (no PCIe inside the call) ------------------------------------------
+ * d_text: device buffer of at least bfk_text_device_bytes(text_bytes) bytes whose first text_bytes hold the rows' bytes (rows
+ * abut, as in bfk_build_csr); the library writes separator padding behind them.  d_row_off: device int64[n_rows + 1],
+ * row_off[0] == 0, row_off[n_rows] == text_bytes, non-decreasing (checked by the kernels: BFK_EARG).  Both are borrowed
+ * until the context is bound to another CSR.
+ *   bfk_ctx_build_csr_device     sparse_feature_matrix (:193-215) -> CSR resident and bound
+ *   bfk_ctx_cluster_text_device  + the body of cluster_features (:287-326) -> canonical labels in d_labels_out (device
+ *                                int32[n_rows]); returns with the clustering kernels enqueued (bfk_ctx_sync waits for them).
+ * One wait for the device happens inside (the token count and the longest row size the clustering kernels' grids).
+ * This is the step bench.py times: profile strings in HBM -> labels in HBM.                                              */
+int64_t bfk_text_device_bytes(int64_t text_bytes);
+int bfk_ctx_build_csr_device(bfk_ctx *ctx, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
+                             const char *sep, int64_t sep_len, int64_t *nnz_out, int32_t *n_vocab_out);
+int bfk_ctx_cluster_text_device(bfk_ctx *ctx, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
+                                const char *sep, int64_t sep_len, int32_t max_dist, void *d_labels_out);
 /* copy the bound CSR to the host: indptr_out int32[n_rows + 1], indices_out int32[nnz] (synchronous) */
 int bfk_ctx_download_csr(bfk_ctx *ctx, int32_t *indptr_out, int32_t *indices_out);
 /* counters / phase times (with bfk_ctx_set_profiling) of the last bfk_ctx_build_csr / bfk_cluster_text */

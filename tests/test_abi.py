@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libbfk.so does not export {s}"
     assert set(syms) == set(_lib.EXPORTS), "python binding table and bfk.h disagree"
-    assert _lib.load().bfk_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().bfk_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_no_gpu_means_loud_failure():

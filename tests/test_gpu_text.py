@@ -158,6 +158,94 @@ def test_ctx_build_csr_binds_what_it_built_and_cluster_text_agrees():
     ctx.close()
 
 
+def _device_text(rows):
+    """the rows' bytes in a torch CUDA buffer of bfk_text_device_bytes (the tail deliberately poisoned: the library must pad
+    it itself) + the offsets as a CUDA int64 tensor"""
+    import torch
+
+    buf, off = _lib.pack_rows(rows)
+    need = _lib.text_device_bytes(len(buf))
+    d_text = torch.full((need,), 0x41, dtype=torch.uint8, device="cuda")  # 'A': a token byte, not a separator
+    if len(buf):
+        d_text[: len(buf)] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    torch.cuda.synchronize()
+    return buf, off, d_text, d_off
+
+
+@pytest.mark.parametrize("case", ["synthetic", "indels", "kat_shapes", "empty_rows", "no_rows"])
+def test_text_resident_in_hbm_gives_the_same_csr_and_labels(case):
+    """bfk_ctx_build_csr_device / bfk_ctx_cluster_text_device — the step bench.py times: profile strings in HBM -> labels in
+    HBM, no copy of the text — against the host-buffer entry and the oracle"""
+    import torch
+
+    rows = {"synthetic": list(dict.fromkeys(generate_profiles(20000))),
+            "indels": list(dict.fromkeys(generate_profiles(5000, p_del=0.05, p_ins=0.01))),
+            "kat_shapes": ["X Y", "X X Y", "", "Y X", "X  Y", "Q R S", "ab", "cd", "ab cd", "abcd", " ", "X"],
+            "empty_rows": ["", "", ""], "no_rows": []}[case]
+    buf, off, d_text, d_off = _device_text(rows)
+    want = orc.sparse_feature_matrix(rows, " ") if rows else (np.zeros(1, np.int32), np.zeros(0, np.int32), 0)
+    ctx = _lib.Context(0)
+    nnz, nv = ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ")
+    assert (nnz, nv) == (len(want[1]), want[2])
+    ip, ix = ctx.download_csr()
+    assert np.array_equal(ip, want[0]) and np.array_equal(ix, want[1])
+    assert d_text[len(buf):].cpu().numpy().tolist() == [32] * (len(d_text) - len(buf))  # the library padded the caller's buffer
+    if len(ix):
+        d_lab = torch.empty(max(len(rows), 1), dtype=torch.int32, device="cuda")
+        for d in (1, 3):
+            for _ in range(2):  # twice: a second step on the same buffers finds nothing left over from the first
+                ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", d, d_lab.data_ptr())
+                st = ctx.sync()
+                assert st["n_retry_slices"] == 0
+                assert np.array_equal(d_lab.cpu().numpy()[: len(rows)], orc.cluster_csr(want[0], want[1], d, n_threads=8)["labels"])
+    ctx.close()
+
+
+def test_text_resident_in_hbm_checks_the_offsets_on_the_device():
+    import torch
+
+    rows = ["A1C G5T", "", "G5T", "Q9R A1C"]
+    buf, off, d_text, d_off = _device_text(rows)
+    ctx = _lib.Context(0)
+    for bad in ("not_from_zero", "short_of_the_text", "decreasing"):
+        o = off.copy()
+        if bad == "not_from_zero":
+            o[0] = 1
+        elif bad == "short_of_the_text":
+            o[-1] -= 2
+        else:
+            o[2] = o[1] - 1
+        d_bad = torch.from_numpy(o).cuda()
+        with pytest.raises(_lib.BfkError) as ei:
+            ctx.build_csr_device(d_text.data_ptr(), len(buf), d_bad.data_ptr(), len(rows), " ")
+        assert ei.value.code == -1, bad
+    with pytest.raises(_lib.BfkError):
+        ctx.build_csr_device(0, len(buf), d_off.data_ptr(), len(rows), " ")
+    with pytest.raises(_lib.Unsupported):
+        ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), "||")
+    nnz, nv = ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ")  # and the context still works
+    assert (nnz, nv) == (5, 3)
+    ctx.close()
+
+
+def test_pinned_host_buffer_for_the_text():
+    """bfk_host_alloc / bfk_host_free: a caller builds its text in page-locked memory and hands that to bfk_cluster_text"""
+    rows = list(dict.fromkeys(generate_profiles(20000)))
+    buf, off = _lib.pack_rows(rows)
+    want, _, nnz, nv = _lib.cluster_text(buf, off, " ", 1)
+    pin = _lib.PinnedBuffer(len(buf))
+    pin.view[:] = np.frombuffer(buf, dtype=np.uint8)
+    out = np.empty(len(rows), dtype=np.int32)
+    got, _, nnz2, nv2 = _lib.cluster_text(pin, off, " ", 1, labels_out=out)
+    assert got is out[: len(rows)] or np.shares_memory(got, out)
+    assert np.array_equal(got, want) and (nnz2, nv2) == (nnz, nv)
+    pin.free()
+    pin.free()  # idempotent
+    z = _lib.PinnedBuffer(0)
+    z.free()
+
+
 def test_cluster_text_falls_back_to_the_host_tokeniser_for_inputs_the_device_declines():
     rows = ["A||B", "A||B||C", "Q", "A||B"]
     buf, off = _lib.pack_rows(rows)
