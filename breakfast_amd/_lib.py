@@ -590,7 +590,13 @@ class Context:
         _check(rc)
         self.n_rows = int(n_rows)
 
-    def download_csr(self):
+    def download_csr(self, n_rows=None, nnz=None):
+        """the bound CSR as numpy arrays; its sizes come from a bfk_ctx_sync unless the caller knows them"""
+        if n_rows is None or nnz is None:
+            st = Stats()  # (rows and entries of the CSR that is bound: also completes a text step's open bind)
+            _check(self.lib.bfk_ctx_sync(self.h, C.byref(st)))
+            n_rows, nnz = int(st.n_rows), int(st.nnz)
+        self.n_rows, self.nnz = int(n_rows), int(nnz)
         indptr = np.empty(self.n_rows + 1, dtype=np.int32)
         indices = np.empty(max(self.nnz, 1), dtype=np.int32)
         _check(self.lib.bfk_ctx_download_csr(self.h, _p32(indptr), _p32(indices)))

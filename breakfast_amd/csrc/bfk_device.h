@@ -61,6 +61,10 @@ struct JoinArgs {
     int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
     uint32_t mask, bmask;
     int dup_cap;
+    const int *dyn;    // NULL, or the device words of a bind the host has not completed yet (k_maxlen's outputs + the tokeniser's
+                       // counters: [0] longest row, [1] negative row length seen, [3] nnz, [10] tokeniser failure flags): the kernels
+                       // take nnz and the longest row from there, and do nothing when the CSR is unusable or outside what the host
+                       // assumed (a row over JOIN_INLINE_ROW tokens, no token at all: Counters::join_fail = 2, the host redoes the step)
     int inline_exact;  // no row of the bound CSR is longer than JOIN_INLINE_ROW: k_join decides every match itself, no k_verify launch
     int dbg;  // BFK_JOIN_DEBUG (timing experiments, results invalid): 1 no settle, 2 no table probe, 4 no queueing of
               // bitmap hits, 8 no table insert, 16 no clearing, 32 no unions, 128 no scattered bitmap loads, 256 no bitmap atomicOr
@@ -125,7 +129,16 @@ constexpr int TOK_TEXT_SLACK = 64;                     // separator bytes behind
 constexpr uint32_t TOK_MAX_LEN = 65534;                // longest token the table word can describe (16-bit length)
 constexpr unsigned TOK_HOLD_UNITS = 17;                // hash units (4 KiB) at the end of a text piece that wait for the next piece: > TOK_MAX_LEN + 64 bytes
 constexpr int TOK_MAX_PROBE = 512;                     // probe chain at which the table counts as too full
-constexpr unsigned long long TOK_EMPTY = ~0ull;        // free slot of the vocabulary table {tag16 : len16 : offset32}
+constexpr unsigned long long TOK_EMPTY = ~0ull;        // free slot of the vocabulary table
+constexpr int TOK_LIST_CAP = 1024;                     // token starts a wave lists at a time (a 4 KiB unit with more is taken window by window)
+constexpr int TOK_LOOKUP_U = 10;                       // table lookups a lane keeps in flight (x 64 lanes: a typical unit of ~540 tokens is ONE round)
+// slot of the vocabulary table (bfk_text.hip): INLINE key {len8 (1..7) : 56 bits of token bytes} or HASHED key
+// {1 : tag15 : len16 : offset32}; `first` = smallest byte offset of an inline token; `id` = its first-appearance id
+struct alignas(16) TokSlot {
+    unsigned long long key;
+    uint32_t first;
+    int id;
+};
 enum : int { TOK_FAIL_ROWOFF = 1, TOK_FAIL_LONG = 2, TOK_FAIL_TABLE = 4 };
 
 struct TokCounters {
@@ -146,15 +159,17 @@ struct TokArgs {
     uint32_t *firstbits;       // ... / a token's first occurrence starts here
     uint32_t *winbase, *vocwin; // [T_pad / TOK_WIN]: tokens / vocabulary entries in front of every window inside its scan block
     uint32_t *blkbase, *vocblk; // [T_pad / TOK_PAD_BYTES + 1]: ... in front of every scan block (k_scan_single)
-    unsigned long long *table; // tmask + 1 slots
+    TokSlot *table;            // tmask + 1 slots of 16 bytes
     uint32_t tmask;
-    int *tabid;                // vocabulary id per slot
     uint32_t *tokslot;         // per token: its slot (aliases `indices`)
     uint32_t *indices;
     int *indptr;
     TokCounters *tc;
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
-    int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 2 no table loads, 4 no byte compares
+    int head_units;            // > 0: k_tok_hash runs the first so many units in a launch of their own before the rest
+    int sample;                // > 1: then every sample-th unit, then the others (three launches in all)
+    int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 1 no atomicMin of a found token's first offset,
+                               // 2 no table loads, 4 no lookups at all (staging + list only), 8 no head block
 };
 int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_pieces, const unsigned *piece_blk,
                     hipEvent_t *piece_ev);  // bfk_text.hip

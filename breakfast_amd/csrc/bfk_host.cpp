@@ -81,6 +81,9 @@ struct bfk_ctx {
     int4 *d_srec = nullptr;
     uint32_t *d_sig1 = nullptr, *d_sigu1 = nullptr, *d_sigu2 = nullptr;
     bool need_zero = true;  // head (counters + histogram) must be memset before the next run
+    bool ctr_dirty = true;  // the Counters block alone must be zeroed before the next run (first use, after a failure or a change of
+                            // path): a join step after a bind zeroes only that and leaves the histogram — stale by the bind's new
+                            // row lengths, need_zero — to the next step that uses it
     int64_t rows_cap = 0;
     int4 *d_tiles = nullptr;
     int64_t tile_cap = 0, tile_slots_cap = 0;
@@ -119,10 +122,8 @@ struct bfk_ctx {
     long long *tk_rowoff = nullptr;
     char *tk_zero = nullptr;  // [TokCounters | rowbits | firstbits]: zeroed by ONE memset per build
     uint32_t *tk_bits = nullptr, *tk_winbase = nullptr;
-    unsigned long long *tk_table = nullptr;
-    int *tk_tabid = nullptr;
-    int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_table_cap = 0,
-            tk_tabid_cap = 0;
+    TokSlot *tk_table = nullptr;
+    int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_table_cap = 0;
     int tk_grow = 0;  // how often the table was enlarged 8x for this context's inputs (kept: the next input is likely alike)
     hipEvent_t tk_ev[7] = {};
     bool tk_ev_ready = false;
@@ -133,6 +134,32 @@ struct bfk_ctx {
     bfk_text_stats tk_stats{};
     bool tok_pending = false;  // the tokeniser's counters (d_small[8..15]) are to come back with the next bind's copy
     int tok_host[8] = {0};
+    int *h_small = nullptr;    // pinned host copies of d_small (16 ints each): slot 0 for binds the host waits for, slots 1 .. SPEC_RING for open text steps
+    // Text steps whose bind the host has not completed yet: bfk_ctx_cluster_text_device enqueued the clustering kernels behind
+    // the tokeniser with the token count and the longest row read ON THE DEVICE (JoinArgs::dyn) and returned.  Up to SPEC_RING
+    // such steps may be open at once — a caller that streams batches enqueues the next step while the last one runs; every
+    // other entry (bfk_ctx_sync first of all) completes them in order through ctx_enter: the counters of each step have
+    // landed in its own pinned slot, and what a step's assumptions did not cover is redone — that step and, in order, every
+    // later one (they wrote their results behind it).
+    struct TokPlan {
+        uint8_t *d_text = nullptr;
+        const long long *d_rowoff = nullptr;
+        int64_t base = 0, T = 0, n_rows = 0;
+        char sep = ' ';
+        bool strict = false;
+        int n_pieces = 1;
+        unsigned piece_blk[9] = {0};
+    };
+    struct SpecStep {
+        TokPlan tp;
+        int d = 0;
+        void *labels = nullptr;
+        hipEvent_t ev = nullptr;  // recorded behind the copy of the step's counters
+    };
+    static constexpr int SPEC_RING = 4;
+    SpecStep spec_ring[SPEC_RING];
+    int spec_head = 0, spec_count = 0;  // oldest open step, number of open steps
+    bool spec_enqueueing = false;       // ctx_enqueue is being called for a device-driven step (JoinArgs::dyn is set)
     // last run
     bool ran = false;
     int last_d = 0, last_w1 = 0, last_shards = 1;
@@ -140,9 +167,13 @@ struct bfk_ctx {
     bfk_stats stats{};
 };
 
-static int ctx_enter(bfk_ctx *c) {
+static int ctx_spec_finish(bfk_ctx *c);
+
+// every entry point starts here; one that finds a text step whose bind is still open (spec_pending) completes it first
+static int ctx_enter(bfk_ctx *c, bool finish_spec = true) {
     if (!c) return fail(BFK_EARG, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    if (finish_spec && c->spec_count > 0) return ctx_spec_finish(c);
     return BFK_OK;
 }
 
@@ -180,7 +211,7 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
         return fail(BFK_EHIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess || hipHostMalloc((void **)&c->h_small, 64 * (bfk_ctx::SPEC_RING + 1), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&c->d_blk_stats, (size_t)VERIFY_GRID_MAX * 4 * sizeof(int)) != hipSuccess) {
         delete c;
         return fail(BFK_ENOMEM, "hipMalloc failed");
@@ -194,12 +225,15 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
     if (!c) return BFK_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    c->spec_count = 0;
+    for (auto &st : c->spec_ring)
+        if (st.ev) (void)hipEventDestroy(st.ev);
     void *ptrs[] = {c->own_indptr, c->own_indices, c->d_head,       c->d_start3, c->d_gkey,  c->d_srec,  c->d_sigu1,
                     c->d_parent,   c->d_gcnt,      c->d_sig1,       c->d_tiles,  c->d_rowkey, c->d_rowrank,
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
-                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid};
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -209,6 +243,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->tk_piece_ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->tk_start_ev) (void)hipEventDestroy(c->tk_start_ev);
     if (c->tk_copy_stream) (void)hipStreamDestroy(c->tk_copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -240,6 +275,7 @@ extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
     if (mode < 0 || mode > 3) return fail(BFK_EARG, "candidate path: 0 auto, 1 all-pairs, 2 variant join, 3 prefix groups");
     if (mode != c->path_mode) {  // the other path's per-step invariants (clean histogram / cleared table sets) are void
         c->need_zero = true;
+        c->ctr_dirty = true;
         c->join_clear = true;
         c->last_tiles = 0;
     }
@@ -305,6 +341,7 @@ static int ctx_size_workspace(bfk_ctx *c, int d_hint) {
             return fail(BFK_ENOMEM, "hipMalloc(histogram) failed");
         c->bins_cap = bins3;
         c->need_zero = true;
+        c->ctr_dirty = true;
     }
     if (c->hist_copies != want_copies) c->need_zero = true;  // another stride: the copies must be clean
     c->hist_copies = want_copies;
@@ -377,7 +414,8 @@ static int ctx_after_bind(bfk_ctx *c) {
     c->max_tok = -1;
     c->ran = false;
     c->need_zero = true;  // bins are laid out by kcap
-    c->join_clear = true;
+    // (the variant join's table sets keep their state over a bind: the set the last step filled is cleared by the next step's
+    // k_jhash, the other one is clean — whatever CSR comes next; ctx_size_join asks for a clearing when their size changes)
     c->join_off = false;
     c->pg_off = false;
     return ctx_size_workspace(c, 0);
@@ -423,13 +461,15 @@ extern "C" int64_t bfk_text_device_bytes(int64_t text_bytes) {
 }
 
 // The tokeniser on text that is RESIDENT IN HBM: d_text holds T bytes of rows and has room for bfk_text_device_bytes(T);
-// d_rowoff = int64[n_rows + 1] on the device, offsets relative to `base`.  `pieces` > 1: the text is still arriving on the copy
+// d_rowoff = int64[n_rows + 1] on the device, offsets relative to `base`.  `n_pieces` > 1: the text is still arriving on the copy
 // stream, piece by piece (host wrapper below).  `strict`: the offsets come from the caller's device memory, the kernels also
-// check row_off[0] == base and row_off[n_rows] == base + T (the host wrapper has checked its own).  Leaves the CSR bound.
-// ONE wait for the device inside: nnz, the longest row and the tokeniser's counters come back in one small copy (the
-// clustering kernels' grids and workspace are sized from them).
-static int ctx_tokenize(bfk_ctx *c, uint8_t *d_text, const long long *d_rowoff, int64_t base, int64_t T, int64_t n_rows, char sep,
-                        bool strict, int n_pieces, const unsigned *piece_blk, int64_t *nnz_out, int32_t *n_vocab_out) {
+// check row_off[0] == base and row_off[n_rows] == base + T (the host wrapper has checked its own).
+//   ctx_tok_launch  allocations, clearing, the tokenising kernels, k_maxlen over the new indptr, and ONE small copy of the
+//                   counters (token count, longest row, failure flags) into pinned host memory — all enqueued, no wait
+//   ctx_tok_finish  waits for the stream and completes the bind from those counters (workspace sized by the longest row);
+//                   *retry: the vocabulary table was too small, it has been enlarged, launch again
+static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, int h_slot = 0, hipEvent_t done_ev = nullptr) {
+    const int64_t T = tp.T, n_rows = tp.n_rows;
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     // every token but the last of a row is followed by a separator: at most T/2 + n_rows + 1 tokens
     const int64_t nnz_cap = T / 2 + n_rows + 1;
@@ -446,70 +486,86 @@ static int ctx_tokenize(bfk_ctx *c, uint8_t *d_text, const long long *d_rowoff, 
     if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
     hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
-    HIP_TRY(hipMemsetAsync(d_text + T, (unsigned char)sep, (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
-    TokCounters tc{};
-    int rc_bind = BFK_OK;
-    for (int attempt = 0;; attempt++) {
-        // vocabulary table: 1/32 slot per possible token (real inputs: ~8 bytes per token — a quarter of the bound — and a
-        // vocabulary of a few % of the tokens: load below 20%); an input with more distinct tokens overflows the probe
-        // limit, the table grows 8x (twice at most: 2 slots per possible token) and the kernels run again on the
-        // resident text
-        int64_t slots = 1 << 16;
-        while (slots < nnz_cap / 32) slots <<= 1;
-        slots <<= 3 * c->tk_grow;
-        if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
-        if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
-        if (int rc = dev_realloc(&c->tk_tabid, &c->tk_tabid_cap, slots)) return rc;
-        HIP_TRY(hipMemsetAsync(c->tk_zero, 0, (size_t)z_bytes, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_small + 8, 0, 32, c->stream));
-        HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * 8, c->stream));
-        TokArgs a{};
-        a.text = d_text;
-        a.row_off = d_rowoff;
-        a.base = base;
-        a.T = (uint32_t)T;
-        a.T_pad = (uint32_t)T_pad;
-        a.n_rows = (int)n_rows;
-        a.sep = (uint8_t)sep;
-        a.strict = strict ? 1 : 0;
-        a.tc = (TokCounters *)(c->d_small + 8);
-        a.rowbits = (uint32_t *)(c->tk_zero + z_rowbits);
-        a.firstbits = (uint32_t *)(c->tk_zero + z_firstbits);
-        a.startbits = c->tk_bits;
-        a.boundbits = c->tk_bits + bit_words;
-        a.winbase = c->tk_winbase;
-        a.vocwin = c->tk_winbase + n_win;
-        a.blkbase = c->tk_winbase + 2 * n_win;
-        a.vocblk = c->tk_winbase + 2 * n_win + n_blk;
-        a.table = c->tk_table;
-        a.tmask = (uint32_t)(slots - 1);
-        a.tabid = c->tk_tabid;
-        a.tokslot = c->own_indices;
-        a.indices = c->own_indices;
-        a.indptr = c->own_indptr;
-        a.nnz_cap = nnz_cap;
-        a.dbg = getenv("BFK_TOK_DEBUG") ? atoi(getenv("BFK_TOK_DEBUG")) : 0;
-        // (a second attempt — the table grew — finds the text resident: no pieces to wait for)
-        const bool pieces = n_pieces > 1 && attempt == 0;
-        if (int e = launch_tokenize(a, c->stream, ev, pieces ? n_pieces : 1, piece_blk, pieces ? c->tk_piece_ev : nullptr))
-            return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
-        // bind: its one copy + sync (longest row, nnz) also lands the tokeniser's counters
-        c->d_indptr = c->own_indptr;
-        c->d_indices = c->own_indices;
-        c->n = n_rows;
-        c->tok_pending = true;
-        rc_bind = ctx_after_bind(c);
-        if (rc_bind == BFK_EHIP) return rc_bind;
-        static_assert(sizeof(TokCounters) == sizeof c->tok_host, "TokCounters = d_small[8..15]");
-        memcpy(&tc, c->tok_host, sizeof tc);
-        if (!(tc.fail & TOK_FAIL_TABLE) || (tc.fail & (TOK_FAIL_ROWOFF | TOK_FAIL_LONG))) break;
-        if (attempt >= 2 || slots >= ((int64_t)1 << 31)) break;
-        c->tk_grow++;
+    if (attempt == 0) HIP_TRY(hipMemsetAsync(tp.d_text + T, (unsigned char)tp.sep, (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
+    // vocabulary table: 1/32 slot per possible token (real inputs: ~8 bytes per token — a quarter of the bound — and a
+    // vocabulary of a few % of the tokens: load below 20%); an input with more distinct tokens overflows the probe
+    // limit, the table grows 8x (twice at most: 2 slots per possible token) and the kernels run again on the
+    // resident text
+    int64_t slots = 1 << 16;
+    while (slots < nnz_cap / 32) slots <<= 1;
+    slots <<= 3 * c->tk_grow;
+    if (const char *e = getenv("BFK_TOK_SLOTS_SHIFT")) slots = atoi(e) >= 0 ? slots << atoi(e) : std::max<int64_t>(1 << 12, slots >> -atoi(e));  // (experiments)
+    if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
+    if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
+    HIP_TRY(hipMemsetAsync(c->tk_zero, 0, (size_t)z_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_small, 0, 64, c->stream));  // k_maxlen's outputs [0..7] and the tokeniser's counters [8..15]
+    HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * sizeof(TokSlot), c->stream));
+    TokArgs a{};
+    a.text = tp.d_text;
+    a.row_off = tp.d_rowoff;
+    a.base = tp.base;
+    a.T = (uint32_t)T;
+    a.T_pad = (uint32_t)T_pad;
+    a.n_rows = (int)n_rows;
+    a.sep = (uint8_t)tp.sep;
+    a.strict = tp.strict ? 1 : 0;
+    a.tc = (TokCounters *)(c->d_small + 8);
+    a.rowbits = (uint32_t *)(c->tk_zero + z_rowbits);
+    a.firstbits = (uint32_t *)(c->tk_zero + z_firstbits);
+    a.startbits = c->tk_bits;
+    a.boundbits = c->tk_bits + bit_words;
+    a.winbase = c->tk_winbase;
+    a.vocwin = c->tk_winbase + n_win;
+    a.blkbase = c->tk_winbase + 2 * n_win;
+    a.vocblk = c->tk_winbase + 2 * n_win + n_blk;
+    a.table = c->tk_table;
+    a.tmask = (uint32_t)(slots - 1);
+    a.tokslot = c->own_indices;
+    a.indices = c->own_indices;
+    a.indptr = c->own_indptr;
+    a.nnz_cap = nnz_cap;
+    a.dbg = getenv("BFK_TOK_DEBUG") ? atoi(getenv("BFK_TOK_DEBUG")) : 0;
+    a.head_units = getenv("BFK_TOK_HEAD_UNITS") ? atoi(getenv("BFK_TOK_HEAD_UNITS")) : 16;
+    a.sample = getenv("BFK_TOK_SAMPLE") ? atoi(getenv("BFK_TOK_SAMPLE")) : 16;
+    // (a second attempt — the table grew — finds the text resident: no pieces to wait for)
+    const bool pieces = tp.n_pieces > 1 && attempt == 0;
+    if (int e = launch_tokenize(a, c->stream, ev, pieces ? tp.n_pieces : 1, tp.piece_blk, pieces ? c->tk_piece_ev : nullptr))
+        return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
+    // the bind's device half: longest row, token count (k_maxlen over the new indptr), then the counters on their way to the host
+    c->d_indptr = c->own_indptr;
+    c->d_indices = c->own_indices;
+    c->n = n_rows;
+    if (n_rows > 0) {
+        if (int e = launch_maxlen(c->d_indptr, (int)n_rows, c->d_small, c->stream))
+            return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
     }
+    HIP_TRY(hipMemcpyAsync(c->h_small + 16 * h_slot, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
+    if (done_ev) HIP_TRY(hipEventRecord(done_ev, c->stream));
+    return BFK_OK;
+}
+
+static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, int h_slot = 0, hipEvent_t done_ev = nullptr) {
+    *retry = false;
+    if (done_ev) HIP_TRY(hipEventSynchronize(done_ev));  // (the step's counters have landed; its clustering kernels may still run)
+    else HIP_TRY(hipStreamSynchronize(c->stream));
+    int h[16];
+    memcpy(h, c->h_small + 16 * h_slot, sizeof h);
+    TokCounters tc{};
+    static_assert(sizeof(TokCounters) == 8 * sizeof(int), "TokCounters = d_small[8..15]");
+    memcpy(&tc, h + 8, sizeof tc);
+    memcpy(c->tok_host, h + 8, sizeof c->tok_host);
+    if (getenv("BFK_TOK_DEBUG") && (atoi(getenv("BFK_TOK_DEBUG")) & 32))
+        fprintf(stderr, "[bfk] tokeniser: %d tokens deferred by %d waves, nnz %u, vocabulary %u\n", tc.pad_[0], tc.pad_[1], tc.nnz, tc.n_vocab);
     c->tk_stats = bfk_text_stats{};
-    c->tk_stats.text_bytes = T;
-    c->tk_stats.n_rows = n_rows;
+    c->tk_stats.text_bytes = tp.T;
+    c->tk_stats.n_rows = tp.n_rows;
     c->tk_stats.table_slots = (int64_t)c->tk_table_cap;
+    if ((tc.fail & TOK_FAIL_TABLE) && !(tc.fail & (TOK_FAIL_ROWOFF | TOK_FAIL_LONG)) && c->tk_grow < 2 &&
+        c->tk_table_cap < ((int64_t)1 << 31)) {
+        c->tk_grow++;
+        *retry = true;
+        return BFK_OK;
+    }
     c->tk_stats.table_growths = c->tk_grow;
     if (tc.fail) {
         c->n = -1;  // nothing usable is bound
@@ -517,12 +573,23 @@ static int ctx_tokenize(bfk_ctx *c, uint8_t *d_text, const long long *d_rowoff, 
         if (tc.fail & TOK_FAIL_LONG) return fail(BFK_EUNSUPPORTED, "device tokeniser: a token of 64 KiB or more (the host tokeniser takes it)");
         return fail(BFK_EUNSUPPORTED, "device tokeniser: vocabulary table overflow (the host tokeniser takes it)");
     }
-    if (rc_bind) return rc_bind;
+    // the bind's host half (what ctx_after_bind does for a CSR that comes from elsewhere)
+    c->last_tiles = 0;
+    if (c->n > 0 && (h[1] || h[4] != 0 || h[3] < 0)) return fail(BFK_EARG, "malformed CSR: indptr must start at 0 and be non-decreasing");
+    c->nnz = c->n > 0 ? h[3] : 0;
+    c->kcap = h[0];
+    c->n_short = h[2];
+    c->ran = false;
+    c->need_zero = true;  // bins are laid out by kcap
+    c->join_off = false;
+    c->pg_off = false;
+    c->tok_pending = false;
+    if (int rc = ctx_size_workspace(c, 0)) return rc;
     if ((int64_t)tc.nnz != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
     c->max_tok = (int)tc.n_vocab - 1;  // ids are 0 .. n_vocab - 1: the prefix-group path needs no k_maxtok pass
     c->tk_stats.nnz = tc.nnz;
     c->tk_stats.n_vocab = (int32_t)tc.n_vocab;
-    if (ev) {
+    if (hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr) {  // (profiled steps are completed one at a time: the events are this step's)
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
         if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->tk_stats.ms_hash = ms;
@@ -530,8 +597,110 @@ static int ctx_tokenize(bfk_ctx *c, uint8_t *d_text, const long long *d_rowoff, 
         if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->tk_stats.ms_ids = ms;
         if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
     }
-    if (nnz_out) *nnz_out = tc.nnz;
-    if (n_vocab_out) *n_vocab_out = (int32_t)tc.n_vocab;
+    return BFK_OK;
+}
+
+// launch + finish (and again while the vocabulary table has to grow): the CSR is bound when this returns
+static int ctx_tokenize(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int64_t *nnz_out, int32_t *n_vocab_out) {
+    for (int attempt = 0;; attempt++) {
+        if (int rc = ctx_tok_launch(c, tp, attempt)) return rc;
+        bool retry = false;
+        if (int rc = ctx_tok_finish(c, tp, &retry)) return rc;
+        if (!retry) break;
+    }
+    if (nnz_out) *nnz_out = c->tk_stats.nnz;
+    if (n_vocab_out) *n_vocab_out = c->tk_stats.n_vocab;
+    return BFK_OK;
+}
+
+static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out, bool allow_join);
+
+// May the clustering kernels of a text step go out BEFORE the host knows the token count and the longest row?  Only the
+// variant join (max_dist 1, the CLI's default, up to 800k rows) has a device-driven form: its kernels read both from the
+// counters k_maxlen leaves in device memory (JoinArgs::dyn), their grids are sized by the most tokens the text can hold, and
+// they assume what nearly every profile input satisfies — no row longer than JOIN_INLINE_ROW tokens (k_join then decides every
+// match itself: no k_verify launch) and at least one token.  An input outside that flags it and is redone by ctx_spec_finish.
+static bool spec_wanted(const bfk_ctx *c, int64_t n_rows, int64_t T, int32_t max_dist) {
+    if (const char *e = getenv("BFK_SPEC")) if (atoi(e) == 0) return false;
+    if (const char *e = getenv("BFK_JOIN")) if (atoi(e) == 0) return false;
+    if (getenv("BFK_JOIN_INLINE") || getenv("BFK_JOIN_DEBUG")) return false;
+    if (max_dist != 1 || n_rows < 1 || n_rows > 800000 || c->edge_capture) return false;
+    if (c->path_mode != 0 && c->path_mode != 2) return false;
+    return T / 2 + n_rows + 1 < ((int64_t)1 << 30);
+}
+
+static int ctx_spec_finish_one(bfk_ctx *c);
+
+// tokeniser launched -> the join's kernels behind it on device-resident counts; nothing waits
+static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_dist, void *d_labels_out) {
+    // with the ring full the oldest open step is completed first (it finished long ago); profiled steps one at a time
+    while (c->spec_count >= (c->profiling ? 1 : bfk_ctx::SPEC_RING))
+        if (int rc = ctx_spec_finish_one(c)) return rc;
+    const int idx = (c->spec_head + c->spec_count) % bfk_ctx::SPEC_RING;
+    bfk_ctx::SpecStep &st = c->spec_ring[idx];
+    if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    st.tp = tp;
+    st.d = max_dist;
+    st.labels = d_labels_out;
+    if (int rc = ctx_tok_launch(c, tp, 0, 1 + idx, st.ev)) return rc;
+    // what the host assumes until the counters are back: the most tokens the text can hold, no row over JOIN_INLINE_ROW
+    c->nnz = tp.T / 2 + tp.n_rows + 1;
+    c->kcap = JOIN_INLINE_ROW;
+    c->n_short = 0;
+    c->max_tok = -1;
+    c->last_tiles = 0;
+    c->join_off = false;
+    c->pg_off = false;
+    c->need_zero = true;
+    c->spec_enqueueing = true;  // (ctx_enqueue marks the plan device-driven by this)
+    const int rc = ctx_enqueue(c, max_dist, 0, 1, d_labels_out, true);
+    c->spec_enqueueing = false;
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        c->n = -1;
+        return rc;
+    }
+    c->spec_count++;
+    return BFK_OK;
+}
+
+// completes the bind of the OLDEST open text step from the counters in its slot.  What its assumptions did not cover — a
+// vocabulary table that has to grow, a row over JOIN_INLINE_ROW tokens, an all-empty input — is redone with the host in the
+// loop, and so is, in order, every step enqueued behind it (their results were written behind this step's).
+static int ctx_spec_finish_one(bfk_ctx *c) {
+    if (c->spec_count <= 0) return BFK_OK;
+    const int idx = c->spec_head;
+    const bfk_ctx::SpecStep st = c->spec_ring[idx];
+    c->spec_head = (c->spec_head + 1) % bfk_ctx::SPEC_RING;
+    c->spec_count--;
+    bool retry = false;
+    int rc = ctx_tok_finish(c, st.tp, &retry, 1 + idx, st.ev);
+    const bool outside = !rc && !retry && (c->kcap > JOIN_INLINE_ROW || c->nnz <= 0);
+    if (!rc && !retry && !outside) {
+        c->ran = true;  // (ctx_tok_finish cleared it: the step it belongs to has been enqueued)
+        return BFK_OK;
+    }
+    // this step again — and the open ones behind it — one after the other, each completed before the next
+    std::vector<bfk_ctx::SpecStep> redo{st};
+    while (c->spec_count > 0) {
+        redo.push_back(c->spec_ring[c->spec_head]);
+        c->spec_head = (c->spec_head + 1) % bfk_ctx::SPEC_RING;
+        c->spec_count--;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->need_zero = c->ctr_dirty = true;
+    c->join_clear = true;
+    if (rc) return rc;  // (malformed offsets, a token of 64 KiB: the caller's error; the later steps are dropped with it)
+    for (const bfk_ctx::SpecStep &r : redo) {
+        if (int r2 = ctx_tokenize(c, r.tp, nullptr, nullptr)) return r2;
+        if (int r2 = ctx_enqueue(c, r.d, 0, 1, r.labels, true)) return r2;
+    }
+    return BFK_OK;
+}
+
+static int ctx_spec_finish(bfk_ctx *c) {
+    while (c->spec_count > 0)
+        if (int rc = ctx_spec_finish_one(c)) return rc;
     return BFK_OK;
 }
 
@@ -555,8 +724,11 @@ static int ctx_check_text_args(const int64_t n_rows, const char *sep, int64_t se
 }
 
 // host buffers: the text and the offsets cross PCIe once into context-owned device buffers, then ctx_tokenize
+// spec_d >= 0: the caller clusters at that max_dist right away into spec_labels — where spec_wanted() allows it the clustering
+// kernels are enqueued behind the tokeniser here (*spec_done) instead of after a wait for its counters
 static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
-                          int64_t *nnz_out, int32_t *n_vocab_out) {
+                          int64_t *nnz_out, int32_t *n_vocab_out, int32_t spec_d = -1, void *spec_labels = nullptr,
+                          bool *spec_done = nullptr) {
     if (!row_off) return fail(BFK_EARG, "bfk_ctx_build_csr: null argument");
     const int64_t base = n_rows >= 0 ? row_off[0] : 0, T = n_rows >= 0 ? row_off[n_rows] - base : -1;
     if (int rc = ctx_check_text_args(n_rows, sep, sep_len, T)) return rc;
@@ -611,7 +783,30 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         }
     }
     if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
-    const int rc = ctx_tokenize(c, c->tk_text, c->tk_rowoff, base, T, n_rows, sep[0], false, n_pieces, piece_blk, nnz_out, n_vocab_out);
+    bfk_ctx::TokPlan tp;
+    tp.d_text = c->tk_text;
+    tp.d_rowoff = c->tk_rowoff;
+    tp.base = base;
+    tp.T = T;
+    tp.n_rows = n_rows;
+    tp.sep = sep[0];
+    tp.strict = false;
+    tp.n_pieces = n_pieces;
+    memcpy(tp.piece_blk, piece_blk, sizeof tp.piece_blk);
+    int rc;
+    if (spec_d >= 0 && spec_wanted(c, n_rows, T, spec_d)) {
+        // bfk_cluster_text: the clustering kernels follow the tokeniser without the host in between; the caller's buffers are
+        // released by the guard above (it waits for the stream), the bind is completed by the bfk_ctx_sync that follows
+        rc = ctx_spec_enqueue(c, tp, spec_d, spec_labels);
+        if (!rc) rc = ctx_spec_finish(c);  // (ONE wait: for the copies, the tokeniser and the clustering kernels together)
+        if (!rc) *spec_done = true;
+    } else {
+        rc = ctx_tokenize(c, tp, nnz_out, n_vocab_out);
+    }
+    if (!rc && (nnz_out || n_vocab_out)) {
+        if (nnz_out) *nnz_out = c->tk_stats.nnz;
+        if (n_vocab_out) *n_vocab_out = c->tk_stats.n_vocab;
+    }
     if (!rc && ev) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->tk_stats.ms_h2d = ms;
@@ -628,15 +823,38 @@ extern "C" int bfk_ctx_build_csr_device(bfk_ctx *c, void *d_text, int64_t text_b
     if (!d_text || !d_row_off) return fail(BFK_EARG, "bfk_ctx_build_csr_device: null device pointer");
     if (n_rows == 0 && text_bytes != 0) return fail(BFK_EARG, "bfk_ctx_build_csr_device: text without rows");
     if (int rc = ctx_text_events(c)) return rc;
-    return ctx_tokenize(c, (uint8_t *)d_text, (const long long *)d_row_off, 0, text_bytes, n_rows, sep[0], true, 1, nullptr, nnz_out,
-                        n_vocab_out);
+    bfk_ctx::TokPlan tp;
+    tp.d_text = (uint8_t *)d_text;
+    tp.d_rowoff = (const long long *)d_row_off;
+    tp.T = text_bytes;
+    tp.n_rows = n_rows;
+    tp.sep = sep[0];
+    tp.strict = true;
+    return ctx_tokenize(c, tp, nnz_out, n_vocab_out);
 }
 
-// a1 .. a8 with the text RESIDENT IN HBM and the labels left in HBM: what bench.py times as one step
+// a1 .. a8 with the text RESIDENT IN HBM and the labels left in HBM: what bench.py times as one step.  Where the variant join
+// serves the step (spec_wanted) nothing waits between the tokeniser and the clustering kernels; elsewhere the host sizes the
+// clustering kernels from the tokeniser's counters first (one wait).
 extern "C" int bfk_ctx_cluster_text_device(bfk_ctx *c, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
                                            const char *sep, int64_t sep_len, int32_t max_dist, void *d_labels_out) {
     if (max_dist < 0) return fail(BFK_EARG, "max_dist must be >= 0");
     if (n_rows > 0 && !d_labels_out) return fail(BFK_EARG, "null labels");
+    if (int rc = ctx_enter(c)) return rc;
+    if (int rc = ctx_check_text_args(n_rows, sep, sep_len, text_bytes)) return rc;
+    if (!d_text || !d_row_off) return fail(BFK_EARG, "bfk_ctx_cluster_text_device: null device pointer");
+    if (n_rows == 0 && text_bytes != 0) return fail(BFK_EARG, "bfk_ctx_cluster_text_device: text without rows");
+    if (int rc = ctx_text_events(c)) return rc;
+    if (spec_wanted(c, n_rows, text_bytes, max_dist)) {
+        bfk_ctx::TokPlan tp;
+        tp.d_text = (uint8_t *)d_text;
+        tp.d_rowoff = (const long long *)d_row_off;
+        tp.T = text_bytes;
+        tp.n_rows = n_rows;
+        tp.sep = sep[0];
+        tp.strict = true;
+        return ctx_spec_enqueue(c, tp, max_dist, d_labels_out);
+    }
     if (int rc = bfk_ctx_build_csr_device(c, d_text, text_bytes, d_row_off, n_rows, sep, sep_len, nullptr, nullptr)) return rc;
     return bfk_ctx_cluster(c, max_dist, 0, 1, d_labels_out);
 }
@@ -669,6 +887,7 @@ extern "C" int bfk_ctx_build_csr(bfk_ctx *c, const char *buf, const int64_t *row
 
 extern "C" int bfk_ctx_text_stats(bfk_ctx *c, bfk_text_stats *out) {
     if (!c || !out) return fail(BFK_EARG, "null argument");
+    if (int rc = ctx_enter(c)) return rc;
     *out = c->tk_stats;
     return BFK_OK;
 }
@@ -970,7 +1189,10 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.mask = (uint32_t)(c->join_slots - 1);
         pl.ja.bmask = (uint32_t)(c->join_bits - 1);
         pl.ja.dbg = getenv("BFK_JOIN_DEBUG") ? atoi(getenv("BFK_JOIN_DEBUG")) : 0;
+        // a text step whose bind is still open: token count, longest row and the tokeniser's failure flags are read on the device
+        pl.ja.dyn = c->spec_enqueueing ? c->d_small : nullptr;
     }
+    if (c->spec_enqueueing && !pl.join) return fail(BFK_ESTATE, "internal: a device-driven text step needs the variant join");
     pl.pg = 0;
     if (!pl.join && pg_wanted(c, max_dist, n_shards)) {
         if (int rc = pg_key_bits(c, &pl.pg_tb)) return rc;
@@ -1000,10 +1222,14 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.pg_rowinfo = c->pg_rowinfo;
     }
     c->plan = pl;
-    if (c->need_zero) {  // steady state: k_plan leaves counters and histogram clean for the next step
+    if (pl.join) {  // (the join touches the counters only: a histogram made stale by a bind waits for the step that uses it)
+        if (c->ctr_dirty) HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters), c->stream));
+        c->ctr_dirty = false;
+    } else if (c->need_zero || c->ctr_dirty) {  // steady state: k_cells leaves counters and histogram clean for the next step
         HIP_TRY(hipMemsetAsync(c->d_head, 0, sizeof(Counters) + (size_t)c->hist_ints_cap * 4, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_chain, 0, (size_t)(c->bins_cap / 1024 + 2) * 8, c->stream));
         c->need_zero = false;
+        c->ctr_dirty = false;
     }
     hipEvent_t *evs = c->profiling ? c->ev[c->n_prof_calls++ % bfk_ctx::EV_SLOTS] : nullptr;
     if (int e = launch_pipeline(pl, c->stream, evs))
@@ -1114,7 +1340,7 @@ static int ctx_recover_overflow(bfk_ctx *c, Counters *h, int64_t *n_slices) {  /
 }
 
 extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
-    if (int rc = ctx_enter(c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;  // (completes the bind of a device-driven text step, redoing it where it has to)
     HIP_TRY(hipStreamSynchronize(c->stream));
     bfk_stats s{};
     s.n_rows = c->n < 0 ? 0 : c->n;
@@ -1123,7 +1349,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
     if (c->ran && c->n > 0) {
         Counters h;
         HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
-        if (h.err || h.err_rows) c->need_zero = true;
+        if (h.err || h.err_rows) c->need_zero = c->ctr_dirty = true;
         c->last_tiles = (int64_t)h.n_work;
         if (h.err_rows) return fail(BFK_EARG, "CSR changed after bind: a row is longer than at bind time");
         if (h.err & ERR_WORKCAP) return fail(BFK_EOVERFLOW, "band work list overflow (input too large for 32-bit unit counts)");
@@ -1147,7 +1373,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
             // or its candidates did not fit the queue: the step is redone on the all-pairs path, which has its own
             // recovery; a give-up also turns the join off for this CSR
             if (h.join_fail) c->join_off = true;
-            c->need_zero = true;
+            c->need_zero = c->ctr_dirty = true;
             c->join_clear = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1158,7 +1384,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         if (c->plan.pg && h.pg_fail) {
             // the prefix groups are too big to pay (the walk did nothing): the step is redone on the band kernels
             c->pg_off = true;
-            c->need_zero = true;
+            c->need_zero = c->ctr_dirty = true;
             if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(&h, c->d_head, sizeof(Counters), hipMemcpyDeviceToHost));
@@ -1349,7 +1575,7 @@ extern "C" int bfk_warmup(int device, int64_t rows_hint, int64_t nnz_hint) {
         c->n = n0;
         c->nnz = nnz0;
         c->kcap = k0;
-        c->need_zero = true;
+        c->need_zero = c->ctr_dirty = true;
         c->join_clear = true;
         if (rc) return rc;
     }
@@ -1499,7 +1725,9 @@ extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = ctx_enter(c)) return rc;
-    int rc = ctx_build_text(c, buf, row_off, n_rows, sep, sep_len, nnz_out, n_vocab_out);
+    if (int r2 = ctx_own_labels(c, n_rows)) return r2;
+    bool clustered = false;  // (the clustering kernels went out behind the tokeniser without a wait in between)
+    int rc = ctx_build_text(c, buf, row_off, n_rows, sep, sep_len, nnz_out, n_vocab_out, max_dist, c->own_labels, &clustered);
     if (rc == BFK_EUNSUPPORTED) {  // the host tokeniser (same contract) and an upload of its CSR
         std::vector<int32_t> indptr((size_t)n_rows + 1);
         int32_t *indices = nullptr, nv = 0;
@@ -1513,8 +1741,7 @@ extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t
         c->tk_stats.host_fallback = 1;
     }
     if (rc) return rc;
-    if (int r2 = ctx_own_labels(c, n_rows)) return r2;
-    rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
+    if (!clustered) rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
     if (!rc && indptr_out)  // the row lengths (n_features of the reference's frame, :287) ride along with the kernels
         if (hipMemcpyAsync(indptr_out, c->d_indptr, (size_t)(n_rows + 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail(BFK_EHIP, "bfk_cluster_text: indptr copy failed");

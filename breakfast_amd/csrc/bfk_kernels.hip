@@ -1489,6 +1489,11 @@ __device__ __forceinline__ uint32_t wave_add_to_lane63(uint32_t x) {
     return x;
 }
 
+// device-driven text steps (JoinArgs::dyn): is the CSR unusable (the tokeniser failed, a negative row length) / outside what the
+// host assumed when it sized the launch (a row over JOIN_INLINE_ROW tokens, no token at all)?  Wave-uniform scalar loads.
+__device__ __forceinline__ bool join_dyn_unusable(const int *dyn) { return (dyn[1] | dyn[10]) != 0; }
+__device__ __forceinline__ bool join_dyn_outside(const int *dyn) { return dyn[0] > JOIN_INLINE_ROW || dyn[3] <= 0; }
+
 // k_jhash: same row-to-wave layout as k_sig.  H of every row -> rowhash[i], bitmap bit, table entry
 // {H.y (tag) : row} by linear probing (load <= 1/8: 94% of the inserts take one CAS); parent[i] = i; counters
 // reset; next step's table set cleared.  A failed CAS returns the entry in the way: if its tag is this row's, the
@@ -1501,6 +1506,15 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
     constexpr int MAXRPW = 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (ja.dyn) {  // a text step whose bind the host has not completed: counts from the device (JoinArgs::dyn)
+        if (join_dyn_unusable(ja.dyn)) return;
+        nnz = ja.dyn[3];
+        kcap = ja.dyn[0];
+        if (join_dyn_outside(ja.dyn)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctr->join_fail = 2;
+            return;
+        }
+    }
     if (!(ja.dbg & 16)) {  // clear the other table set for the next step (this step never touches it)
         const size_t tid = (size_t)blockIdx.x * 1024 + threadIdx.x, nth = (size_t)gridDim.x * 1024;
         ulonglong2 *t2 = reinterpret_cast<ulonglong2 *>(ja.tab_next);
@@ -1667,6 +1681,10 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cshard = (blockIdx.x * 16 + wave) & (CAND_SHARDS - 1);
+    if (ja.dyn) {  // (see k_jhash)
+        if (join_dyn_unusable(ja.dyn) || join_dyn_outside(ja.dyn)) return;
+        nnz = ja.dyn[3];
+    }
     if (threadIdx.x == 0) s_edges = s_cands = 0;
     __syncthreads();
 
@@ -2765,8 +2783,10 @@ __global__ void k_compress(int *parent, int n) {
 }
 
 // (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
-__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue) {
+__global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue,
+                          const int *dyn) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dyn && (join_dyn_unusable(dyn) || join_dyn_outside(dyn))) return;  // (no forest was built: the host redoes the step)
     if (i == 0 && ctr) ctr->n_dup = 0;  // the dup list of the variant join: consumed, empty for the next step
     // k_verify was not launched because k_join decides every match of this CSR itself: a queue that is not empty all the
     // same means the step is redone on the all-pairs path
@@ -3055,7 +3075,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
     hipLaunchKernelGGL(k_flatten, dim3((std::max(pl.n, CAND_SHARDS) + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels, pl.ctr,
-                       pl.join && pl.join_skip_verify ? 1 : 0);
+                       pl.join && pl.join_skip_verify ? 1 : 0, pl.join ? pl.ja.dyn : nullptr);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return 0;
@@ -3172,7 +3192,7 @@ int launch_lists(int *parent, int n, const long long *off, const int *flat, long
                            n_lists, n, ctr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0);
+    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -3183,7 +3203,7 @@ int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labe
     dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr, skip, splice);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0);
+    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr);
     LAUNCH_CHECK();
     if (changed) {
         hipLaunchKernelGGL(k_changed, g, b, 0, st, (const int *)labels, gathered, n, changed);

@@ -25,9 +25,9 @@
 //                  empty -> compare-and-swap; tag and length equal -> the BYTES are compared (the table is exact: hash
 //                  collisions cost a probe, never an id) and the word is lowered to the smaller offset by atomicMin, so
 //                  a slot ends up holding the offset of the token's FIRST occurrence.  Per token: its slot is stored.
-//   k_tok_head     the same for the first 4 KiB of text alone, BEFORE k_tok_hash: the tokens every row carries are in the
-//                  table before 8000 waves ask for them at once (same-address atomics serialise at ~11 ns each: 357 us for
-//                  k_tok_hash at 100k rows without this launch, ~80 with it)
+//                  THREE launches: the first 16 units (64 KiB), every 16th unit of the rest, the others — the tokens that many
+//                  rows carry are in the table before 8000 waves ask for them at once (same-address compare-and-swaps
+//                  serialise at ~11 ns each: 1.3 ms for one launch at 100k rows)
 //   k_tok_rows     one thread per row: indptr[r] = number of token starts in front of row_off[r]; and one thread per
 //                  table slot: bit `first occurrence` set at the byte offset the slot holds
 //   k_voc_count    first-occurrence bits counted per window; k_scan_single again -> vocabulary entries in front of a window
@@ -92,13 +92,295 @@ __global__ __launch_bounds__(256) void k_tok_rowbits(TokArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// separator / token-start / token-bound masks of one 1 KiB window step: 16 bytes per lane -> 16-bit masks per lane.
+// `prev_sep`: is the byte in front of the window a separator (wave-uniform; nothing in front of the text counts as one).
+__device__ __forceinline__ void tok_masks(const uint4 v, uint32_t rb, uint32_t sepx4, uint32_t prev_sep, int lane, uint32_t *start,
+                                          uint32_t *bound, uint32_t *last_is_sep) {
+    const uint32_t m = eq_bytes4(v.x, sepx4) | (eq_bytes4(v.y, sepx4) << 4) | (eq_bytes4(v.z, sepx4) << 8) | (eq_bytes4(v.w, sepx4) << 12);
+    uint32_t cin = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, true) >> 15) & 1u;  // wave_shr:1
+    if (lane == 0) cin = prev_sep;
+    const uint32_t before_sep = ((m << 1) | cin) & 0xFFFFu;
+    *start = ~m & (before_sep | rb) & 0xFFFFu;
+    *bound = (m | rb) & 0xFFFFu;
+    *last_is_sep = ((uint32_t)__builtin_amdgcn_readlane((int)m, 63) >> 15) & 1u;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mur_step(uint32_t h, uint32_t w) {
+    w *= 0xCC9E2D51u;
+    w = (w << 15) | (w >> 17);
+    w *= 0x1B873593u;
+    h ^= w;
+    h = (h << 13) | (h >> 19);
+    return h * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t mur_final(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+
+__device__ __forceinline__ bool same_bytes(const uint8_t *p, const uint8_t *q, uint32_t len) {
+    uint32_t k = 0;
+    for (; k + 8 <= len; k += 8)
+        if (ldu64(p + k) != ldu64(q + k)) return false;
+    const uint32_t rem = len - k;  // (the buffers are padded: the tail reads stay inside)
+    if (rem == 0) return true;
+    const unsigned long long mask = (1ull << (8 * rem)) - 1ull;
+    return ((ldu64(p + k) ^ ldu64(q + k)) & mask) == 0ull;
+}
+
+// ---- the vocabulary table -------------------------------------------------------------------------------------------
+// 16-byte slots {key64, first32, id32}, open addressing, linear probing.  Two kinds of key:
+//   INLINE  (top byte = length 1 .. 7, low 56 bits = the token's bytes): the token IS the key — a lookup is one 16-byte load
+//           and one 64-bit compare, no bytes of the text are fetched (a mutation like A23403G is 7 bytes: every substitution
+//           of a 29 903-base genome fits).  `first` = smallest byte offset at which the token was seen (atomicMin).
+//   HASHED  (bit 63 set: {1 : tag15 : len16 : offset32}) for tokens of 8 bytes and more (insertions, del:11288:9): tag and
+//           length must match, then the BYTES are compared with the entry's occurrence; the word is lowered to the smaller
+//           offset by a 64-bit atomicMin.  The table is exact either way: a hash collision costs a probe, never an id.
+// Keys only ever appear; an entry's kind, length and bytes never change — so a PLAIN (cached) load that shows a key shows the
+// truth, and only a slot that looks free is read again past the caches before it is claimed by compare-and-swap.
+__device__ __forceinline__ uint32_t tok_entry_offset(const TokSlot &e) {
+    return (e.key >> 63) ? (uint32_t)e.key : e.first;
+}
+
+__device__ __forceinline__ uint32_t tok_hash_inline(unsigned long long key) {
+    uint32_t h = (uint32_t)key * 0x9E3779B1u;
+    h ^= h >> 15;
+    h += (uint32_t)(key >> 32) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+
+// a token of 8 bytes or more at byte offset j: length from the bound bits in global memory, hash over its bytes, HASHED entry
+__device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j) {
+    uint32_t w = (j + 1) >> 5;
+    uint32_t bw = a.boundbits[w] & (~0u << ((j + 1) & 31u));
+    const uint32_t w_max = (j + TOK_MAX_LEN + 64u) >> 5;  // (beyond: the token is too long whatever follows; the padding is all separators)
+    while (!bw && w < w_max) bw = a.boundbits[++w];
+    if (!bw) bw = 1u;
+    const uint32_t len = w * 32 + (uint32_t)__builtin_ctz(bw) - j;
+    if (len > TOK_MAX_LEN) {
+        atomicOr(&a.tc->fail, TOK_FAIL_LONG);
+        return 0;
+    }
+    const uint8_t *p = a.text + j;
+    uint32_t h = 0x9747B28Cu ^ len, k = 0;
+    for (; k + 4 <= len; k += 4) h = mur_step(h, ldu32(p + k));
+    if (len & 3u) h = mur_step(h, ldu32(p + k) & ((1u << (8 * (len & 3u))) - 1u));
+    h = mur_final(h);
+    const uint32_t hi = 0x80000000u | (h & 0x7FFF0000u) | (len & 0xFFFFu);  // 1 : tag15 : len16
+    const unsigned long long me = ((unsigned long long)hi << 32) | j;
+    uint32_t slot = h & a.tmask;
+    for (int probes = 0;; probes++) {
+        unsigned long long cur = a.table[slot].key;
+        if (cur == TOK_EMPTY || (uint32_t)(cur >> 32) == hi)  // free, or maybe this token: the state past the caches (the offset moves)
+            cur = __hip_atomic_load(&a.table[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cur == TOK_EMPTY) {
+            cur = atomicCAS(&a.table[slot].key, TOK_EMPTY, me);
+            if (cur == TOK_EMPTY) return slot;
+        }
+        if ((uint32_t)(cur >> 32) == hi && ((uint32_t)cur == j || same_bytes(a.text + (uint32_t)cur, p, len))) {
+            if ((uint32_t)cur > j) atomicMin(&a.table[slot].key, me);
+            return slot;
+        }
+        if (probes >= TOK_MAX_PROBE) {
+            atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
+            return 0;
+        }
+        slot = (slot + 1) & a.tmask;
+    }
+}
+
+// LDS of one wave of the hashing kernels: its 4 KiB of text (+ 16 bytes behind it: a token may start on the unit's last byte),
+// the bound bits of those bytes (+ 64 behind), the list of token starts (reused, from its front, as the list of the tokens whose
+// first look at the table did not settle them) and those tokens' indices
+struct alignas(16) TokUnitLds {
+    uint32_t text[TOK_WPW * TOK_WIN / 4 + 4];
+    uint32_t bound[TOK_WPW * TOK_WIN / 32 + 2];
+    uint16_t list[TOK_LIST_CAP];
+    uint16_t pend_t[TOK_LIST_CAP];
+};
+
+// the token that starts at byte `pos` of the staged unit: its inline key (length 1 .. 7 in the top byte, bytes below) and
+// whether it is that short at all
+__device__ __forceinline__ bool tok_key_at(const TokUnitLds &s, uint32_t pos, unsigned long long *key) {
+    const uint32_t aw = pos >> 2, sh = pos & 3u;
+    const uint32_t w0 = s.text[aw], w1 = s.text[aw + 1], w2 = s.text[aw + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    const uint32_t bi = pos + 1;
+    const uint32_t win = __builtin_amdgcn_alignbit(s.bound[(bi >> 5) + 1], s.bound[bi >> 5], bi & 31u);  // bound bits of bytes pos+1 ..
+    const uint32_t len = (uint32_t)__builtin_ctz(win | 0x40u) + 1u;  // 1 .. 7 (the key is only used when the token is that short)
+    const unsigned long long bytes = (((unsigned long long)hi << 32) | lo) & ((1ull << (8 * len)) - 1ull);
+    *key = ((unsigned long long)len << 56) | bytes;
+    return (win & 0x7Fu) != 0u;  // the token ends within 7 bytes
+}
+
+// Tokens [0, n_tok) of the list -> table; the slot of token t is stored at out[t].
+// Phase 1, U tokens per lane and round: all their LDS reads, then all their table slots — ONE 16-byte plain load each — in
+// flight together; a token whose slot shows its key is settled there (its first offset lowered when this occurrence is
+// earlier).  Everything else — a slot that looks free (the token is new, or this XCD's L2 / this CU's L1 holds the line as it
+// was before another XCD put the token in), a slot taken by another token, a token of 8 bytes or more — is DEFERRED: its list
+// position goes to the front of the list, which the rounds have already consumed.
+// Phase 2: the deferred tokens, 64 at a time, through the probe chain that reads past the caches.  (Settling them inside
+// the rounds made every round as long as its slowest lane's chain — plain load, load past the caches, compare-and-swap,
+// offset: 100 us at 100k rows against 30 for the rounds alone.)
+__device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s, uint32_t text0, uint32_t n_tok, uint32_t *out) {
+    constexpr int U = TOK_LOOKUP_U;
+    const int lane = threadIdx.x & 63;
+    uint32_t n_pend = 0;
+    for (uint32_t r0 = 0; r0 < n_tok; r0 += 64 * U) {
+        bool act[U], inl[U];
+        uint32_t pos[U], slot[U];
+        unsigned long long key[U];
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t t = r0 + u * 64 + lane;
+            act[u] = t < n_tok;
+            pos[u] = act[u] ? (uint32_t)s.list[t] : 0u;
+            inl[u] = tok_key_at(s, pos[u], &key[u]);
+            slot[u] = tok_hash_inline(key[u]) & a.tmask;
+            q[u] = *reinterpret_cast<const uint4 *>(&a.table[(act[u] && inl[u] && !(a.dbg & 2)) ? slot[u] : 0u]);
+            if (a.dbg & 2) {  // (timing experiment: every token "found" without a look at the table)
+                q[u].x = (uint32_t)key[u];
+                q[u].y = (uint32_t)(key[u] >> 32);
+                q[u].z = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t t = r0 + u * 64 + lane;
+            const bool found = act[u] && inl[u] && ((((unsigned long long)q[u].y << 32) | q[u].x) == key[u]);
+            if (found) {
+                const uint32_t j = text0 + pos[u];
+                if (j < q[u].z && !(a.dbg & 1)) atomicMin(&a.table[slot[u]].first, j);
+                out[t] = slot[u];
+            }
+            const bool pend = act[u] && !found && !(a.dbg & 16);
+            const unsigned long long bal = __ballot(pend);
+            if (pend) {
+                const uint32_t idx = n_pend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                s.list[idx] = (uint16_t)pos[u];  // (idx <= tokens consumed so far: nothing unread is overwritten)
+                s.pend_t[idx] = (uint16_t)t;
+            }
+            n_pend += (uint32_t)__popcll(bal);
+            if ((a.dbg & 16) && act[u] && !found) out[t] = slot[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if ((a.dbg & 32) && lane == 0) {  // (counting experiment: deferred tokens, waves)
+        atomicAdd((unsigned *)&a.tc->pad_[0], n_pend);
+        atomicAdd((unsigned *)&a.tc->pad_[1], 1u);
+    }
+    for (uint32_t p0 = 0; p0 < n_pend; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        if (p >= n_pend) continue;
+        const uint32_t pos = s.list[p], t = s.pend_t[p];
+        unsigned long long key;
+        const bool inl = tok_key_at(s, pos, &key);
+        const uint32_t j = text0 + pos;
+        uint32_t sl;
+        if (!inl) sl = tok_long(a, j);
+        else {
+            uint32_t slot = tok_hash_inline(key) & a.tmask;
+            // the slot's state past the caches, key and first offset requested together
+            unsigned long long cur = __hip_atomic_load(&a.table[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint32_t first = __hip_atomic_load(&a.table[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sl = 0;
+            for (int probes = 0;; probes++) {
+                if (cur == TOK_EMPTY) {
+                    cur = atomicCAS(&a.table[slot].key, TOK_EMPTY, key);
+                    if (cur == TOK_EMPTY) {
+                        cur = key;
+                        first = 0xFFFFFFFFu;
+                    } else if (cur == key)  // another wave put it there since the load: its offset may have landed by now
+                        first = __hip_atomic_load(&a.table[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (cur == key) {
+                    if (j < first) atomicMin(&a.table[slot].first, j);
+                    sl = slot;
+                    break;
+                }
+                if (probes >= TOK_MAX_PROBE) {  // table too full: the host enlarges it and runs again
+                    atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
+                    break;
+                }
+                slot = (slot + 1) & a.tmask;
+                cur = __hip_atomic_load(&a.table[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                first = __hip_atomic_load(&a.table[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        out[t] = sl;
+    }
+}
+
+// A wave owns a UNIT of TOK_WPW consecutive windows (4 KiB of text).  The unit's text and bound bits are staged in the wave's
+// LDS with coalesced loads (one round trip), the positions of its token starts go into a list in LDS (prefix sums of the
+// lanes' bit counts: the list is in text order, so token t of the list is token `first token of the unit + t` of the whole
+// input), and the lanes then take tokens from the list — every lane busy whatever the token lengths, the per-token stores
+// coalesced, nothing but the table itself read from global memory per token.  (Round 3 read every token's bytes and bound
+// bits with scattered global loads and compared them with the bytes of the entry's first occurrence, somewhere in the text:
+// three dependent round trips per token instead of one; 101 us at 100k rows.)
+// masks: start / bound masks of the unit's four windows per lane (from k_tok_scan's arrays, or computed by the caller).
+__device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, TokUnitLds &s, const uint4 (&v)[TOK_WPW],
+                                              const uint32_t (&st)[TOK_WPW], const uint32_t (&bd)[TOK_WPW], uint32_t g0) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t text0 = unit * TOK_WPW * TOK_WIN;
+#pragma unroll
+    for (int u = 0; u < TOK_WPW; u++) {
+        *reinterpret_cast<uint4 *>(&s.text[u * (TOK_WIN / 4) + 4 * lane]) = v[u];
+        reinterpret_cast<uint16_t *>(s.bound)[u * (TOK_WIN / 16) + lane] = (uint16_t)bd[u];
+    }
+    if (lane < 4) s.text[TOK_WPW * TOK_WIN / 4 + lane] = ldu32(a.text + text0 + TOK_WPW * TOK_WIN + 4 * lane);
+    if (lane < 2) s.bound[TOK_WPW * TOK_WIN / 32 + lane] = a.boundbits[(text0 + TOK_WPW * TOK_WIN) / 32 + lane];
+    int cnt[TOK_WPW], inc[TOK_WPW];
+    uint32_t total = 0;
+#pragma unroll
+    for (int u = 0; u < TOK_WPW; u++) {
+        cnt[u] = __popc(st[u]);
+        inc[u] = tok_wave_incl_scan(cnt[u]);
+        total += (uint32_t)__builtin_amdgcn_readlane(inc[u], 63);
+    }
+    // the list holds TOK_LIST_CAP starts: a unit with more (rows of a byte or two) is taken one window at a time
+    const int n_sub = total <= TOK_LIST_CAP ? 1 : TOK_WPW;
+    uint32_t done = 0;
+    for (int sub = 0; sub < n_sub; sub++) {
+        uint32_t n_tok = 0;
+#pragma unroll
+        for (int u = 0; u < TOK_WPW; u++) {
+            if (n_sub > 1 && u != sub) continue;
+            uint32_t o = n_tok + (uint32_t)(inc[u] - cnt[u]);
+            for (uint32_t b = st[u]; b; b &= b - 1) s.list[o++] = (uint16_t)(u * TOK_WIN + 16 * lane + __builtin_ctz(b));
+            n_tok += (uint32_t)__builtin_amdgcn_readlane(inc[u], 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!(a.dbg & 4)) tok_unit_lookup(a, s, text0, n_tok, a.tokslot + g0 + done);
+        else  // (timing experiment: a defined slot for every token all the same — k_tok_ids follows them)
+            for (uint32_t t = threadIdx.x & 63; t < n_tok; t += 64) a.tokslot[g0 + done + t] = 0u;
+        done += n_tok;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the next sub-unit overwrites the list)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tok_scan: a block = 64 KiB of text — masks stored, token starts counted per window and block.
 __global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a, uint32_t blk0) {
     __shared__ unsigned s_cnt[TOK_SCAN_WINS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t sepx4 = (uint32_t)a.sep * 0x01010101u;
     const uint32_t blk = blk0 + (uint32_t)blockIdx.x;
     const uint32_t win0 = blk * TOK_SCAN_WINS + wave * TOK_WPW;  // this wave's first window
-    const uint32_t sepx4 = (uint32_t)a.sep * 0x01010101u;
     uint4 v[TOK_WPW];
     uint32_t rb[TOK_WPW];
 #pragma unroll
@@ -113,18 +395,12 @@ __global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a, uint32_t blk0) {
 #pragma unroll
     for (int i = 0; i < TOK_WPW; i++) {
         const uint32_t w0 = (win0 + i) * TOK_WIN;
-        const uint32_t m = eq_bytes4(v[i].x, sepx4) | (eq_bytes4(v[i].y, sepx4) << 4) | (eq_bytes4(v[i].z, sepx4) << 8) |
-                           (eq_bytes4(v[i].w, sepx4) << 12);
-        uint32_t cin = ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, true) >> 15) & 1u;  // wave_shr:1
-        if (lane == 0) cin = prev_sep;
-        const uint32_t before_sep = ((m << 1) | cin) & 0xFFFFu;
-        const uint32_t start = ~m & (before_sep | rb[i]) & 0xFFFFu;
-        const uint32_t bound = (m | rb[i]) & 0xFFFFu;
+        uint32_t start, bound;
+        tok_masks(v[i], rb[i], sepx4, prev_sep, lane, &start, &bound, &prev_sep);
         reinterpret_cast<uint16_t *>(a.startbits)[(w0 >> 4) + lane] = (uint16_t)start;
         reinterpret_cast<uint16_t *>(a.boundbits)[(w0 >> 4) + lane] = (uint16_t)bound;
         const int inc = tok_wave_incl_scan(__popc(start));
         if (lane == 63) s_cnt[wave * TOK_WPW + i] = (unsigned)inc;
-        prev_sep = ((uint32_t)__builtin_amdgcn_readlane((int)m, 63) >> 15) & 1u;
     }
     __syncthreads();
     if (wave == 0) {  // tokens in front of every window INSIDE the block; the block's total goes to the scan of the blocks
@@ -182,192 +458,32 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mur_step(uint32_t h, uint32_t w) {
-    w *= 0xCC9E2D51u;
-    w = (w << 15) | (w >> 17);
-    w *= 0x1B873593u;
-    h ^= w;
-    h = (h << 13) | (h >> 19);
-    return h * 5u + 0xE6546B64u;
-}
-__device__ __forceinline__ uint32_t mur_final(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    return h ^ (h >> 16);
-}
-
-__device__ __forceinline__ bool same_bytes(const uint8_t *p, const uint8_t *q, uint32_t len) {
-    uint32_t k = 0;
-    for (; k + 8 <= len; k += 8)
-        if (ldu64(p + k) != ldu64(q + k)) return false;
-    const uint32_t rem = len - k;  // (the buffers are padded: the tail reads stay inside)
-    if (rem == 0) return true;
-    const unsigned long long mask = (1ull << (8 * rem)) - 1ull;
-    return ((ldu64(p + k) ^ ldu64(q + k)) & mask) == 0ull;
-}
-
-// tokens of at most 16 bytes (all of a mutation profile's): bytes in two registers, no loop
-__device__ __forceinline__ unsigned long long low_bytes(unsigned long long w, uint32_t n) {  // n in 0..8
-    return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1ull));
-}
-
-// the probe chain of one token from `slot` on (any token length): -> the token's slot
-__device__ __forceinline__ uint32_t tok_probe(const TokArgs &a, uint32_t slot, uint32_t hi, uint32_t j, uint32_t len) {
-    const uint8_t *p = a.text + j;
-    const unsigned long long me = ((unsigned long long)hi << 32) | j;
-    for (int probes = 0;; probes++) {
-        // system scope: past this XCD's L2 (a slot filled by another XCD must not keep looking empty here)
-        unsigned long long cur = __hip_atomic_load(&a.table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (cur == TOK_EMPTY) {
-            cur = atomicCAS(&a.table[slot], TOK_EMPTY, me);
-            if (cur == TOK_EMPTY) return slot;
-        }
-        if ((uint32_t)(cur >> 32) == hi && ((uint32_t)cur == j || same_bytes(a.text + (uint32_t)cur, p, len))) {
-            if ((uint32_t)cur > j) atomicMin(&a.table[slot], me);
-            return slot;
-        }
-        if (probes >= TOK_MAX_PROBE) {  // table too full: the host enlarges it and runs again
-            atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
-            return 0;
-        }
-        slot = (slot + 1) & a.tmask;
-    }
-}
-
-// k_tok_hash: a wave owns a UNIT of TOK_WPW consecutive windows (4 KiB of text).  The positions of the unit's token
-// starts go into a list in the wave's LDS (prefix sums of the lanes' bit counts: the list is in text order, so token t
-// of the list is token `first token of the unit + t` of the whole input), and the lanes then take tokens from the list,
-// four per lane and round — every lane busy whatever the token lengths, the per-token stores coalesced, and four
-// independent chains {bound bits + first 16 bytes -> table word -> bytes of the entry} in flight per lane.  (A lane
-// working through the tokens of its own 16 bytes, one window after the other: half the lanes idle and one dependent load
-// at a time.)  The first probe of a token is part of the pipelined round; the few it does not settle (a slot taken by
-// another token, tokens over 16 bytes) go through tok_probe one at a time.
-__device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, uint16_t *list /*LDS: TOK_WPW * TOK_WIN entries*/) {
-    constexpr int U = 4;
+// Units [unit0, n_units).  sample = 0: all of them, in order.  sample = S > 1, part 0: every S-th unit (unit0, unit0 + S, ...);
+// part 1: the others.  (The hash runs in THREE launches — the first units, a sample spread over the text, the rest: when all
+// 8 000 waves start at once, every token that many rows carry is met by thousands of waves while its slot is still free, and
+// each of them claims it by compare-and-swap: same-address atomics serialise at ~11 ns.  The waves of the earlier launches are
+// few, and what they insert the later ones find by a plain load.)
+__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units, uint32_t sample, uint32_t part) {
+    __shared__ TokUnitLds s_unit[4];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t idx = (uint32_t)blockIdx.x * 4 + wave;
+    uint32_t unit;
+    if (sample <= 1) unit = unit0 + idx;
+    else if (part == 0) unit = unit0 + idx * sample;
+    else unit = unit0 + (idx / (sample - 1)) * sample + idx % (sample - 1) + 1;
+    if (unit >= n_units) return;
     const uint32_t win0 = unit * TOK_WPW;
-    uint32_t st[TOK_WPW];
-#pragma unroll
-    for (int u = 0; u < TOK_WPW; u++) st[u] = reinterpret_cast<const uint16_t *>(a.startbits)[(win0 + u) * (TOK_WIN / 16) + lane];
-    const uint32_t g0 = a.blkbase[win0 / TOK_SCAN_WINS] + a.winbase[win0];  // (a unit lies in one scan block)
-    uint32_t total = 0;
+    uint4 v[TOK_WPW];
+    uint32_t st[TOK_WPW], bd[TOK_WPW];
 #pragma unroll
     for (int u = 0; u < TOK_WPW; u++) {
-        const int c = __popc(st[u]);
-        const int inc = tok_wave_incl_scan(c);
-        uint32_t o = total + (uint32_t)(inc - c);
-        for (uint32_t s = st[u]; s; s &= s - 1) list[o++] = (uint16_t)(u * TOK_WIN + 16 * lane + __builtin_ctz(s));
-        total += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+        v[u] = *reinterpret_cast<const uint4 *>(a.text + (win0 + u) * TOK_WIN + 16 * lane);
+        st[u] = reinterpret_cast<const uint16_t *>(a.startbits)[(win0 + u) * (TOK_WIN / 16) + lane];
+        bd[u] = reinterpret_cast<const uint16_t *>(a.boundbits)[(win0 + u) * (TOK_WIN / 16) + lane];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t text0 = win0 * TOK_WIN;
-    for (uint32_t r0 = 0; r0 < total; r0 += 64 * U) {
-        bool act[U];
-        uint32_t j[U], wi[U], bw0[U], bw1[U];
-        unsigned long long t0[U], t1[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // stage 1: four tokens of the list; bound bits + first 16 bytes requested
-            const uint32_t t = r0 + u * 64 + lane;
-            act[u] = t < total;
-            j[u] = text0 + (act[u] ? (uint32_t)list[t] : 0u);
-            wi[u] = (j[u] + 1) >> 5;
-            bw0[u] = a.boundbits[wi[u]];
-            bw1[u] = a.boundbits[wi[u] + 1];
-            t0[u] = ldu64(a.text + j[u]);
-            t1[u] = ldu64(a.text + j[u] + 8);
-        }
-        uint32_t len[U], hi[U], slot[U];
-        unsigned long long m0[U], m1[U], cur[U];
-        bool small[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // stage 2: token end -> length -> hash -> table word requested
-            // end of the token: the first bound bit (separator or row start) behind j; the padding is all separators
-            uint32_t bw = bw0[u] & (~0u << ((j[u] + 1) & 31u));
-            uint32_t w = wi[u];
-            if (!bw) {
-                bw = bw1[u];
-                w++;
-                const uint32_t w_max = (j[u] + TOK_MAX_LEN + 64u) >> 5;  // (beyond: the token is too long whatever follows)
-                while (!bw && w < w_max) bw = a.boundbits[++w];
-                if (!bw) bw = 1u;
-            }
-            len[u] = w * 32 + (uint32_t)__builtin_ctz(bw) - j[u];
-            small[u] = len[u] <= 16;
-            m0[u] = low_bytes(t0[u], len[u]);
-            m1[u] = low_bytes(t1[u], len[u] > 8 ? len[u] - 8 : 0u);
-            uint32_t h = 0x9747B28Cu ^ len[u];
-            if (small[u]) {  // the same words the loop below feeds
-                h = mur_step(h, (uint32_t)m0[u]);
-                if (len[u] > 4) h = mur_step(h, (uint32_t)(m0[u] >> 32));
-                if (len[u] > 8) h = mur_step(h, (uint32_t)m1[u]);
-                if (len[u] > 12) h = mur_step(h, (uint32_t)(m1[u] >> 32));
-            } else if (act[u] && len[u] <= TOK_MAX_LEN) {
-                const uint8_t *p = a.text + j[u];
-                uint32_t k = 0;
-                for (; k + 4 <= len[u]; k += 4) h = mur_step(h, ldu32(p + k));
-                if (len[u] & 3u) h = mur_step(h, ldu32(p + k) & ((1u << (8 * (len[u] & 3u))) - 1u));
-            }
-            h = mur_final(h);
-            hi[u] = (h & 0xFFFF0000u) | (len[u] & 0xFFFFu);  // tag : length
-            slot[u] = h & a.tmask;
-            // PLAIN load (this XCD's L2): entries only ever appear and only ever move to smaller offsets, so a stale word
-            // is an older state — an entry seen here exists (its bytes are compared below), a stale offset is larger than
-            // the true one and at worst costs an atomicMin that changes nothing; only what looks free or foreign is read
-            // again past the L2.  The tokens every row carries are settled in L2 hits that way.
-            cur[u] = a.table[act[u] ? slot[u] : 0u];
-            if (a.dbg & 2) cur[u] = ((unsigned long long)hi[u] << 32) | j[u];
-        }
-        unsigned long long q0[U], q1[U];
-        bool cmp[U], done[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // stage 3: free slot -> claim it; tag and length equal -> the entry's bytes requested
-            done[u] = !act[u];
-            if (!done[u] && !(a.dbg & 1) && (cur[u] == TOK_EMPTY || (uint32_t)(cur[u] >> 32) != hi[u]))
-                cur[u] = __hip_atomic_load(&a.table[slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (act[u] && len[u] > TOK_MAX_LEN) {
-                atomicOr(&a.tc->fail, TOK_FAIL_LONG);
-                slot[u] = 0;
-                done[u] = true;
-            }
-            if (!done[u] && cur[u] == TOK_EMPTY) {
-                cur[u] = atomicCAS(&a.table[slot[u]], TOK_EMPTY, ((unsigned long long)hi[u] << 32) | j[u]);
-                done[u] = cur[u] == TOK_EMPTY;
-            }
-            cmp[u] = !done[u] && small[u] && (uint32_t)(cur[u] >> 32) == hi[u] && !(a.dbg & 4);
-            if (a.dbg & 4) done[u] = true;
-            const uint8_t *q = a.text + (cmp[u] ? (uint32_t)cur[u] : j[u]);
-            q0[u] = ldu64(q);
-            q1[u] = ldu64(q + 8);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // stage 4: same bytes -> this is the token's slot; lower the entry to the first occurrence
-            if (cmp[u] && low_bytes(q0[u], len[u]) == m0[u] && (len[u] <= 8 || low_bytes(q1[u], len[u] - 8) == m1[u])) {
-                if ((uint32_t)cur[u] > j[u]) atomicMin(&a.table[slot[u]], ((unsigned long long)hi[u] << 32) | j[u]);
-                done[u] = true;
-            }
-            if (!done[u])  // long tokens start here, short ones whose first slot holds another token go on behind it
-                slot[u] = tok_probe(a, small[u] ? ((slot[u] + 1) & a.tmask) : slot[u], hi[u], j[u], len[u]);
-            if (act[u]) a.tokslot[g0 + r0 + u * 64 + lane] = slot[u];
-        }
-    }
-}
-
-// the unit of the first 4 KiB, alone: the tokens every row carries are in the table before the whole text asks for them
-__global__ __launch_bounds__(64) void k_tok_head(TokArgs a) {
-    __shared__ uint16_t s_list[TOK_WPW * TOK_WIN];  // a token per byte at worst (rows of one byte)
-    tok_hash_unit(a, 0u, s_list);
-}
-
-__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units) {
-    __shared__ uint16_t s_list[4][TOK_WPW * TOK_WIN];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t unit = unit0 + (uint32_t)blockIdx.x * 4 + wave;
-    if (unit >= n_units) return;
-    tok_hash_unit(a, unit, s_list[wave]);
+    const uint32_t g0 = a.blkbase[win0 / TOK_SCAN_WINS] + a.winbase[win0];  // (a unit lies in one scan block)
+    tok_hash_unit(a, unit, s_unit[wave], v, st, bd, g0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,8 +503,11 @@ __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
         a.indptr[r] = (int)cnt;
     }
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
-        const unsigned long long e = a.table[s];
-        if (e != TOK_EMPTY) atomicOr(&a.firstbits[(uint32_t)e >> 5], 1u << ((uint32_t)e & 31u));
+        const TokSlot e = a.table[s];
+        if (e.key != TOK_EMPTY) {
+            const uint32_t o = tok_entry_offset(e);
+            atomicOr(&a.firstbits[o >> 5], 1u << (o & 31u));
+        }
     }
 }
 
@@ -415,14 +534,14 @@ __global__ __launch_bounds__(512) void k_voc_count(TokArgs a) {
 __global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
-        const unsigned long long e = a.table[s];
-        if (e == TOK_EMPTY) continue;
-        const uint32_t o = (uint32_t)e;
+        const TokSlot e = a.table[s];
+        if (e.key == TOK_EMPTY) continue;
+        const uint32_t o = tok_entry_offset(e);
         const uint32_t w = o / TOK_WIN;
         uint32_t cnt = a.vocblk[w / TOK_SCAN_WINS] + a.vocwin[w];
         for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.firstbits[q]);
         cnt += (uint32_t)__popc(a.firstbits[o >> 5] & ((1u << (o & 31u)) - 1u));
-        a.tabid[s] = (int)cnt;
+        a.table[s].id = (int)cnt;
     }
 }
 
@@ -432,10 +551,10 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     if (g0 >= nnz) return;
     const uint4 s = *reinterpret_cast<const uint4 *>(a.tokslot + g0);
     uint4 o;
-    o.x = (uint32_t)a.tabid[s.x];
-    o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y] : 0u;
-    o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z] : 0u;
-    o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w] : 0u;
+    o.x = (uint32_t)a.table[s.x].id;
+    o.y = g0 + 1 < nnz ? (uint32_t)a.table[s.y].id : 0u;
+    o.z = g0 + 2 < nnz ? (uint32_t)a.table[s.z].id : 0u;
+    o.w = g0 + 3 < nnz ? (uint32_t)a.table[s.w].id : 0u;
     *reinterpret_cast<uint4 *>(a.indices + g0) = o;
 }
 
@@ -470,25 +589,33 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
             hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase + b0, b1 - b0, &a.tc->nnz);
             LAUNCH_CHECK();
         }
-        if (ev && k == 0) (void)hipEventRecord(ev[1], st);
+        if (ev && k == 0) {
+            (void)hipEventRecord(ev[1], st);
+            (void)hipEventRecord(ev[6], st);
+        }
         // A token that starts near the end of the piece may reach into the next one (up to TOK_MAX_LEN bytes), whose text and
         // bound bits are not there yet: the last TOK_HOLD_UNITS units of a piece wait for the next piece's scan.
-        unsigned u0 = hashed;
+        const unsigned u0 = hashed;
         const unsigned u_end = b1 * UNITS_PER_BLK;
         const unsigned u1 = k + 1 == n_pieces ? u_end : (u_end > hashed + TOK_HOLD_UNITS ? u_end - TOK_HOLD_UNITS : hashed);
-        if (k == 0) {
-            // the first 4 KiB alone (one wave), then the rest: the tokens every row carries are in the table before everyone
-            // asks for them at once.  (A text so short that its first piece is held back whole hashes unit 0 with the rest.)
-            if (u1 >= 1) {
-                hipLaunchKernelGGL(k_tok_head, dim3(1), dim3(64), 0, st, a);
-                LAUNCH_CHECK();
-                u0 = 1;
-            }
-            if (ev) (void)hipEventRecord(ev[6], st);
-        }
-        if (u1 > u0) {
-            hipLaunchKernelGGL(k_tok_hash, dim3((u1 - u0 + 3) / 4), dim3(256), 0, st, a, u0, u1);
+        unsigned uh = u0;
+        if (k == 0 && a.head_units > 0 && u1 > u0 + (unsigned)a.head_units) {  // the first units by themselves
+            uh = u0 + (unsigned)a.head_units;
+            hipLaunchKernelGGL(k_tok_hash, dim3((uh - u0 + 3) / 4), dim3(256), 0, st, a, u0, uh, 0u, 0u);
             LAUNCH_CHECK();
+        }
+        if (u1 > uh) {
+            const unsigned cnt = u1 - uh, S = (unsigned)a.sample;
+            if (S > 1 && cnt >= 4 * S) {  // a sample spread over the text, then the rest
+                const unsigned n0 = (cnt + S - 1) / S, n1 = cnt - n0;
+                hipLaunchKernelGGL(k_tok_hash, dim3((n0 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 0u);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_tok_hash, dim3((n1 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 1u);
+                LAUNCH_CHECK();
+            } else {
+                hipLaunchKernelGGL(k_tok_hash, dim3((cnt + 3) / 4), dim3(256), 0, st, a, uh, u1, 0u, 0u);
+                LAUNCH_CHECK();
+            }
         }
         hashed = std::max(hashed, u1);
     }

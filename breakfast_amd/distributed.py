@@ -65,6 +65,13 @@ class GpuEngine:
         self.n = int(n_rows)
         self._keep = None
 
+    def cluster_text(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str, max_dist: int, labels_out):
+        """tokeniser + clustering kernels as ONE enqueue (bfk_ctx_cluster_text_device): where the variant join serves the step
+        the clustering kernels follow the tokeniser with no wait in between; the bind is completed by sync()"""
+        self.n = int(n_rows)
+        self._keep = None
+        self.ctx.cluster_text_device(d_text, text_bytes, d_row_off, n_rows, sep, max_dist, labels_out.data_ptr())
+
     def run(self):
         """context manager: what is enqueued inside goes to the engine's stream"""
         return torch.cuda.stream(self.stream)
@@ -113,14 +120,21 @@ class ShardedClusterer:
         (see _step) every time."""
         run = getattr(self.e, "run", None)
         with run():
-            self.e.bind_text(d_text, text_bytes, d_row_off, n_rows, sep)
-            if getattr(self, "labels", None) is None or self.labels.shape[1] != max(self.e.n, 1):
+            if getattr(self, "labels", None) is None or self.labels.shape[1] != max(int(n_rows), 1):
+                self.e.n = int(n_rows)
                 self.local = self.e.new_labels(1)
                 self.labels = self.e.new_labels(1)
                 self.gathered = self.e.new_labels(self.world) if (self.world > 1 or self.force_exchange) else None
                 self.flag = self.e.new_flag()
-            self._settled = set()
-            out = self._step(max_dist)
+            if self.world == 1 and not self.force_exchange:
+                # one rank: tokeniser and clustering kernels in one enqueue, nothing waits in between where the library can
+                # drive the clustering kernels from device-resident counts
+                self.e.cluster_text(d_text, text_bytes, d_row_off, n_rows, sep, max_dist, self.labels)
+                out = self.labels[0]
+            else:
+                self.e.bind_text(d_text, text_bytes, d_row_off, n_rows, sep)
+                self._settled = set()
+                out = self._step(max_dist)
         torch.cuda.current_stream(self.e.device).wait_stream(self.e.stream)
         return out
 

@@ -170,13 +170,21 @@ int bfk_ctx_build_csr(bfk_ctx *ctx, const char *buf, const int64_t *row_off, int
 /* ---- the same stages on text that is RESIDENT IN HBM (no PCIe inside the call) ------------------------------------------
  * d_text: device buffer of at least bfk_text_device_bytes(text_bytes) bytes whose first text_bytes hold the rows' bytes (rows
  * abut, as in bfk_build_csr); the library writes separator padding behind them.  d_row_off: device int64[n_rows + 1],
- * row_off[0] == 0, row_off[n_rows] == text_bytes, non-decreasing (checked by the kernels: BFK_EARG).  Both are borrowed
- * until the context is bound to another CSR.
- *   bfk_ctx_build_csr_device     sparse_feature_matrix (:193-215) -> CSR resident and bound
+ * row_off[0] == 0, row_off[n_rows] == text_bytes, non-decreasing (checked by the kernels: BFK_EARG).
+ *   bfk_ctx_build_csr_device     sparse_feature_matrix (:193-215) -> CSR resident and bound; waits once for the device (the
+ *                                token count and the longest row size what follows)
  *   bfk_ctx_cluster_text_device  + the body of cluster_features (:287-326) -> canonical labels in d_labels_out (device
- *                                int32[n_rows]); returns with the clustering kernels enqueued (bfk_ctx_sync waits for them).
- * One wait for the device happens inside (the token count and the longest row size the clustering kernels' grids).
- * This is the step bench.py times: profile strings in HBM -> labels in HBM.                                              */
+ *                                int32[n_rows]).  This is the step bench.py times: profile strings in HBM -> labels in HBM.
+ *                                ASYNCHRONOUS: it returns with tokeniser and clustering kernels enqueued.  At max_dist 1 up to
+ *                                800k rows (the variant join) NOTHING waits in between — the clustering kernels read the token
+ *                                count and the longest row from device memory — and up to four such steps may be open at once:
+ *                                a caller that streams batches enqueues the next while the last one runs.  Every other entry
+ *                                point — bfk_ctx_sync first of all — completes the open steps in order: a step whose input was
+ *                                outside what the launch assumed (a row of more than 128 tokens, no token at all, a vocabulary
+ *                                table that has to grow) is redone then, with every step enqueued behind it; an error of a
+ *                                step (malformed offsets ...) is reported there and drops the steps behind it.  d_text,
+ *                                d_row_off and d_labels_out therefore stay the library's until that bfk_ctx_sync returns.
+ *                                Elsewhere (other max_dist, larger inputs) the call waits once between the halves.          */
 int64_t bfk_text_device_bytes(int64_t text_bytes);
 int bfk_ctx_build_csr_device(bfk_ctx *ctx, void *d_text, int64_t text_bytes, const void *d_row_off, int64_t n_rows,
                              const char *sep, int64_t sep_len, int64_t *nnz_out, int32_t *n_vocab_out);

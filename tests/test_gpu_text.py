@@ -229,6 +229,128 @@ def test_text_resident_in_hbm_checks_the_offsets_on_the_device():
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["long_row", "all_empty", "table_grows", "bad_offsets", "shuffled_multisets"])
+def test_device_driven_text_step_redoes_what_its_assumptions_do_not_cover(case, monkeypatch):
+    """bfk_ctx_cluster_text_device at max-dist 1 enqueues the clustering kernels behind the tokeniser on device-resident
+    counts, assuming no row over 128 tokens, at least one token and a vocabulary table that is big enough; bfk_ctx_sync
+    completes the bind and redoes the step where that did not hold — labels always the oracle's, errors reported by the sync.
+    With BFK_SPEC=0 (the host sizes the clustering kernels after a wait) the result is the same."""
+    import torch
+
+    rng = np.random.default_rng(7)
+    if case == "long_row":
+        base = [f"A{i}T" for i in range(300)]
+        rows = [" ".join(base[:200]), " ".join(base[:199]), " ".join(base[1:200]), "A1T A2T", "A1T", " ".join(base[:150])]
+    elif case == "all_empty":
+        rows = ["", "", " ", ""]
+    elif case == "table_grows":
+        rows = [" ".join(f"T{i}" for i in range(r * 50000, (r + 1) * 50000)) for r in range(4)] + ["T1 T2", "T1"]
+    elif case == "shuffled_multisets":
+        toks = [f"C{i}G" for i in range(40)]
+        rows = []
+        for _ in range(300):
+            k = int(rng.integers(1, 9))
+            r = [toks[int(x)] for x in rng.integers(0, 40, size=k)]
+            rows.append(" ".join(r))
+            r2 = list(r)
+            rng.shuffle(r2)
+            rows.append(" ".join(r2[: max(1, k - 1)]))
+    else:
+        rows = ["A1C G5T", "", "G5T", "Q9R A1C"]
+    buf, off, d_text, d_off = _device_text(rows)
+    if case == "bad_offsets":
+        o = off.copy()
+        o[2] = o[1] - 1
+        d_off = torch.from_numpy(o).cuda()
+    results = []
+    for spec in ("1", "0"):
+        monkeypatch.setenv("BFK_SPEC", spec)
+        ctx = _lib.Context(0)
+        d_lab = torch.full((max(len(rows), 1),), -7, dtype=torch.int32, device="cuda")
+        for rep in range(2):
+            if case == "bad_offsets":
+                with pytest.raises(_lib.BfkError) as ei:
+                    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+                    ctx.sync()
+                assert ei.value.code == -1
+                continue
+            ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+            st = ctx.sync()
+            results.append((d_lab.cpu().numpy()[: len(rows)].copy(), st["n_edges"]))
+        if case != "bad_offsets":
+            ip, ix = ctx.download_csr()
+            want = orc.sparse_feature_matrix(rows, " ")
+            assert np.array_equal(ip, want[0]) and np.array_equal(ix, want[1])
+        ctx.close()
+    if case == "bad_offsets":
+        return
+    want = orc.sparse_feature_matrix(rows, " ")
+    if len(want[1]):
+        lab = orc.cluster_csr(want[0], want[1], 1, n_threads=8)["labels"]
+    else:  # (the reference's csr_matrix cannot even be built from an all-empty input: every row is the same empty multiset)
+        lab = np.zeros(len(rows), dtype=np.int32)
+    for got, _ in results:
+        assert np.array_equal(got, lab), case
+    assert len({e for _, e in results}) == 1
+
+
+def test_device_driven_step_then_other_entries_without_a_sync():
+    """an entry that follows bfk_ctx_cluster_text_device without a bfk_ctx_sync in between completes the open bind first"""
+    import torch
+
+    rows = list(dict.fromkeys(generate_profiles(5000)))
+    buf, off, d_text, d_off = _device_text(rows)
+    want = orc.sparse_feature_matrix(rows, " ")
+    ctx = _lib.Context(0)
+    d_lab = torch.empty(len(rows), dtype=torch.int32, device="cuda")
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+    ip, ix = ctx.download_csr(len(rows), len(want[1]))   # no sync before: the entry itself completes the open bind
+    assert np.array_equal(ip, want[0]) and np.array_equal(ix, want[1])
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+    ctx.cluster(2, d_lab.data_ptr())                 # another step on the CSR the open bind leaves
+    ctx.sync()
+    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 2, n_threads=8)["labels"])
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())  # back to back
+    assert ctx.text_stats()["nnz"] == len(want[1])
+    ctx.sync()
+    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 1, n_threads=8)["labels"])
+    ctx.close()                                       # and a context destroyed with a bind still open
+    ctx = _lib.Context(0)
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+    ctx.close()
+
+
+def test_open_text_steps_complete_in_order_and_a_step_outside_the_assumptions_redoes_the_ones_behind_it():
+    """up to four device-driven text steps may be open at once (a caller that streams batches); a step whose input breaks the
+    launch's assumptions is redone at the sync — and so is every step behind it, in order: each batch's labels are its own"""
+    import torch
+
+    ok_a = list(dict.fromkeys(generate_profiles(3000)))
+    ok_b = list(dict.fromkeys(generate_profiles(2000, seed=5)))
+    base = [f"A{i}T" for i in range(260)]
+    long_rows = [" ".join(base[:200]), " ".join(base[:199]), "A1T A2T", "A1T"] + ok_b[:50]      # a row of 200 tokens
+    batches = [ok_a, ok_b, long_rows, ok_b, ok_a, ok_b, long_rows, ok_a]                          # more than the ring holds
+    dev = [_device_text(r) for r in batches]
+    labs = [torch.full((len(r),), -3, dtype=torch.int32, device="cuda") for r in batches]
+    ctx = _lib.Context(0)
+    for (buf, off, d_text, d_off), rows, lab in zip(dev, batches, labs):
+        ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, lab.data_ptr())
+    ctx.sync()
+    for rows, lab in zip(batches, labs):
+        ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
+        assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+    # the same buffer for every step (what bench.py does): the last step's labels are in it
+    lab = torch.empty(len(ok_a), dtype=torch.int32, device="cuda")
+    buf, off, d_text, d_off = dev[0]
+    for _ in range(11):
+        ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(ok_a), " ", 1, lab.data_ptr())
+    st = ctx.sync()
+    ip, ix, _ = orc.sparse_feature_matrix(ok_a, " ")
+    assert st["n_retry_slices"] == 0 and np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+    ctx.close()
+
+
 def test_pinned_host_buffer_for_the_text():
     """bfk_host_alloc / bfk_host_free: a caller builds its text in page-locked memory and hands that to bfk_cluster_text"""
     rows = list(dict.fromkeys(generate_profiles(20000)))

@@ -3,7 +3,7 @@
 # usage (through gpurun): tools/tok_ab.sh [rows]
 cd "$(dirname "$0")/.."
 rows=${1:-100000}
-for dbg in 0 1 2 4 6; do
+for dbg in ${DBGS:-0 1 2 4 8}; do
   echo "== BFK_TOK_DEBUG=$dbg"
   BFK_TOK_DEBUG=$dbg python - "$rows" <<'PY'
 import sys, time
