@@ -41,7 +41,8 @@ class TextStats(C.Structure):
     _fields_ = [("text_bytes", C.c_int64), ("n_rows", C.c_int64), ("nnz", C.c_int64), ("table_slots", C.c_int64),
                 ("n_vocab", C.c_int32), ("table_growths", C.c_int32), ("host_fallback", C.c_int32), ("reserved_", C.c_int32),
                 ("ms_h2d", C.c_float), ("ms_scan", C.c_float), ("ms_hash", C.c_float), ("ms_ids", C.c_float),
-                ("ms_total", C.c_float), ("ms_head", C.c_float), ("reserved2_", C.c_float)]
+                ("ms_total", C.c_float), ("ms_head", C.c_float), ("reserved2_", C.c_float), ("n_invalid", C.c_int64),
+                ("n_empty", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -116,6 +117,11 @@ EXPORTS = {
     "bfk_table_feature": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_id": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_write": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i64p]),
+    "bfk_table_prepare_device": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.POINTER(PrepInfo)]),
+    "bfk_table_cluster_write_device": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
+                                                 C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
+    "bfk_table_pipeline_device": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
+                                            C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
     "bfk_table_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_cluster_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, c_i64p]),
@@ -422,6 +428,36 @@ class Table:
         _check(rc)
         self.info = info
         return info
+
+    def prepare_device(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length):
+        """bfk_table_prepare_device: the same contract computed on the GPU (filter in the tokeniser, collapse by row hash)"""
+        opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
+                          int(reference_length))
+        info = PrepInfo()
+        sepb = sep2.encode()
+        rc = self.lib.bfk_table_prepare_device(self.h, sepb, len(sepb), C.byref(opts), C.byref(info))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        if rc == -1 and len(sepb) == 0:
+            raise ValueError("empty separator")
+        _check(rc)
+        self.info = info
+        return info
+
+    def cluster_write_device(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length, max_dist: int,
+                             min_cluster_size: int, path):
+        """bfk_table_cluster_write_device -> (PrepInfo, clusters written)"""
+        opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
+                          int(reference_length))
+        info, n = PrepInfo(), C.c_int64()
+        sepb = sep2.encode()
+        rc = self.lib.bfk_table_cluster_write_device(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
+                                                     str(path).encode(), C.byref(info), C.byref(n))
+        if rc == EUNSUPPORTED:
+            raise Unsupported(self.lib.bfk_last_error().decode(errors="replace"))
+        _check(rc)
+        self.info = info
+        return info, int(n.value)
 
     def _view(self, fn, n):
         p = fn(self.h)

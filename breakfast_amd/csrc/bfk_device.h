@@ -144,8 +144,20 @@ enum : int { TOK_FAIL_ROWOFF = 1, TOK_FAIL_LONG = 2, TOK_FAIL_TABLE = 4 };
 struct TokCounters {
     unsigned int nnz, n_vocab;
     int fail;  // TOK_FAIL_*
-    int pad_[5];
+    unsigned int n_invalid;    // filter mode: non-empty token occurrences that match no pattern of the feature type
+    unsigned int nnz_kept;     // filter mode: tokens that survive the filter (the CSR's entries)
+    unsigned int n_empty;      // filter mode: empty tokens inside the rows' spans (k_tok_empties)
+    int pad_[2];               // (debug counters)
 };
+
+// filter_features (breakfast.py:116-190) on the device: every token occurrence is judged where it is hashed
+struct TokFilter {
+    int on;          // 0: every token is kept (sparse_feature_matrix alone)
+    int var_type;    // BFK_VAR_* of include/bfk.h (0 covsonar_dna, 1 covsonar_aa, 2 nextclade_dna, 3 nextclade_aa, 4 raw)
+    int skip_ins, skip_del;
+    long long trim_start, upper;  // a DNA substitution is dropped when pos <= trim_start or pos >= upper (= reference_length - trim_end)
+};
+constexpr uint32_t TOK_NONE = 0xFFFFFFFFu;  // slot of a token that the filter dropped
 
 struct TokArgs {
     const uint8_t *text;       // T bytes + separator padding up to T_pad + TOK_TEXT_SLACK
@@ -157,6 +169,11 @@ struct TokArgs {
     int strict;                // 1: also check row_off[0] == base and row_off[n_rows] == base + T (offsets from a caller's device memory)
     uint32_t *rowbits, *startbits, *boundbits;  // one bit per byte position: row start / token start / separator or row start
     uint32_t *firstbits;       // ... / a token's first occurrence starts here
+    uint32_t *keptbits;        // filter mode: ... / a token that survives the filter starts here (the CSR counts these instead of startbits)
+    uint32_t *keptwin, *keptblk; // filter mode: kept tokens in front of every window inside its scan block / in front of every scan block
+    const int *span_len;       // filter mode with rows that do not abut (bfk_table): length of row r's span (what lies behind it up to the
+                               // next row's start has been blanked with separator bytes); NULL: a row ends where the next one starts
+    TokFilter flt;
     uint32_t *winbase, *vocwin; // [T_pad / TOK_WIN]: tokens / vocabulary entries in front of every window inside its scan block
     uint32_t *blkbase, *vocblk; // [T_pad / TOK_PAD_BYTES + 1]: ... in front of every scan block (k_scan_single)
     TokSlot *table;            // tmask + 1 slots of 16 bytes
@@ -173,6 +190,39 @@ struct TokArgs {
 };
 int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_pieces, const unsigned *piece_blk,
                     hipEvent_t *piece_ev);  // bfk_text.hip
+
+// ---- collapse of duplicate rows (bfk_prep.hip) ----------------------------------------------------------------------
+constexpr unsigned long long PREP_EMPTY = ~0ull;
+constexpr int PREP_MAX_PROBE = 4096;
+enum : int { PREP_FAIL_TABLE = 1, PREP_FAIL_COLLISION = 2 };
+struct alignas(16) PrepSlot {
+    unsigned long long key;  // row hash
+    uint32_t row;            // smallest row with it (0xFFFFFFFF: none yet)
+    uint32_t pad_;
+};
+struct PrepArgs {
+    int n;                       // input rows
+    int by_bytes;                // identity of a row: 1 its raw bytes (nothing is filtered), 0 its sequence of CSR entries
+    const uint8_t *text;         // by_bytes: the rows' bytes ...
+    const long long *row_off;    // ... row r starts at row_off[r] - base
+    long long base;
+    const int *span_len;         // ... and is span_len[r] long (NULL: up to the next row's start)
+    const int *indptr;           // CSR of ALL input rows (the tokeniser's)
+    const uint32_t *indices;
+    unsigned long long *rowhash; // [n]
+    PrepSlot *table;             // mask + 1 slots
+    uint32_t mask;
+    int *rep;                    // [n] representative (smallest row with the same identity)
+    int2 *val, *blk;             // [n] / [n / 1024 + 1]: {is representative, its entries} -> exclusive prefix sums
+    int *totals;                 // [2]: unique rows, their CSR entries
+    int *group;                  // [n]  out: unique index of every input row
+    int *first_row;              // [n]  out: input row of every unique row
+    int *u_indptr;               // [n + 1] out: CSR of the unique rows
+    uint32_t *u_indices;
+    int *fail;                   // PREP_FAIL_*
+};
+int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, uint32_t T, uint8_t sep, hipStream_t st);
+int launch_collapse(const PrepArgs &a, hipStream_t st);
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip

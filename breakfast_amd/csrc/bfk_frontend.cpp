@@ -418,6 +418,8 @@ struct bfk_table {
     std::vector<Span> invalid;  // into `bytes`
     std::string sep2;
     bool filtered = false, prepared = false;
+    bool device_prepared = false;  // prepare() ran on the device (bfk_table_set_prepared): group / weight / first_row (/ CSR) are here, the
+                                   // vocabulary's bytes are not — the feature-string accessors need the host prepare
     bool any_high = false;  // the bytes hold non-ASCII (valid UTF-8) somewhere: prepare() looks at the feature column when it filters
     int32_t n_vocab = 0;
     std::vector<Span> vocab;  // token bytes of every vocabulary id (for bfk_table_feature)
@@ -848,6 +850,7 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
         if (high.load()) return unsupported("non-ASCII bytes in a feature that is matched against the token patterns");
     }
     t->filtered = filtering;
+    t->device_prepared = false;
     t->sep2.assign(sep2, (size_t)sep2_len);
     t->group.assign((size_t)n, 0);
     t->weight.clear();
@@ -949,6 +952,49 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
     return BFK_OK;
 }
 
+// ---- the table's raw material for a prepare that runs elsewhere (libbfk.so: the device stages), and the way back ----------
+extern "C" int bfk_table_raw(const bfk_table *t, const char **bytes_out, int64_t *n_bytes_out, const void **feat_spans_out,
+                             int64_t *span_stride_out, int64_t *n_rows_out) {
+    if (!t || !bytes_out || !n_bytes_out || !feat_spans_out || !span_stride_out || !n_rows_out) return bfk_fail(BFK_EARG, "bfk_table_raw: null argument");
+    *bytes_out = t->bytes.data();
+    *n_bytes_out = (int64_t)t->bytes.size();  // (includes the sentinel byte behind the last line)
+    *feat_spans_out = t->feats.data();
+    *span_stride_out = (int64_t)sizeof(Span);
+    *n_rows_out = (int64_t)t->feats.size();
+    return BFK_OK;
+}
+
+extern "C" int bfk_table_any_high(const bfk_table *t) { return t && t->any_high ? 1 : 0; }
+
+extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
+                                      const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len) {
+    if (!t || !group || !first_row || !info || n_unique < 0 || !sep2) return bfk_fail(BFK_EARG, "bfk_table_set_prepared: bad argument");
+    const int64_t n = (int64_t)t->ids.size();
+    t->group.assign(group, group + n);
+    t->first_row.assign(first_row, first_row + n_unique);
+    t->weight.assign((size_t)n_unique, 0);
+    for (int64_t r = 0; r < n; r++) {
+        if (group[r] < 0 || group[r] >= n_unique) return bfk_fail(BFK_EARG, "bfk_table_set_prepared: group index out of range");
+        t->weight[(size_t)group[r]]++;
+    }
+    t->indptr.clear();
+    t->indices.clear();
+    if (indptr) {
+        t->indptr.assign(indptr, indptr + n_unique + 1);
+        t->indices.reserve((size_t)std::max<int64_t>(info->nnz, 1));
+        t->indices.resize((size_t)info->nnz);
+        if (info->nnz) memcpy(t->indices.data(), indices, (size_t)info->nnz * sizeof(int32_t));
+    }
+    t->invalid.clear();
+    t->vocab.clear();  // (the vocabulary's bytes stay on the device: bfk_table_feature needs the host prepare)
+    t->sep2.assign(sep2, (size_t)sep2_len);
+    t->filtered = info->filtered != 0;
+    t->n_vocab = info->n_vocab;
+    t->prepared = true;
+    t->device_prepared = true;
+    return BFK_OK;
+}
+
 extern "C" const int32_t *bfk_table_group(const bfk_table *t) { return t && t->prepared ? t->group.data() : nullptr; }
 extern "C" const int32_t *bfk_table_weight(const bfk_table *t) { return t && t->prepared ? t->weight.data() : nullptr; }
 extern "C" const int32_t *bfk_table_indptr(const bfk_table *t) { return t && t->prepared ? t->indptr.data() : nullptr; }
@@ -969,6 +1015,7 @@ extern "C" int bfk_table_id(const bfk_table *t, int64_t r, const char **id_out, 
 }
 
 extern "C" int bfk_table_feature(const bfk_table *t, int64_t u, char **str_out, int64_t *len_out) {
+    if (t && t->device_prepared && t->filtered) return bfk_fail(BFK_ESTATE, "the filtered feature strings need bfk_table_prepare (the device prepare keeps the vocabulary in HBM)");
     if (!t || !t->prepared || !str_out || !len_out || u < 0 || u >= (int64_t)t->first_row.size()) return bfk_fail(BFK_EARG, "bfk_table_feature: bad argument");
     std::string s;
     if (!t->filtered) {
@@ -1070,6 +1117,7 @@ extern "C" int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int
 // bulk accessors for callers that need the strings themselves (the cache path keeps the reference's pickle format, which
 // stores the unique rows' feature strings and id tuples): one buffer + offsets instead of a call per row
 extern "C" int bfk_table_features(const bfk_table *t, char **buf_out, int64_t **off_out) {
+    if (t && t->device_prepared && t->filtered) return bfk_fail(BFK_ESTATE, "the filtered feature strings need bfk_table_prepare (the device prepare keeps the vocabulary in HBM)");
     if (!t || !t->prepared || !buf_out || !off_out) return bfk_fail(BFK_EARG, "bfk_table_features: bad argument");
     const size_t nu = t->first_row.size();
     int64_t *off = (int64_t *)malloc(sizeof(int64_t) * (nu + 1));
@@ -1187,6 +1235,7 @@ extern "C" int bfk_match_hashes(const uint64_t *a, int64_t n_a, const uint64_t *
 // the same for the filtered feature strings of a prepared table's unique rows (what bfk_table_features would hand out),
 // without building the strings' blob: out[2 u], out[2 u + 1]
 extern "C" int bfk_table_feature_hashes(const bfk_table *t, uint64_t *out) {
+    if (t && t->device_prepared && t->filtered) return bfk_fail(BFK_ESTATE, "the filtered feature strings need bfk_table_prepare (the device prepare keeps the vocabulary in HBM)");
     if (!t || !t->prepared || !out) return bfk_fail(BFK_EARG, "bfk_table_feature_hashes: bad argument");
     const size_t nu = t->first_row.size();
     const char *base = t->bytes.data();

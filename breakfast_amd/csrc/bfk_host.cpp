@@ -123,6 +123,16 @@ struct bfk_ctx {
     char *tk_zero = nullptr;  // [TokCounters | rowbits | firstbits]: zeroed by ONE memset per build
     uint32_t *tk_bits = nullptr, *tk_winbase = nullptr;
     TokSlot *tk_table = nullptr;
+    // device prepare of a table (filter + collapse, bfk_prep.hip): span lengths, row hashes, the hash table, representatives,
+    // prefix sums, group index / first row of the unique rows, their CSR, {totals, failure flags}
+    int *pr_spanlen = nullptr, *pr_rep = nullptr, *pr_group = nullptr, *pr_first = nullptr, *pr_uindptr = nullptr, *pr_small = nullptr;
+    unsigned long long *pr_rowhash = nullptr;
+    PrepSlot *pr_table = nullptr;
+    int2 *pr_val = nullptr, *pr_blk = nullptr;
+    uint32_t *pr_uindices = nullptr;
+    int64_t pr_rows_cap = 0, pr_table_cap = 0, pr_uidx_cap = 0, pr_blk_cap = 0;
+    uint32_t *tk_slots = nullptr;  // filter mode: the slots of ALL tokens in text order (the CSR holds the kept ones)
+    int64_t tk_slots_cap = 0;
     int64_t tk_text_cap = 0, tk_rowoff_cap = 0, tk_zero_cap = 0, tk_bits_cap = 0, tk_winbase_cap = 0, tk_table_cap = 0;
     int tk_grow = 0;  // how often the table was enlarged 8x for this context's inputs (kept: the next input is likely alike)
     hipEvent_t tk_ev[7] = {};
@@ -149,6 +159,8 @@ struct bfk_ctx {
         bool strict = false;
         int n_pieces = 1;
         unsigned piece_blk[9] = {0};
+        TokFilter flt{};                // filter_features on the device (flt.on), judged token by token where it is hashed
+        const int *d_span_len = nullptr;  // rows that do not abut (a table's feature column): the rows' lengths
     };
     struct SpecStep {
         TokPlan tp;
@@ -233,7 +245,8 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
-                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table};
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_slots, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
+                    c->pr_uindptr, c->pr_small, c->pr_rowhash, c->pr_table, c->pr_val, c->pr_blk, c->pr_uindices};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -480,9 +493,11 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     const int64_t bit_words = T_pad / 32 + 16;
     const int64_t z_rowbits = 0, z_firstbits = z_rowbits + bit_words * 4, z_bytes = z_firstbits + bit_words * 4;
     if (int rc = dev_realloc(&c->tk_zero, &c->tk_zero_cap, z_bytes, 1.05)) return rc;
-    if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 2 * bit_words, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 3 * bit_words, 1.05)) return rc;  // start | bound | kept
     const int64_t n_blk = round_up(T_pad / TOK_PAD_BYTES + 1, 4) + 4;  // (+ the total behind the last block; 16-byte pieces)
-    if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, 2 * (n_win + n_blk), 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, 3 * (n_win + n_blk), 1.05)) return rc;
+    if (tp.flt.on)
+        if (int rc = dev_realloc(&c->tk_slots, &c->tk_slots_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
     hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
@@ -518,9 +533,14 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     a.vocwin = c->tk_winbase + n_win;
     a.blkbase = c->tk_winbase + 2 * n_win;
     a.vocblk = c->tk_winbase + 2 * n_win + n_blk;
+    a.keptbits = c->tk_bits + 2 * bit_words;
+    a.keptwin = c->tk_winbase + 2 * n_win + 2 * n_blk;
+    a.keptblk = c->tk_winbase + 3 * n_win + 2 * n_blk;
+    a.flt = tp.flt;
+    a.span_len = tp.d_span_len;
     a.table = c->tk_table;
     a.tmask = (uint32_t)(slots - 1);
-    a.tokslot = c->own_indices;
+    a.tokslot = tp.flt.on ? c->tk_slots : c->own_indices;  // (in place without the filter: the slot array IS the indices array)
     a.indices = c->own_indices;
     a.indptr = c->own_indptr;
     a.nnz_cap = nnz_cap;
@@ -585,9 +605,11 @@ static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, i
     c->pg_off = false;
     c->tok_pending = false;
     if (int rc = ctx_size_workspace(c, 0)) return rc;
-    if ((int64_t)tc.nnz != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
+    if ((int64_t)(tp.flt.on ? tc.nnz_kept : tc.nnz) != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
+    c->tk_stats.n_invalid = tc.n_invalid;
+    c->tk_stats.n_empty = tc.n_empty;
     c->max_tok = (int)tc.n_vocab - 1;  // ids are 0 .. n_vocab - 1: the prefix-group path needs no k_maxtok pass
-    c->tk_stats.nnz = tc.nnz;
+    c->tk_stats.nnz = c->nnz;
     c->tk_stats.n_vocab = (int32_t)tc.n_vocab;
     if (hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr) {  // (profiled steps are completed one at a time: the events are this step's)
         float ms = 0;
@@ -1748,6 +1770,226 @@ extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t
     if (!rc) rc = bfk_ctx_sync(c, stats_out);
     if (!rc) rc = bfk_ctx_download(c, c->own_labels, labels_out, n_rows * 4);
     return rc;
+}
+
+// ================================================================================================
+// the CLI's stages between reader and writer on the device: filter_features + collapse_duplicates + sparse_feature_matrix of a
+// bfk_table (breakfast.py:116-190, :72-79, :193-215) — the table's bytes cross PCIe once, everything else happens in HBM
+// ================================================================================================
+extern "C" int bfk_table_raw(const bfk_table *t, const char **bytes_out, int64_t *n_bytes_out, const void **feat_spans_out,
+                             int64_t *span_stride_out, int64_t *n_rows_out);  // libbfk_front.so
+extern "C" int bfk_table_any_high(const bfk_table *t);
+extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
+                                      const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len);
+
+struct PrepResult {
+    int64_t n_rows = 0, n_unique = 0, nnz = 0, n_invalid = 0;
+    int32_t n_vocab = 0;
+    bool filtering = false;
+};
+
+// -> BFK_EUNSUPPORTED (nothing printed, nothing written: the host stages take the input) for what the device stages do not
+// restate: multi-byte token separators, 4 GiB of text, non-empty tokens that match no pattern (the reference prints each of
+// them, in order), a feature with non-ASCII bytes under a grammar, two different rows with one 64-bit hash
+static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, PrepResult *res) {
+    if (!t || !sep2 || !opts || !res) return fail(BFK_EARG, "device prepare: null argument");
+    if (sep2_len <= 0) return fail(BFK_EARG, "empty separator");
+    if (opts->var_type < BFK_VAR_COVSONAR_DNA || opts->var_type > BFK_VAR_RAW) return fail(BFK_EARG, "device prepare: unknown var_type");
+    if (sep2_len != 1) return fail(BFK_EUNSUPPORTED, "device prepare: one-byte token separators only");
+    const unsigned char sp = (unsigned char)sep2[0];
+    if (sp >= 0x80 || sp == '\n' || sp == '\r' || sp == 0) return fail(BFK_EUNSUPPORTED, "device prepare: token separator");
+    const char *bytes = nullptr;
+    const void *spans = nullptr;
+    int64_t n_bytes = 0, stride = 0, n = 0;
+    if (int rc = bfk_table_raw(t, &bytes, &n_bytes, &spans, &stride, &n)) return rc;
+    if (n <= 0) return fail(BFK_EUNSUPPORTED, "device prepare: no rows");
+    if (n > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EUNSUPPORTED, "device prepare: too many rows");
+    const bool filtering = opts->skip_del || opts->skip_ins || opts->trim_start > 0 || opts->trim_end > 0;
+    if (filtering && opts->var_type != BFK_VAR_RAW && bfk_table_any_high(t))
+        return fail(BFK_EUNSUPPORTED, "device prepare: non-ASCII bytes (the host stage decides whether a feature holds them)");
+    struct SpanView {
+        int64_t off;
+        int32_t len;
+    };
+    auto span = [&](int64_t r) { return *(const SpanView *)((const char *)spans + (size_t)r * (size_t)stride); };
+    const int64_t base = span(0).off, T = n_bytes - base;
+    if (int rc = ctx_check_text_args(n, sep2, sep2_len, T)) return rc;
+    std::vector<int64_t> row_off((size_t)n + 1);
+    std::vector<int32_t> row_len((size_t)n);
+    {
+        int64_t prev = base;
+        for (int64_t r = 0; r < n; r++) {
+            const SpanView sv = span(r);
+            if (sv.off < prev || sv.len < 0 || sv.off + sv.len > n_bytes) return fail(BFK_EUNSUPPORTED, "device prepare: feature spans not in file order");
+            row_off[(size_t)r] = sv.off;
+            row_len[(size_t)r] = sv.len;
+            prev = sv.off + sv.len;
+        }
+        row_off[(size_t)n] = n_bytes;
+    }
+    const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
+    if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
+    if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n + 1, 1.05)) return rc;
+    if (n + 1 > c->pr_rows_cap) {
+        int64_t cap;
+        int rc = 0;
+        const int64_t want = n + 1;
+        cap = 0; rc |= dev_realloc(&c->pr_spanlen, &cap, want, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_rep, &cap, want, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_group, &cap, want, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_first, &cap, want, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_uindptr, &cap, want + 1, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_rowhash, &cap, want, 1.05);
+        cap = 0; rc |= dev_realloc(&c->pr_val, &cap, want, 1.05);
+        if (rc) return BFK_ENOMEM;
+        c->pr_rows_cap = (int64_t)((double)want * 1.05);
+    }
+    if (int rc = dev_realloc(&c->pr_blk, &c->pr_blk_cap, n / 1024 + 2)) return rc;
+    if (!c->pr_small && hipMalloc((void **)&c->pr_small, 64) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc failed");
+    int64_t slots = 1024;
+    while (slots < 2 * n) slots <<= 1;
+    if (int rc = dev_realloc(&c->pr_table, &c->pr_table_cap, slots)) return rc;
+    // the table's bytes from the first feature on, the rows' starts and lengths: one copy each; the caller's buffers are the
+    // table's own (they outlive the call), the stream is waited for before the call returns
+    HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pr_spanlen, row_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tk_text, bytes + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() { (void)hipStreamSynchronize(s); }
+    } guard{c->stream};
+    if (int e = launch_blank(c->tk_text, c->tk_rowoff, c->pr_spanlen, (int)n, base, (uint32_t)T, (uint8_t)sp, c->stream))
+        return fail(BFK_EHIP, std::string("k_blank launch: ") + hipGetErrorString((hipError_t)e));
+    bfk_ctx::TokPlan tp;
+    tp.d_text = c->tk_text;
+    tp.d_rowoff = c->tk_rowoff;
+    tp.base = base;
+    tp.T = T;
+    tp.n_rows = n;
+    tp.sep = (char)sp;
+    tp.d_span_len = c->pr_spanlen;
+    tp.flt.on = filtering ? 1 : 0;
+    tp.flt.var_type = opts->var_type;
+    tp.flt.skip_ins = opts->skip_ins;
+    tp.flt.skip_del = opts->skip_del;
+    tp.flt.trim_start = opts->trim_start;
+    tp.flt.upper = opts->reference_length - opts->trim_end;
+    if (int rc = ctx_text_events(c)) return rc;
+    if (int rc = ctx_tokenize(c, tp, nullptr, nullptr)) return rc;  // (the CSR of ALL rows is bound now)
+    if (c->tk_stats.n_invalid > 0)
+        return fail(BFK_EUNSUPPORTED, "device prepare: tokens that match no pattern of the feature type (the host stage lists them in the reference's order)");
+    // empty tokens are "invalid" for every grammar whose patterns do not match the empty string (:182-184)
+    const int64_t n_invalid = (filtering && opts->var_type != BFK_VAR_RAW && opts->var_type != BFK_VAR_NEXTCLADE_AA) ? c->tk_stats.n_empty : 0;
+    const int64_t nnz_all = c->nnz;
+    if (int rc = dev_realloc(&c->pr_uindices, &c->pr_uidx_cap, nnz_all + 16, 1.05)) return rc;
+    HIP_TRY(hipMemsetAsync(c->pr_table, 0xFF, (size_t)slots * sizeof(PrepSlot), c->stream));
+    HIP_TRY(hipMemsetAsync(c->pr_small, 0, 64, c->stream));
+    PrepArgs pa{};
+    pa.n = (int)n;
+    pa.by_bytes = filtering ? 0 : 1;
+    pa.text = c->tk_text;
+    pa.row_off = c->tk_rowoff;
+    pa.base = base;
+    pa.span_len = c->pr_spanlen;
+    pa.indptr = c->own_indptr;
+    pa.indices = c->own_indices;
+    pa.rowhash = c->pr_rowhash;
+    pa.table = c->pr_table;
+    pa.mask = (uint32_t)(slots - 1);
+    pa.rep = c->pr_rep;
+    pa.val = c->pr_val;
+    pa.blk = c->pr_blk;
+    pa.totals = c->pr_small;
+    pa.group = c->pr_group;
+    pa.first_row = c->pr_first;
+    pa.u_indptr = c->pr_uindptr;
+    pa.u_indices = c->pr_uindices;
+    pa.fail = c->pr_small + 2;
+    if (int e = launch_collapse(pa, c->stream)) return fail(BFK_EHIP, std::string("collapse launch: ") + hipGetErrorString((hipError_t)e));
+    int h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->pr_small, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h[2] & PREP_FAIL_COLLISION) return fail(BFK_EUNSUPPORTED, "device prepare: two different rows with one hash (the host stage collapses)");
+    if (h[2]) return fail(BFK_EHIP, "device prepare: row table overflow");
+    res->n_rows = n;
+    res->n_unique = h[0];
+    res->nnz = h[1];
+    res->n_invalid = n_invalid;
+    res->n_vocab = c->tk_stats.n_vocab;
+    res->filtering = filtering;
+    return BFK_OK;
+}
+
+static void prep_info(const PrepResult &r, bfk_prep_info *info) {
+    info->n_rows = r.n_rows;
+    info->n_unique = r.n_unique;
+    info->nnz = r.nnz;
+    info->n_invalid = r.n_invalid;
+    info->n_vocab = r.n_vocab;
+    info->filtered = r.filtering ? 1 : 0;
+}
+
+// bfk_table_prepare's contract computed on the device, results installed in the table (group, weight, CSR of the unique rows):
+// what the parity tests compare with the host stage field by field.  (bfk_table_invalid has nothing to hand out: inputs with
+// non-empty invalid tokens are declined, the empty ones are counted in info_out->n_invalid.)
+extern "C" int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, bfk_prep_info *info_out) {
+    if (!info_out) return fail(BFK_EARG, "bfk_table_prepare_device: null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;
+    PrepResult r;
+    if (int rc = ctx_prepare_table(c, t, sep2, sep2_len, opts, &r)) return rc;
+    std::vector<int32_t> group((size_t)r.n_rows), first((size_t)std::max<int64_t>(r.n_unique, 1)), ip((size_t)r.n_unique + 1),
+        ix((size_t)std::max<int64_t>(r.nnz, 1));
+    HIP_TRY(hipMemcpyAsync(group.data(), c->pr_group, (size_t)r.n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    if (r.n_unique) HIP_TRY(hipMemcpyAsync(first.data(), c->pr_first, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ip.data(), c->pr_uindptr, (size_t)(r.n_unique + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (r.nnz) HIP_TRY(hipMemcpyAsync(ix.data(), c->pr_uindices, (size_t)r.nnz * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prep_info(r, info_out);
+    return bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, ip.data(), ix.data(), sep2, sep2_len);
+}
+
+// The CLI's whole middle in one call: filter + collapse + CSR on the device, the unique rows clustered where they lie (no CSR
+// ever visits the host), component sizes against min_cluster_size (:329-339), clusters.tsv by the native writer.
+// max_dist must be > 0 (max-dist 0 needs no device).  info_out->nnz == 0: nothing was clustered or written — the reference
+// cannot build a matrix from an all-empty input (:214), the caller raises its error.
+extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                              int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
+    if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    bfk_ctx *c;
+    if (int rc = default_ctx(&c)) return rc;
+    if (int rc = ctx_enter(c)) return rc;
+    PrepResult r;
+    if (int rc = ctx_prepare_table(c, t, sep2, sep2_len, opts, &r)) return rc;
+    prep_info(r, info_out);
+    std::vector<int32_t> group((size_t)r.n_rows), first((size_t)std::max<int64_t>(r.n_unique, 1)), labels((size_t)std::max<int64_t>(r.n_unique, 1));
+    HIP_TRY(hipMemcpyAsync(group.data(), c->pr_group, (size_t)r.n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    if (r.n_unique) HIP_TRY(hipMemcpyAsync(first.data(), c->pr_first, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
+    if (r.nnz > 0) {
+        // the unique rows' CSR is clustered where the collapse left it
+        if (int rc = bfk_ctx_bind_csr_device(c, c->pr_uindptr, c->pr_uindices, r.n_unique)) return rc;
+        if (int rc = ctx_own_labels(c, r.n_unique)) return rc;
+        if (int rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels)) return rc;
+        if (int rc = bfk_ctx_sync(c, nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(labels.data(), c->own_labels, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, nullptr, nullptr, sep2, sep2_len)) return rc;
+    if (r.nnz <= 0) return BFK_OK;
+    // a component counts the ORIGINAL sequences of its rows (:329-339); labels are the component's smallest row
+    const int32_t *weight = bfk_table_weight(t);
+    const size_t nu = (size_t)r.n_unique;
+    std::vector<int64_t> size(nu, 0);
+    for (size_t u = 0; u < nu; u++) {
+        if (labels[u] < 0 || (size_t)labels[u] >= nu) return fail(BFK_EHIP, "bfk_table_cluster_write_device: label out of range");
+        size[(size_t)labels[u]] += weight[u];
+    }
+    std::vector<int32_t> cl(nu, 0);
+    for (size_t u = 0; u < nu; u++) cl[u] = size[(size_t)labels[u]] >= min_cluster_size ? labels[u] + 1 : 0;
+    return bfk_table_write(t, path, cl.data(), n_clusters_out);
 }
 
 extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,

@@ -132,6 +132,110 @@ __device__ __forceinline__ bool same_bytes(const uint8_t *p, const uint8_t *q, u
     return ((ldu64(p + k) ^ ldu64(q + k)) & mask) == 0ull;
 }
 
+// ---- token classification (filter_features, breakfast.py:131-187): the five feature grammars as byte matchers ----------
+// The same rules as Classifier in bfk_frontend.cpp (the host stage), which tests/test_frontend.py pins against the regex mirror;
+// tests/test_gpu_prep.py runs both on the same tokens.  GET(i) = byte i of the token (0 <= i < n, n >= 1: empty tokens never
+// get here).  -> 0 keep, 1 drop, 2 invalid ("Skipping invalid feature")
+enum : int { TOKV_KEEP = 0, TOKV_DROP = 1, TOKV_INVALID = 2 };
+
+template <typename GET>
+__device__ __forceinline__ int tok_classify(const TokFilter &f, uint32_t n, GET get) {
+    auto up = [](uint32_t c) { return c >= 'A' && c <= 'Z'; };
+    auto dg = [](uint32_t c) { return c >= '0' && c <= '9'; };
+    auto alnum = [&](uint32_t c) { return up(c) || dg(c) || (c >= 'a' && c <= 'z'); };
+    auto all_digits = [&](uint32_t b, uint32_t e) {  // [b, e) non-empty and all digits
+        if (e <= b) return false;
+        for (uint32_t i = b; i < e; i++)
+            if (!dg(get(i))) return false;
+        return true;
+    };
+    auto find = [&](uint32_t b, uint32_t e, uint32_t ch) {  // first index of ch in [b, e), or e
+        for (uint32_t i = b; i < e; i++)
+            if (get(i) == ch) return i;
+        return e;
+    };
+    auto num_colon_num = [&](uint32_t b, uint32_t e) {  // \d+:\d+ over [b, e)
+        const uint32_t c = find(b, e, ':');
+        return c < e && all_digits(b, c) && all_digits(c + 1, e);
+    };
+    auto is_del_prefix = [&](uint32_t b, uint32_t e) {  // del:\d+:\d+ over [b, e)
+        return e > b + 4 && get(b) == 'd' && get(b + 1) == 'e' && get(b + 2) == 'l' && get(b + 3) == ':' && num_colon_num(b + 4, e);
+    };
+    const int ins = f.skip_ins ? TOKV_DROP : TOKV_KEEP, del = f.skip_del ? TOKV_DROP : TOKV_KEEP;
+    // ^[A-Z](\d+)[A-Z]$ with the trims (:166-175): dropped when pos <= trim_start or pos >= upper
+    auto dna_sub = [&](int *v) {
+        if (n < 3 || !up(get(0)) || !up(get(n - 1)) || !all_digits(1, n - 1)) return false;
+        uint32_t b = 1, e = n - 1;
+        while (e - b > 1 && get(b) == '0') b++;
+        bool trimmed = true;  // more than 18 digits: beyond any int64 bound, pos >= upper
+        if (e - b <= 18) {
+            long long pos = 0;
+            for (uint32_t i = b; i < e; i++) pos = pos * 10 + (long long)(get(i) - '0');
+            trimmed = pos <= f.trim_start || pos >= f.upper;
+        }
+        *v = trimmed ? TOKV_DROP : TOKV_KEEP;
+        return true;
+    };
+    // [a-zA-Z0-9]+: -> index behind the ':' or 0
+    auto gene_prefix = [&]() {
+        uint32_t i = 0;
+        while (i < n && alnum(get(i))) i++;
+        return (i > 0 && i < n && get(i) == ':') ? i + 1 : 0u;
+    };
+    // [A-Z]\d+ from b -> index behind the digits or 0
+    auto letter_digits = [&](uint32_t b) {
+        if (n < b + 2 || !up(get(b)) || !dg(get(b + 1))) return 0u;
+        uint32_t i = b + 1;
+        while (i < n && dg(get(i))) i++;
+        return i;
+    };
+    int v;
+    switch (f.var_type) {
+    case 0:  // covsonar_dna
+        if (dna_sub(&v)) return v;
+        if (n >= 2 && up(get(n - 1)) && up(get(n - 2))) return ins;  // ^.*[A-Z][A-Z]$
+        if (is_del_prefix(0, n)) return del;                          // ^del:\d+:\d+$
+        return TOKV_INVALID;
+    case 2: {  // nextclade_dna
+        if (dna_sub(&v)) return v;
+        const uint32_t c = find(0, n, ':');
+        if (c < n && all_digits(0, c)) {  // ^\d+:[A-Z]+$
+            bool ok = n > c + 1;
+            for (uint32_t i = c + 1; ok && i < n; i++) ok = up(get(i));
+            if (ok) return ins;
+        }
+        const uint32_t m = find(0, n, '-');  // ^\d+(-\d+)?$
+        if (m < n ? (all_digits(0, m) && all_digits(m + 1, n)) : all_digits(0, n)) return del;
+        return TOKV_INVALID;
+    }
+    case 1: {  // covsonar_aa
+        const uint32_t g = gene_prefix();
+        if (!g) return TOKV_INVALID;
+        const uint32_t e = letter_digits(g);
+        if (e && e < n) {
+            bool letters = true;
+            for (uint32_t i = e; i < n; i++) letters = letters && up(get(i));
+            if (letters) return n - e == 1 ? TOKV_KEEP : ins;  // [A-Z]\d+[A-Z] | [A-Z]\d+[A-Z][A-Z]+
+        }
+        if (is_del_prefix(g, n)) return del;
+        return TOKV_INVALID;
+    }
+    case 3: {  // nextclade_aa (its insertion pattern is ^$: only an empty token matches it)
+        const uint32_t g = gene_prefix();
+        if (!g) return TOKV_INVALID;
+        const uint32_t e = letter_digits(g);
+        if (e && e + 1 == n) {
+            const uint32_t c = get(e);
+            if (up(c) || c == '*') return TOKV_KEEP;  // [A-Z]\d+[A-Z*]
+            if (c == '-') return del;                 // [A-Z]\d+-
+        }
+        return TOKV_INVALID;
+    }
+    default:
+        return TOKV_KEEP;  // raw: no patterns
+    }
+}
+
 // ---- the vocabulary table -------------------------------------------------------------------------------------------
 // 16-byte slots {key64, first32, id32}, open addressing, linear probing.  Two kinds of key:
 //   INLINE  (top byte = length 1 .. 7, low 56 bits = the token's bytes): the token IS the key — a lookup is one 16-byte load
@@ -155,8 +259,9 @@ __device__ __forceinline__ uint32_t tok_hash_inline(unsigned long long key) {
     return h ^ (h >> 16);
 }
 
-// a token of 8 bytes or more at byte offset j: length from the bound bits in global memory, hash over its bytes, HASHED entry
-__device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j) {
+// a token of 8 bytes or more at byte offset j: length from the bound bits in global memory, the filter's verdict, hash over
+// its bytes, HASHED entry.  -> its slot, or TOK_NONE when the filter drops it (*invalid: it matched no pattern)
+__device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j, bool *invalid) {
     uint32_t w = (j + 1) >> 5;
     uint32_t bw = a.boundbits[w] & (~0u << ((j + 1) & 31u));
     const uint32_t w_max = (j + TOK_MAX_LEN + 64u) >> 5;  // (beyond: the token is too long whatever follows; the padding is all separators)
@@ -168,6 +273,13 @@ __device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j) {
         return 0;
     }
     const uint8_t *p = a.text + j;
+    if (a.flt.on) {
+        const int v = tok_classify(a.flt, len, [&](uint32_t i) { return (uint32_t)p[i]; });
+        if (v != TOKV_KEEP) {
+            *invalid = v == TOKV_INVALID;
+            return TOK_NONE;
+        }
+    }
     uint32_t h = 0x9747B28Cu ^ len, k = 0;
     for (; k + 4 <= len; k += 4) h = mur_step(h, ldu32(p + k));
     if (len & 3u) h = mur_step(h, ldu32(p + k) & ((1u << (8 * (len & 3u))) - 1u));
@@ -203,6 +315,7 @@ struct alignas(16) TokUnitLds {
     uint32_t bound[TOK_WPW * TOK_WIN / 32 + 2];
     uint16_t list[TOK_LIST_CAP];
     uint16_t pend_t[TOK_LIST_CAP];
+    uint32_t kept[TOK_WPW * TOK_WIN / 32];  // filter mode: a bit per byte of the unit — a token the filter keeps starts here
 };
 
 // the token that starts at byte `pos` of the staged unit: its inline key (length 1 .. 7 in the top byte, bytes below) and
@@ -232,6 +345,7 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
     constexpr int U = TOK_LOOKUP_U;
     const int lane = threadIdx.x & 63;
     uint32_t n_pend = 0;
+    uint32_t n_inval = 0;  // (per lane) token occurrences that match no pattern of the feature type
     for (uint32_t r0 = 0; r0 < n_tok; r0 += 64 * U) {
         bool act[U], inl[U];
         uint32_t pos[U], slot[U];
@@ -243,6 +357,15 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
             act[u] = t < n_tok;
             pos[u] = act[u] ? (uint32_t)s.list[t] : 0u;
             inl[u] = tok_key_at(s, pos[u], &key[u]);
+            if (a.flt.on && act[u] && inl[u]) {  // the filter's verdict on a short token, from the bytes in its key
+                const unsigned long long kb = key[u];
+                const int v = tok_classify(a.flt, (uint32_t)(kb >> 56), [&](uint32_t i) { return (uint32_t)(kb >> (8 * i)) & 0xFFu; });
+                if (v != TOKV_KEEP) {  // dropped: no table entry, no CSR entry
+                    act[u] = false;
+                    out[t] = TOK_NONE;
+                    n_inval += v == TOKV_INVALID ? 1u : 0u;
+                }
+            }
             slot[u] = tok_hash_inline(key[u]) & a.tmask;
             q[u] = *reinterpret_cast<const uint4 *>(&a.table[(act[u] && inl[u] && !(a.dbg & 2)) ? slot[u] : 0u]);
             if (a.dbg & 2) {  // (timing experiment: every token "found" without a look at the table)
@@ -259,6 +382,7 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
                 const uint32_t j = text0 + pos[u];
                 if (j < q[u].z && !(a.dbg & 1)) atomicMin(&a.table[slot[u]].first, j);
                 out[t] = slot[u];
+                if (a.flt.on) atomicOr(&s.kept[pos[u] >> 5], 1u << (pos[u] & 31u));
             }
             const bool pend = act[u] && !found && !(a.dbg & 16);
             const unsigned long long bal = __ballot(pend);
@@ -286,8 +410,11 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
         const bool inl = tok_key_at(s, pos, &key);
         const uint32_t j = text0 + pos;
         uint32_t sl;
-        if (!inl) sl = tok_long(a, j);
-        else {
+        if (!inl) {
+            bool inval = false;
+            sl = tok_long(a, j, &inval);
+            n_inval += inval ? 1u : 0u;
+        } else {
             uint32_t slot = tok_hash_inline(key) & a.tmask;
             // the slot's state past the caches, key and first offset requested together
             unsigned long long cur = __hip_atomic_load(&a.table[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -316,7 +443,13 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
                 first = __hip_atomic_load(&a.table[slot].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        if (a.flt.on && sl != TOK_NONE) atomicOr(&s.kept[pos >> 5], 1u << (pos & 31u));
         out[t] = sl;
+    }
+    if (a.flt.on) {  // invalid occurrences of the wave: one add (they are rare; what they are is the host path's to print)
+        uint32_t tot = n_inval;
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0 && tot) atomicAdd(&a.tc->n_invalid, tot);
     }
 }
 
@@ -336,6 +469,10 @@ __device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, T
     for (int u = 0; u < TOK_WPW; u++) {
         *reinterpret_cast<uint4 *>(&s.text[u * (TOK_WIN / 4) + 4 * lane]) = v[u];
         reinterpret_cast<uint16_t *>(s.bound)[u * (TOK_WIN / 16) + lane] = (uint16_t)bd[u];
+    }
+    if (a.flt.on) {
+        s.kept[lane] = 0u;
+        s.kept[64 + lane] = 0u;
     }
     if (lane < 4) s.text[TOK_WPW * TOK_WIN / 4 + lane] = ldu32(a.text + text0 + TOK_WPW * TOK_WIN + 4 * lane);
     if (lane < 2) s.bound[TOK_WPW * TOK_WIN / 32 + lane] = a.boundbits[(text0 + TOK_WPW * TOK_WIN) / 32 + lane];
@@ -369,6 +506,10 @@ __device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, T
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // (the next sub-unit overwrites the list)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (a.flt.on) {  // the unit's kept-token bits: 128 words, two per lane, coalesced
+        a.keptbits[text0 / 32 + lane] = s.kept[lane];
+        a.keptbits[text0 / 32 + 64 + lane] = s.kept[64 + lane];
     }
 }
 
@@ -492,14 +633,17 @@ __global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uin
 // at the byte offset it holds.
 __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+    // (filter mode: the CSR holds the tokens the filter kept — their bits and prefixes instead of the token starts')
+    const uint32_t *bits = a.flt.on ? a.keptbits : a.startbits;
+    const uint32_t *win = a.flt.on ? a.keptwin : a.winbase, *blk = a.flt.on ? a.keptblk : a.blkbase;
     for (uint32_t r = tid; r <= (uint32_t)a.n_rows; r += nth) {
         long long ol = a.row_off[r] - a.base;
         ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported by k_tok_rowbits)
         const uint32_t o = (uint32_t)ol;
         const uint32_t w = o / TOK_WIN;
-        uint32_t cnt = a.blkbase[w / TOK_SCAN_WINS] + a.winbase[w];
-        for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.startbits[q]);
-        cnt += (uint32_t)__popc(a.startbits[o >> 5] & ((1u << (o & 31u)) - 1u));
+        uint32_t cnt = blk[w / TOK_SCAN_WINS] + win[w];
+        for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(bits[q]);
+        cnt += (uint32_t)__popc(bits[o >> 5] & ((1u << (o & 31u)) - 1u));
         a.indptr[r] = (int)cnt;
     }
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
@@ -511,11 +655,36 @@ __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
     }
 }
 
+// k_tok_empties (filter mode): the EMPTY tokens of every row — str.split hands them to the patterns too, and for every feature
+// type but nextclade_aa (whose insertion pattern is ^$) and raw they are "invalid" and printed as such (breakfast.py:182-184).
+// A row's span [s, e) splits into (separators in it) + 1 tokens, of which (token starts in it) are not empty: both counts
+// from the bit arrays — bound bits are separators and row starts, so separators = bound bits - (a token starts on s).
+__global__ __launch_bounds__(256) void k_tok_empties(TokArgs a) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    uint32_t cnt = 0;
+    if (r < (uint32_t)a.n_rows) {
+        const uint32_t s = (uint32_t)(a.row_off[r] - a.base);
+        const uint32_t e = a.span_len ? s + (uint32_t)a.span_len[r] : (uint32_t)(a.row_off[r + 1] - a.base);
+        uint32_t nb = 0, ns = 0;
+        for (uint32_t q = s >> 5; q <= ((e - 1) >> 5) && e > s; q++) {
+            uint32_t m = ~0u;
+            if (q == (s >> 5)) m &= ~0u << (s & 31u);
+            if (q == ((e - 1) >> 5)) m &= ~0u >> (31u - ((e - 1) & 31u));
+            nb += (uint32_t)__popc(a.boundbits[q] & m);
+            ns += (uint32_t)__popc(a.startbits[q] & m);
+        }
+        const uint32_t first_is_start = e > s ? (a.startbits[s >> 5] >> (s & 31u)) & 1u : 0u;
+        cnt = (nb - first_is_start) + 1u - ns;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.tc->n_empty, cnt);
+}
+
 // first-occurrence bits per window (32 words): 8 lanes per window, a uint4 each; a block = the 64 windows of a scan block
-__global__ __launch_bounds__(512) void k_voc_count(TokArgs a) {
+__global__ __launch_bounds__(512) void k_voc_count(const uint32_t *__restrict__ bits, uint32_t *__restrict__ win_out, uint32_t *__restrict__ blk_out) {
     __shared__ unsigned s_cnt[TOK_SCAN_WINS];
     const uint32_t t = blockIdx.x * 512u + threadIdx.x;  // word quad (T_pad is a multiple of the 64 KiB a block covers)
-    const uint4 q = reinterpret_cast<const uint4 *>(a.firstbits)[t];
+    const uint4 q = reinterpret_cast<const uint4 *>(bits)[t];
     uint32_t c = (uint32_t)(__popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w));
     c += __shfl_xor(c, 1);
     c += __shfl_xor(c, 2);
@@ -525,8 +694,8 @@ __global__ __launch_bounds__(512) void k_voc_count(TokArgs a) {
     if (threadIdx.x < 64) {
         const int v = (int)s_cnt[threadIdx.x];
         const int inc = tok_wave_incl_scan(v);
-        a.vocwin[blockIdx.x * TOK_SCAN_WINS + threadIdx.x] = (uint32_t)(inc - v);
-        if (threadIdx.x == 63) a.vocblk[blockIdx.x] = (uint32_t)inc;
+        win_out[blockIdx.x * TOK_SCAN_WINS + threadIdx.x] = (uint32_t)(inc - v);
+        if (threadIdx.x == 63) blk_out[blockIdx.x] = (uint32_t)inc;
     }
 }
 
@@ -556,6 +725,28 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     o.z = g0 + 2 < nnz ? (uint32_t)a.table[s.z].id : 0u;
     o.w = g0 + 3 < nnz ? (uint32_t)a.table[s.w].id : 0u;
     *reinterpret_cast<uint4 *>(a.indices + g0) = o;
+}
+
+// filter mode: the slots of ALL tokens lie in text order in `tokslot` (TOK_NONE where the filter dropped one); the CSR holds the
+// kept ones.  A wave per unit of 4 KiB: the unit's tokens start at the all-token prefix of its first window, its kept tokens at
+// the kept-token prefix; kept tokens are written densely, in order.  `tokslot` and `indices` are different arrays here.
+__global__ __launch_bounds__(256) void k_tok_ids_kept(TokArgs a, uint32_t n_units) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t unit = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const uint32_t win0 = unit * TOK_WPW, sb = win0 / TOK_SCAN_WINS;
+    const uint32_t g0 = a.blkbase[sb] + a.winbase[win0];
+    // (the unit's end: the next unit's start, or — for the last unit of a scan block — the next block's base)
+    const uint32_t win1 = win0 + TOK_WPW;
+    const uint32_t g1 = (win1 % TOK_SCAN_WINS) ? a.blkbase[sb] + a.winbase[win1] : a.blkbase[sb + 1];
+    uint32_t o = a.keptblk[sb] + a.keptwin[win0];
+    for (uint32_t g = g0; g < g1; g += 64) {
+        const uint32_t s = g + lane < g1 ? a.tokslot[g + lane] : TOK_NONE;
+        const bool keep = s != TOK_NONE;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) a.indices[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)a.table[s].id;
+        o += (uint32_t)__popcll(bal);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -620,15 +811,29 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
         hashed = std::max(hashed, u1);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
+    if (a.flt.on) {  // the tokens the filter kept: counted per window / block like the token starts, prefix over the blocks
+        hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a.keptbits, a.keptwin, a.keptblk);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.keptblk, scan_blocks, &a.tc->nnz_kept);
+        LAUNCH_CHECK();
+        if (a.n_rows > 0) {
+            hipLaunchKernelGGL(k_tok_empties, dim3((a.n_rows + 255) / 256), dim3(256), 0, st, a);
+            LAUNCH_CHECK();
+        }
+    }
     hipLaunchKernelGGL(k_tok_rows, dim3(std::max(table_blocks, (unsigned)std::min(8192, (a.n_rows + 256) / 256))), dim3(256), 0, st, a);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a.firstbits, a.vocwin, a.vocblk);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.vocblk, scan_blocks, &a.tc->n_vocab);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_voc_ids, dim3(table_blocks), dim3(256), 0, st, a);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tok_ids, dim3(std::max(1u, (unsigned)((a.nnz_cap + 1023) / 1024))), dim3(256), 0, st, a);
+    if (a.flt.on) {
+        hipLaunchKernelGGL(k_tok_ids_kept, dim3((scan_blocks * UNITS_PER_BLK + 3) / 4), dim3(256), 0, st, a, scan_blocks * UNITS_PER_BLK);
+    } else {
+        hipLaunchKernelGGL(k_tok_ids, dim3(std::max(1u, (unsigned)((a.nnz_cap + 1023) / 1024))), dim3(256), 0, st, a);
+    }
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     return 0;

@@ -15,6 +15,8 @@ native host stages.
 
 from __future__ import annotations
 
+import os
+
 from . import _front
 
 
@@ -43,6 +45,42 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
         _front.preload(input_file)  # HIP runtime + context + code object on a native thread while the input is parsed
     try:
         table = _front.Table.open(input_file, sep, id_col, clust_col)
+    except _front.Unsupported:
+        return False
+    if max_dist != 0 and n_gpus == 1 and os.environ.get("BFK_DEVICE_PREP", "1") != "0":
+        # filter + collapse + CSR on the device, the unique rows clustered where they lie, the writer: ONE native call
+        # (bfk_table_cluster_write_device).  It declines — nothing printed, nothing written — what only the host stage restates
+        # (multi-byte token separators, tokens that match no pattern and have to be listed, ...): the stages below take over.
+        made = not outdir.exists()
+        outdir.mkdir(parents=True, exist_ok=True)
+        try:
+            info, n_clusters = table.pipeline_device(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length,
+                                                     max_dist, min_cluster_size, outdir / "clusters.tsv")
+        except _front.Unsupported:
+            info = None
+        if info is not None:
+            n, nu = int(info.n_rows), int(info.n_unique)
+            print(f"Number of sequences: {n}")
+            for _ in range(int(info.n_invalid)):  # (only empty tokens get here: the device declines inputs with any other invalid one)
+                print("Skipping invalid feature: ''")
+            print(f"Number of duplicates: {n - nu}")
+            print(f"Number of unique sequences: {nu}")
+            if info.nnz == 0:
+                if made:
+                    try:
+                        outdir.rmdir()
+                    except OSError:
+                        pass
+                # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
+                raise ValueError("unable to infer matrix dimensions")
+            print("Imported cached results are not available. "
+                  "Distance matrix of complete dataset will be calculated.")
+            print("Create graph and recover connected components")
+            print("Save clusters")
+            print(f"Number of clusters found: {n_clusters}")
+            table.close()
+            return True
+    try:
         info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
     except _front.Unsupported:
         return False

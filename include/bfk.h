@@ -205,8 +205,10 @@ typedef struct bfk_text_stats {
     float ms_hash;           /* k_tok_head + k_tok_hash */
     float ms_ids;            /* k_tok_rows + k_tok_first + k_tok_ids */
     float ms_total;          /* first copy to last kernel */
-    float ms_head;           /* k_tok_head alone (part of ms_hash): one wave, the first 4 KiB */
+    float ms_head;           /* (round 3: k_tok_head alone; the hash now runs as three launches, this stays 0) */
     float reserved2_;
+    int64_t n_invalid;       /* filter mode: non-empty token occurrences that matched no pattern of the feature type */
+    int64_t n_empty;         /* filter mode: empty tokens inside the rows' spans */
 } bfk_text_stats;
 int bfk_ctx_text_stats(bfk_ctx *ctx, bfk_text_stats *out);
 
@@ -331,6 +333,27 @@ int bfk_preload_wait(void);
 void bfk_preload_join(void);
 int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cluster_size, int32_t n_gpus, const char *path,
                             int64_t *n_clusters_out);
+
+/* ---- filter + collapse + CSR ON THE DEVICE (libbfk.so; bfk_text.hip's filter mode, bfk_prep.hip) --------------------------
+ * bfk_table_prepare's contract with the work in HBM: the table's bytes cross PCIe once (from its first feature on), what lies
+ * between the feature column's fields is blanked, every token occurrence is judged by the five feature grammars where it is
+ * hashed (a dropped token never enters the vocabulary or the CSR), rows are collapsed by a hash of their identity (the kept-id
+ * sequence, or the raw bytes when nothing is filtered: :128-129) with an exact comparison against the representative, unique
+ * rows in first-appearance order (:72-79).  BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token
+ * separators of several bytes, 4 GiB of text, NON-EMPTY tokens that match no pattern (the reference prints each, in order; the
+ * empty ones are only counted: info_out->n_invalid lines "Skipping invalid feature: ''"), non-ASCII bytes under a grammar.
+ *   bfk_table_prepare_device        results installed in the table like bfk_table_prepare's (group, weight, CSR of the unique
+ *                                   rows; the filtered feature STRINGS stay with the host stage: BFK_ESTATE from their accessors)
+ *   bfk_table_cluster_write_device  the CLI's whole middle: the unique rows are clustered where the collapse left them (no CSR
+ *                                   visits the host), component sizes against min_cluster_size (:329-339), bfk_table_write.
+ *                                   max_dist > 0.  info_out->nnz == 0: nothing clustered or written (the reference cannot build
+ *                                   its matrix from an all-empty input, :214: the caller raises).                            */
+int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, bfk_prep_info *info_out);
+int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                   int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out);
+/* the same through the library bfk_preload_start loaded (libbfk_front.so: no HIP dependency of its own) */
+int bfk_table_pipeline_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                              int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out);
 
 /* write `path` = "id\tcluster_id" per input row in input order; cluster_of_unique[u] = any positive cluster
  * number or 0 for none; numbers are re-assigned 1.. by first appearance in input order (:51-60).       */

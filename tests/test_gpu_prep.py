@@ -1,0 +1,214 @@
+"""GPU parity of the DEVICE prepare — filter_features (breakfast.py:116-190) inside the tokeniser, collapse_duplicates (:72-79)
+by row hash + exact comparison, sparse_feature_matrix (:193-215) of the unique rows — against the host stage
+(bfk_table_prepare), which tests/test_frontend.py pins to the regex / pandas mirror of the reference and to the golden vectors.
+Everything is compared field by field: group index of every input row, weights, CSR of the unique rows, vocabulary size, the
+number of "Skipping invalid feature" lines; and clusters.tsv byte for byte through the one-call pipeline and the CLI."""
+
+import hashlib
+import io
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+from test_frontend import OPTS, _fuzz_tokens
+
+from breakfast_amd import _lib, fastpath, synth
+
+pytestmark = pytest.mark.gpu
+
+VAR_TYPES = ["covsonar_dna", "covsonar_aa", "nextclade_dna", "nextclade_aa", "raw"]
+
+
+def both(ids, feats, sep2, var_type, opts):
+    th = _lib.Table.from_lists(ids, feats)
+    ih = th.prepare(sep2, var_type, *opts)
+    td = _lib.Table.from_lists(ids, feats)
+    try:
+        idv = td.prepare_device(sep2, var_type, *opts)
+    except _lib.Unsupported:
+        return th, ih, None, None
+    return th, ih, td, idv
+
+
+def assert_same(th, ih, td, idv):
+    assert td is not None, "the device stage declined an input without invalid tokens"
+    for k in ("n_rows", "n_unique", "nnz", "n_invalid", "n_vocab", "filtered"):
+        assert getattr(ih, k) == getattr(idv, k), k
+    np.testing.assert_array_equal(td.group, th.group)
+    np.testing.assert_array_equal(td.weight, th.weight)
+    np.testing.assert_array_equal(td.indptr, th.indptr)
+    np.testing.assert_array_equal(td.indices, th.indices)
+
+
+def _structured_tokens(rng, n):
+    """well-formed tokens of every grammar (and near misses): substitutions, insertions, deletions of the DNA and AA dialects"""
+    genes = ["S", "N", "ORF1a", "orf1b", "E", "M", "ORF8", "x9", "7a"]
+    L = "ACDEFGHIKLMNPQRSTVWYZ"
+    out = []
+    for _ in range(n):
+        g, a, b = genes[int(rng.integers(len(genes)))], L[int(rng.integers(len(L)))], L[int(rng.integers(len(L)))]
+        pos = int(rng.choice([0, 1, 99, 100, 101, 263, 264, 265, 771, 772, 899, 900, 999, 1000, 29674, 29675, int(rng.integers(0, 40000))]))
+        k = int(rng.integers(1, 40))
+        p = f"{pos:0{int(rng.integers(1, 8))}d}" if rng.random() < 0.2 else str(pos)
+        out.append([f"{g}:{a}{p}{b}", f"{g}:{a}{p}{b}{a}", f"{g}:{a}{p}{b}{a}{b}", f"{g}:del:{p}:{k}", f"{g}:{a}{p}-", f"{g}:{a}{p}*",
+                    f"{a}{p}{b}", f"{a}{p}{b}{a}", f"{a}{p}{b}{a}{b}{a}", f"del:{p}:{k}", f"{p}:{a}{b}", f"{p}:{a}", f"{p}-{pos + k}",
+                    f"{p}", f"{g}:{a}{p}", f"{g}{a}{p}{b}", f"{g}:{p}{b}", f"{a}{p}", f"del:{p}", f"{p}-", f"{g}:{a}{p}b"][int(rng.integers(21))])
+    return out
+
+
+def host_invalid_tokens(tokens, var_type, opts):
+    """which of `tokens` the host classifier calls invalid (one token per row, no separators inside)"""
+    t = _lib.Table.from_lists([f"t{i}" for i in range(len(tokens))], tokens)
+    info = t.prepare("\x01", var_type, *opts)  # (a separator no token holds: every row is one token)
+    return {t.invalid(i) for i in range(info.n_invalid)}
+
+
+@pytest.mark.parametrize("var_type", VAR_TYPES)
+@pytest.mark.parametrize("opts", OPTS)
+def test_device_filter_and_collapse_vs_host_on_the_token_grammar_fuzz(var_type, opts):
+    """the five grammars as device byte matchers: rows built from the fuzz tokens of tests/test_frontend.py that the host calls
+    valid (kept or dropped: trims, indel switches, 19+ digit positions, leading zeros ...) plus empty tokens in every place —
+    identical group / weight / CSR / counts; with ONE token the host calls invalid the device stage declines the input"""
+    rng = np.random.default_rng(abs(hash((var_type, opts, 1))) % (2**32))
+    toks = sorted({t for t in _fuzz_tokens(rng, 1500) + _structured_tokens(rng, 1500) if t and " " not in t})
+    filtering = opts[0] or opts[1] or opts[2] > 0 or opts[3] > 0
+    bad = host_invalid_tokens(toks, var_type, opts) if filtering else set()
+    good = [t for t in toks if t not in bad]
+    feats = []
+    for _ in range(400):
+        k = int(rng.integers(0, 9))
+        feats.append(" ".join(good[int(rng.integers(0, len(good)))] for _ in range(k)))
+    g = lambda i: good[i % len(good)]
+    feats += ["", " ", "  ", g(0) + "  " + g(1), " " + g(2), g(3) + " ", feats[5], feats[7], feats[5]]
+    ids = [f"s{i}" for i in range(len(feats))]
+    assert_same(*both(ids, feats, " ", var_type, opts))
+    for tok in list(sorted(bad))[:: max(1, len(bad) // 12)]:
+        th, ih, td, idv = both(ids + ["x"], feats + [g(0) + " " + tok], " ", var_type, opts)
+        assert td is None and ih.n_invalid >= 1, tok
+
+
+def test_device_filter_kats(kats):
+    """the reference's own filter cases (tests/golden/kats.json, captured by importing it): the device stage either gives
+    the host stage's result or — where the reference prints a non-empty invalid token — declines"""
+    for c in kats["filter"]:
+        if len(c["sep"]) != 1:
+            continue
+        opts = (c["skip_ins"], c["skip_del"], c["trim_start"], c["trim_end"], c["reference_length"])
+        th, ih, td, idv = both(["a", "b"], [c["input"], c["input"]], c["sep"], c["var_type"], opts)
+        names = [ln.split("'", 1)[1].rsplit("'", 1)[0] for ln in c["stdout"].splitlines() if ln.startswith("Skipping invalid")]
+        if any(n != "" for n in names):
+            assert td is None, c
+        else:
+            assert_same(th, ih, td, idv)
+            assert idv.n_invalid == 2 * len(names)
+
+
+@pytest.mark.parametrize("opts", OPTS[:4])
+@pytest.mark.parametrize("indels", [False, True])
+def test_device_prepare_synthetic_profiles_with_duplicates(opts, indels):
+    kw = dict(p_del=0.05, p_ins=0.02) if indels else {}
+    feats = synth.generate_profiles(20000, seed=11, **kw)
+    feats += feats[:3000] + feats[100:200] * 30 + ["", ""]  # duplicates, a hub of 30 copies, empty profiles
+    rng = np.random.default_rng(3)
+    order = rng.permutation(len(feats))
+    feats = [feats[i] for i in order]
+    ids = [f"q{i}" for i in range(len(feats))]
+    assert_same(*both(ids, feats, " ", "covsonar_dna", opts))
+
+
+def test_device_prepare_identity_is_the_string_when_nothing_is_filtered():
+    """no filter: the reference groups by the RAW string (:128-129) — "A  B" and "A B" stay apart, equal strings collapse"""
+    feats = ["A1T  C2G", "A1T C2G", "A1T C2G", " A1T C2G", "A1T C2G ", "A1T  C2G", "", "", " ", "C2G A1T"]
+    ids = [f"s{i}" for i in range(len(feats))]
+    th, ih, td, idv = both(ids, feats, " ", "covsonar_dna", (False, False, 0, 0, 29903))
+    assert_same(th, ih, td, idv)
+    assert idv.n_unique == 7 and idv.filtered == 0
+    # the same rows with the filter on: identity = the kept tokens in order
+    th, ih, td, idv = both(ids, feats, " ", "covsonar_dna", (True, True, 0, 0, 29903))
+    assert_same(th, ih, td, idv)
+    assert idv.n_unique == 3
+
+
+def test_device_prepare_a_hub_of_identical_rows_and_long_tokens():
+    """60 000 copies of one profile (one slot of the row table for all of them) between other rows; insertions of 8+ bytes
+    (hashed vocabulary entries) kept and dropped"""
+    base = synth.generate_profiles(2000, seed=5, p_del=0.1, p_ins=0.1)
+    feats = base[:1000] + [base[17]] * 60000 + base[1000:] + [base[3]] * 500
+    ids = [f"h{i}" for i in range(len(feats))]
+    for opts in ((True, True, 264, 228, 29903), (False, False, 264, 228, 29903), (False, True, 0, 0, 29903)):
+        th, ih, td, idv = both(ids, feats, " ", "covsonar_dna", opts)
+        assert_same(th, ih, td, idv)
+        assert int(td.weight.max()) >= 60000
+
+
+def test_device_prepare_declines_what_it_does_not_restate():
+    t = _lib.Table.from_lists(["a", "b"], ["A1T||C2G", "A1T"])
+    with pytest.raises(_lib.Unsupported):
+        t.prepare_device("||", "raw", False, False, 0, 0, 0)
+    with pytest.raises(ValueError):
+        t.prepare_device("", "raw", False, False, 0, 0, 0)
+    t = _lib.Table.from_lists(["é", "b"], ["A1T C２G", "A1T"])  # non-ASCII under a grammar
+    with pytest.raises(_lib.Unsupported):
+        t.prepare_device(" ", "covsonar_dna", True, True, 0, 0, 29903)
+    info = t.prepare_device(" ", "raw", True, True, 5, 5, 29903)
+    assert info.n_unique == 2
+    t = _lib.Table.from_lists(["a"], ["A1T C2G"])
+    t.prepare_device(" ", "covsonar_dna", True, True, 0, 0, 29903)
+    with pytest.raises(_lib.BfkError) as ei:  # the filtered strings stay with the host stage
+        t.feature(0)
+    assert ei.value.code == -6
+
+
+@pytest.mark.parametrize("max_dist,indels,opts", [(1, False, OPTS[0]), (3, True, OPTS[1]), (2, True, OPTS[0])])
+def test_pipeline_on_the_device_writes_the_host_path_s_clusters_tsv(max_dist, indels, opts, tmp_path):
+    """bfk_table_cluster_write_device (filter + collapse + CSR + clustering in HBM, writer) against host prepare +
+    bfk_table_cluster_write on the same table: clusters.tsv byte for byte, the same counts"""
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    inp = tmp_path / "in.tsv"
+    synth.generate_tsv(inp, 30000, **kw)
+    text = inp.read_text().splitlines()
+    text += [ln.replace("seq", "dup") for ln in text[1:4000]] + ["empty1\t", "empty2\t"]
+    inp.write_text("\n".join(text) + "\n")
+    th = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    ih = th.prepare(" ", "covsonar_dna", *opts)
+    labels, _ = _lib.cluster_csr(th.indptr, th.indices, max_dist)
+    cid, n_host = fastpath.cluster_ids(labels, th.weight, 2)
+    th.write(tmp_path / "host.tsv", cid)
+    td = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    idv, n_dev = td.cluster_write_device(" ", "covsonar_dna", *opts, max_dist, 2, tmp_path / "dev.tsv")
+    assert (tmp_path / "dev.tsv").read_bytes() == (tmp_path / "host.tsv").read_bytes()
+    assert n_dev == n_host
+    for k in ("n_rows", "n_unique", "nnz", "n_invalid", "n_vocab", "filtered"):
+        assert getattr(ih, k) == getattr(idv, k), k
+
+
+def test_cli_runs_the_device_stages_and_prints_what_the_host_stages_print(tmp_path, monkeypatch):
+    """python -m breakfast_amd through fastpath.run: with the device prepare (the default) and with BFK_DEVICE_PREP=0 (host
+    tokeniser / filter / collapse) — the same stdout, the same clusters.tsv; an input with a token that has to be listed
+    takes the host stages by itself"""
+    inp = tmp_path / "in.tsv"
+    synth.generate_tsv(inp, 20000)
+    lines = inp.read_text().splitlines()
+    lines += ["e1\t", "e2\t", "d1\t" + lines[5].split("\t")[1], "d2\t" + lines[5].split("\t")[1]]
+    inp.write_text("\n".join(lines) + "\n")
+
+    def run(outdir, device):
+        monkeypatch.setenv("BFK_DEVICE_PREP", "1" if device else "0")
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            ok = fastpath.run(inp, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 1, 2, outdir)
+        assert ok
+        return buf.getvalue(), hashlib.sha256((outdir / "clusters.tsv").read_bytes()).hexdigest()
+
+    from breakfast_amd import _front
+
+    _front.preload(inp)
+    out_d, sha_d = run(tmp_path / "dev", True)
+    out_h, sha_h = run(tmp_path / "host", False)
+    assert out_d == out_h and sha_d == sha_h
+    assert out_d.count("Skipping invalid feature: ''") == 2
+    lines.append("bad\tA300T notatoken C400G")
+    inp.write_text("\n".join(lines) + "\n")
+    out_d, sha_d = run(tmp_path / "dev2", True)  # declined by the device stage: the host stages list the token
+    out_h, sha_h = run(tmp_path / "host2", False)
+    assert out_d == out_h and sha_d == sha_h and "Skipping invalid feature: 'notatoken'" in out_d
