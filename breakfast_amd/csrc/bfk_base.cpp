@@ -8,6 +8,8 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -108,7 +110,12 @@ int bfk_front_cluster(const int32_t *indptr, const int32_t *indices, int64_t n_r
 typedef int (*pipeline_fn)(bfk_table *, const char *, int64_t, const bfk_filter_opts *, int32_t, int32_t, const char *, bfk_prep_info *, int64_t *);
 extern "C" int bfk_table_pipeline_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                                          int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
+    const bool timing = getenv("BFK_FRONT_TIMING") && atoi(getenv("BFK_FRONT_TIMING")) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
     if (int rc = bfk_preload_wait()) return rc;
+    if (timing)
+        fprintf(stderr, "[bfk_dev] waited for the preload thread %8.2f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     pipeline_fn f = (pipeline_fn)dlsym(g_handle, "bfk_table_cluster_write_device");
     if (!f) return bfk_fail(BFK_ENODEV, g_path + " does not export bfk_table_cluster_write_device");
     return f(t, sep2, sep2_len, opts, max_dist, min_cluster_size, path, info_out, n_clusters_out);  // (errors: same thread, same bfk_last_error)

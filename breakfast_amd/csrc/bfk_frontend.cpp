@@ -493,7 +493,8 @@ struct StageTimer {
     void lap(const char *what) {
         if (!on) return;
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[bfk_front] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        fprintf(stderr, "[bfk_front] %-28s %8.2f ms   (at %.1f ms)\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e3 * (double)(long long)(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100) * 100);
         t0 = t1;
     }
 };

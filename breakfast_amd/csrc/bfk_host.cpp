@@ -6,6 +6,7 @@
 #include "bfk_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1782,6 +1783,20 @@ extern "C" int bfk_table_any_high(const bfk_table *t);
 extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
                                       const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len);
 
+// BFK_FRONT_TIMING=1: stage times of the device pipeline on stderr (like the host stages' StageTimer)
+struct DevTimer {
+    const bool on = getenv("BFK_FRONT_TIMING") && atoi(getenv("BFK_FRONT_TIMING")) != 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what, hipStream_t st = nullptr) {
+        if (!on) return;
+        if (st) (void)hipStreamSynchronize(st);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bfk_dev]   %-28s %8.2f ms   (at %.1f ms)\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e3 * (double)(long long)(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100) * 100);
+        t0 = t1;
+    }
+};
+
 struct PrepResult {
     int64_t n_rows = 0, n_unique = 0, nnz = 0, n_invalid = 0;
     int32_t n_vocab = 0;
@@ -1827,6 +1842,8 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
         }
         row_off[(size_t)n] = n_bytes;
     }
+    DevTimer tm;
+    tm.lap("prepare: spans");
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n + 1, 1.05)) return rc;
@@ -1849,15 +1866,20 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     int64_t slots = 1024;
     while (slots < 2 * n) slots <<= 1;
     if (int rc = dev_realloc(&c->pr_table, &c->pr_table_cap, slots)) return rc;
+    tm.lap("prepare: allocations");
     // the table's bytes from the first feature on, the rows' starts and lengths: one copy each; the caller's buffers are the
     // table's own (they outlive the call), the stream is waited for before the call returns
     HIP_TRY(hipMemcpyAsync(c->tk_rowoff, row_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->pr_spanlen, row_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    // (ONE copy from the table's pageable buffer, which the driver has never seen: 31 MB in 8-10 ms, 330 MB in 18-28 ms — it pins
+    // the pages on the way.  Slices copied by several host threads on streams of their own were 2-4x SLOWER: 44-84 ms at either
+    // size, a stream costs more to create than the pinning it would share.)
     HIP_TRY(hipMemcpyAsync(c->tk_text, bytes + base, (size_t)T, hipMemcpyHostToDevice, c->stream));
     struct StreamGuard {
         hipStream_t s;
         ~StreamGuard() { (void)hipStreamSynchronize(s); }
     } guard{c->stream};
+    tm.lap("prepare: H2D", c->stream);
     if (int e = launch_blank(c->tk_text, c->tk_rowoff, c->pr_spanlen, (int)n, base, (uint32_t)T, (uint8_t)sp, c->stream))
         return fail(BFK_EHIP, std::string("k_blank launch: ") + hipGetErrorString((hipError_t)e));
     bfk_ctx::TokPlan tp;
@@ -1876,6 +1898,7 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     tp.flt.upper = opts->reference_length - opts->trim_end;
     if (int rc = ctx_text_events(c)) return rc;
     if (int rc = ctx_tokenize(c, tp, nullptr, nullptr)) return rc;  // (the CSR of ALL rows is bound now)
+    tm.lap("prepare: tokenise + filter");
     if (c->tk_stats.n_invalid > 0)
         return fail(BFK_EUNSUPPORTED, "device prepare: tokens that match no pattern of the feature type (the host stage lists them in the reference's order)");
     // empty tokens are "invalid" for every grammar whose patterns do not match the empty string (:182-184)
@@ -1909,6 +1932,7 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     int h[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h, c->pr_small, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    tm.lap("prepare: collapse");
     if (h[2] & PREP_FAIL_COLLISION) return fail(BFK_EUNSUPPORTED, "device prepare: two different rows with one hash (the host stage collapses)");
     if (h[2]) return fail(BFK_EHIP, "device prepare: row table overflow");
     res->n_rows = n;
@@ -1960,10 +1984,13 @@ extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, in
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
+    DevTimer tm;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = ctx_enter(c)) return rc;
+    tm.lap("pipeline: context");
     PrepResult r;
     if (int rc = ctx_prepare_table(c, t, sep2, sep2_len, opts, &r)) return rc;
+    tm.lap("pipeline: prepare (above)");
     prep_info(r, info_out);
     std::vector<int32_t> group((size_t)r.n_rows), first((size_t)std::max<int64_t>(r.n_unique, 1)), labels((size_t)std::max<int64_t>(r.n_unique, 1));
     HIP_TRY(hipMemcpyAsync(group.data(), c->pr_group, (size_t)r.n_rows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1977,6 +2004,7 @@ extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, in
         HIP_TRY(hipMemcpyAsync(labels.data(), c->own_labels, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    tm.lap("pipeline: cluster + D2H");
     if (int rc = bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, nullptr, nullptr, sep2, sep2_len)) return rc;
     if (r.nnz <= 0) return BFK_OK;
     // a component counts the ORIGINAL sequences of its rows (:329-339); labels are the component's smallest row
@@ -1989,7 +2017,10 @@ extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, in
     }
     std::vector<int32_t> cl(nu, 0);
     for (size_t u = 0; u < nu; u++) cl[u] = size[(size_t)labels[u]] >= min_cluster_size ? labels[u] + 1 : 0;
-    return bfk_table_write(t, path, cl.data(), n_clusters_out);
+    tm.lap("pipeline: groups + sizes");
+    const int rc = bfk_table_write(t, path, cl.data(), n_clusters_out);
+    tm.lap("pipeline: writer");
+    return rc;
 }
 
 extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices, int64_t n_rows, int32_t max_dist,
