@@ -14,10 +14,15 @@ constexpr int VERIFY_GRID_MAX = 8192;   // blocks of k_verify (per-block statist
 constexpr int PF_LDS_QUEUE = 256;      // per-wave LDS coarse hit queue entries (2 KiB per wave)
 constexpr int PF_PAIR_LIST = 256;      // per-wave LDS list of exact pairs inside flush_hits (2 KiB per wave)
 constexpr int SIG_PAD_ROWS = 1024;     // signature arrays are padded so tile-rounded reads stay in bounds
-constexpr int VERIFY_TABLE = 256;       // hash-table slots per 16-lane group in k_verify (2 KiB of LDS)
-constexpr int VERIFY_MAX_TOKENS = 192;  // pairs with more tokens (both rows) go to k_verify_long
+// hash-table slots per 16-lane group of k_verify: 256 (2 KiB of LDS; 16 tables = 32 KiB per block) for rows of up to 96 tokens
+// (the instantiations with up to 6 register steps), 512 for the instantiations that serve longer rows — a pair of 100-token
+// rows, what present-day profiles look like, then still fits a group table instead of going to k_verify_long (a block per pair)
+__host__ __device__ constexpr int verify_table(int steps) { return steps >= 8 ? 512 : 256; }
+// pairs with more tokens (both rows) than 3/4 of the table: certificates here, the exact count in k_verify_long
+__host__ __device__ constexpr int verify_max_tokens(int steps) { return verify_table(steps) * 3 / 4; }
 constexpr int LONG_TABLE = 4096;        // hash-table slots in LDS per block of k_verify_long (32 KiB)
-constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long (each owns a slice of the global scratch table)
+constexpr int LONG_BLOCKS = 64;         // blocks of k_verify_long when a global scratch table is in use (each owns a slice of it)
+constexpr int LONG_BLOCKS_LDS = 1024;   // ... when every pair's table fits the block's LDS (4 blocks of 32 KiB per CU)
 constexpr unsigned long long JOIN_EMPTY = ~0ull;  // free slot of the variant-join table {tag : row}
 constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wave of k_join
 constexpr int JOIN_INLINE_ROW = 128;    // longest row k_join's own exact check takes (two tokens per lane); beyond: k_verify's queue
@@ -94,6 +99,7 @@ struct Plan {
     int4 *cand;
     int2 *candk;
     int2 *edges;  // NULL unless edge capture is on
+    const uint32_t *edge_sel;  // edge capture: a bit per row, only edges with a selected end are recorded (NULL: every edge)
     int *labels;
     Counters *ctr;
     unsigned long long *dbg_t;

@@ -97,6 +97,9 @@ struct bfk_ctx {
     int64_t cand_cap_total = 0, cand_cap_shard = 0;
     int2 *d_edges = nullptr;
     int64_t edge_cap = 0;
+    uint32_t *d_edge_sel = nullptr;  // edge capture restricted to edges with a selected end (bfk_neighbours_csr(select_ind)); NULL: all
+    int64_t edge_sel_cap = 0;
+    bool edge_sel_on = false;
     int *d_small = nullptr;  // 4 ints scratch (maxlen, err, ...)
     // variant join (max_dist == 1): [table 0 | table 1 | bitmap 0 | bitmap 1 | row hashes]
     char *d_join = nullptr;
@@ -246,7 +249,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
-                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_slots, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_slots, c->d_edge_sel, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
                     c->pr_uindptr, c->pr_small, c->pr_rowhash, c->pr_table, c->pr_val, c->pr_blk, c->pr_uindices};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1176,6 +1179,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
     pl.cand = c->d_cand;
     pl.candk = c->d_candk;
     pl.edges = c->edge_capture ? c->d_edges : nullptr;
+    pl.edge_sel = c->edge_capture && c->edge_sel_on ? c->d_edge_sel : nullptr;
     pl.labels = (int *)d_labels_out;
     pl.join = 0;
     if (allow_join && join_wanted(c, max_dist)) {
@@ -2028,11 +2032,27 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
                                   int32_t **nbr_indices_out) {
     if (n_rows < 0 || !indptr || !nbr_indptr_out || !nbr_indices_out || (select_ind == nullptr && n_select > 0))
         return fail(BFK_EARG, "bad arguments");
+    const int64_t nq = select_ind ? n_select : n_rows;
+    for (int64_t s = 0; s < nq && select_ind; s++)
+        if (select_ind[s] < 0 || select_ind[s] >= n_rows) return fail(BFK_EARG, "select_ind out of range");
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
     if (int rc = default_ctx(&c)) return rc;
     if (int rc = bfk_ctx_upload_csr(c, indptr, indices, n_rows)) return rc;
     if (int rc = ctx_own_labels(c, n_rows)) return rc;
+    // select_ind (the rows that are new against a cache, breakfast.py:241-245, :300-304): the kernels record only the edges
+    // with a selected end — a bit per row on the device — so what comes back, and what the lists below are built from, is
+    // proportional to the selected rows' neighbourhoods, not to the whole graph
+    std::vector<uint32_t> sel;
+    c->edge_sel_on = false;
+    if (select_ind && n_rows > 0) {
+        sel.assign((size_t)(n_rows + 31) / 32 + 1, 0u);
+        for (int64_t s = 0; s < nq; s++) sel[(size_t)(select_ind[s] >> 5)] |= 1u << (select_ind[s] & 31);
+        if (int rc = dev_realloc(&c->d_edge_sel, &c->edge_sel_cap, (int64_t)sel.size())) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_edge_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->edge_sel_on = true;
+    }
     void *d_labels = c->own_labels;
     int32_t *edges = nullptr;
     int64_t ne = 0;
@@ -2046,31 +2066,41 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
         if ((rc = ctx_size_cand(c, c->cand_cap_total * 4))) break;
     }
     bfk_ctx_set_edge_capture(c, 0);
+    c->edge_sel_on = false;
     if (rc) return rc;
-    // adjacency (both directions) + self, ascending
-    std::vector<int64_t> deg((size_t)n_rows + 1, 0);
-    for (int64_t e = 0; e < ne; e++) {
-        deg[(size_t)edges[2 * e] + 1]++;
-        deg[(size_t)edges[2 * e + 1] + 1]++;
+    // lists of the query rows (all rows, or the selected ones in the caller's order): neighbours in both directions + self,
+    // ascending.  slot[i] = first query position of row i (a row may be selected more than once: its list is copied)
+    std::vector<int32_t> slot((size_t)n_rows, -1);
+    std::vector<int64_t> qrow((size_t)nq);
+    int64_t n_lists = 0;
+    std::vector<int32_t> list_of((size_t)nq);  // query position -> list
+    for (int64_t s = 0; s < nq; s++) {
+        const int64_t i = select_ind ? select_ind[s] : s;
+        if (slot[(size_t)i] < 0) {
+            slot[(size_t)i] = (int32_t)n_lists;
+            qrow[(size_t)n_lists++] = i;
+        }
+        list_of[(size_t)s] = slot[(size_t)i];
     }
-    for (int64_t i = 0; i < n_rows; i++) deg[(size_t)i + 1] += deg[(size_t)i] + 1;  // +1: self
-    std::vector<int32_t> adj((size_t)deg[(size_t)n_rows]);
-    std::vector<int64_t> fill(deg.begin(), deg.end() - 1);
-    for (int64_t i = 0; i < n_rows; i++) adj[(size_t)fill[(size_t)i]++] = (int32_t)i;
+    std::vector<int64_t> deg((size_t)n_lists + 1, 0);
     for (int64_t e = 0; e < ne; e++) {
-        int32_t a = edges[2 * e], b = edges[2 * e + 1];
-        adj[(size_t)fill[(size_t)a]++] = b;
-        adj[(size_t)fill[(size_t)b]++] = a;
+        const int32_t a = edges[2 * e], b = edges[2 * e + 1];
+        if (slot[(size_t)a] >= 0) deg[(size_t)slot[(size_t)a] + 1]++;
+        if (slot[(size_t)b] >= 0) deg[(size_t)slot[(size_t)b] + 1]++;
+    }
+    for (int64_t l = 0; l < n_lists; l++) deg[(size_t)l + 1] += deg[(size_t)l] + 1;  // +1: self
+    std::vector<int32_t> adj((size_t)deg[(size_t)n_lists]);
+    std::vector<int64_t> fill(deg.begin(), deg.end() - 1);
+    for (int64_t l = 0; l < n_lists; l++) adj[(size_t)fill[(size_t)l]++] = (int32_t)qrow[(size_t)l];
+    for (int64_t e = 0; e < ne; e++) {
+        const int32_t a = edges[2 * e], b = edges[2 * e + 1];
+        if (slot[(size_t)a] >= 0) adj[(size_t)fill[(size_t)slot[(size_t)a]]++] = b;
+        if (slot[(size_t)b] >= 0) adj[(size_t)fill[(size_t)slot[(size_t)b]]++] = a;
     }
     free(edges);
-    for (int64_t i = 0; i < n_rows; i++) std::sort(adj.begin() + deg[(size_t)i], adj.begin() + deg[(size_t)i + 1]);
-    const int64_t nq = select_ind ? n_select : n_rows;
+    for (int64_t l = 0; l < n_lists; l++) std::sort(adj.begin() + deg[(size_t)l], adj.begin() + deg[(size_t)l + 1]);
     int64_t total = 0;
-    for (int64_t s = 0; s < nq; s++) {
-        int64_t i = select_ind ? select_ind[s] : s;
-        if (i < 0 || i >= n_rows) return fail(BFK_EARG, "select_ind out of range");
-        total += deg[(size_t)i + 1] - deg[(size_t)i];
-    }
+    for (int64_t s = 0; s < nq; s++) total += deg[(size_t)list_of[(size_t)s] + 1] - deg[(size_t)list_of[(size_t)s]];
     int64_t *op = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nq + 1));
     int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(1, total));
     if (!op || !oi) {
@@ -2080,9 +2110,8 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
     }
     op[0] = 0;
     for (int64_t s = 0; s < nq; s++) {
-        int64_t i = select_ind ? select_ind[s] : s;
-        int64_t len = deg[(size_t)i + 1] - deg[(size_t)i];
-        memcpy(oi + op[s], adj.data() + deg[(size_t)i], sizeof(int32_t) * (size_t)len);
+        const int64_t l = list_of[(size_t)s], len = deg[(size_t)l + 1] - deg[(size_t)l];
+        memcpy(oi + op[s], adj.data() + deg[(size_t)l], sizeof(int32_t) * (size_t)len);
         op[s + 1] = op[s] + len;
     }
     *nbr_indptr_out = op;

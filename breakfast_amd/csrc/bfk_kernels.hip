@@ -555,6 +555,8 @@ struct PairArgs {
     int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
     int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
     int skip_connected;              // labels-only step: candidates whose rows are in one tree already are dropped unchecked
+    int max_tokens;                  // tokens (both rows) whose exact count fits a group table of the k_verify instantiation that runs
+    const uint32_t *sel;             // edge capture: a bit per row — only edges with a selected end are recorded (NULL: all)
     Counters *ctr;
 };
 
@@ -971,6 +973,9 @@ __device__ __forceinline__ void table_add(uint32_t *tkey, int *tcnt, uint32_t ma
 }
 
 __device__ __forceinline__ void record_edge(const PairArgs &pa, int2 *edges, int edge_cap, int a, int b) {
+    // (select_ind of get_neighbours_batch, breakfast.py:241-245: only the lists of the selected rows are wanted — an edge
+    // between two rows that are not selected is in none of them)
+    if (pa.sel && !(((pa.sel[a >> 5] >> (a & 31)) | (pa.sel[b >> 5] >> (b & 31))) & 1u)) return;
     const unsigned long long e = atomicAdd(&pa.ctr->n_edges_cap, 1ull);
     if (e < (unsigned long long)edge_cap) edges[e] = make_int2(min(a, b), max(a, b));
 }
@@ -1017,10 +1022,10 @@ __device__ __forceinline__ int row16_allsum(int x) {
 template <int STEPS, bool UNROLL>
 __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t (&a)[STEPS], const uint32_t (&b0)[STEPS],
                                               int ka, int kb) {
-    // table size: power of two >= 2 * tokens (load <= 1/2), capped at VERIFY_TABLE (load <= 3/4)
+    // table size: power of two >= 2 * tokens (load <= 1/2), capped at the group's table (load <= 3/4)
     const int kt = ka + kb;
     uint32_t tsz = 16;
-    while ((int)tsz < 2 * kt && tsz < VERIFY_TABLE) tsz <<= 1;
+    while ((int)tsz < 2 * kt && tsz < (uint32_t)verify_table(STEPS)) tsz <<= 1;
     const uint32_t mask = tsz - 1;
     for (uint32_t t = l16; t < tsz; t += 16) mt[t] = make_uint2(0xFFFFFFFFu, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1066,10 +1071,14 @@ __device__ __forceinline__ int table_distance(uint2 *mt, int l16, const uint32_t
 }
 
 // The exact test of one candidate by the 16 lanes of a group: is the multiset distance of rows rec.x and rec.y (tokens at
-// rows + rec.z / rec.w, lengths kk) within pa.d?  Group-uniform result; false for pairs with more than VERIFY_MAX_TOKENS
-// tokens (k_verify_long takes those).  With WAVE_TABLE all four groups of the wave must call it together.
+// rows + rec.z / rec.w, lengths kk) within pa.d?  Group-uniform result: 1 edge, 0 not an edge, -1 UNDECIDED — a pair with more
+// than VERIFY_MAX_TOKENS tokens (its exact count does not fit a group table) that the certificates do not settle:
+// k_verify_long takes it.  (Round 4: the certificates need no table, so pairs of long rows — 100+ tokens each, what a
+// present-day SARS-CoV-2 profile against the Wuhan reference looks like — are tried here first as long as both rows fit the
+// registers; before, every such pair went to k_verify_long, a block per pair: 2.5 ms for 68k candidates at 100k rows.)
+// With WAVE_TABLE all four groups of the wave must call it together.
 template <int STEPS, bool WAVE_TABLE>
-__device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int lane, int l16, const int4 &rec, const int2 &kk) {
+__device__ __forceinline__ int verify_pair(const PairArgs &pa, uint2 *mt, int lane, int l16, const int4 &rec, const int2 &kk) {
     // lane l16 of the group holds, per step st, position j = 16 st + l16 of row A, of row B, and of row B
     // shifted by the length difference s = k_b - k_a
     auto tokens = [&](uint32_t(&a)[STEPS], uint32_t(&b0)[STEPS], uint32_t(&bs)[STEPS]) {
@@ -1087,8 +1096,9 @@ __device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int l
     uint32_t a[STEPS], b0[STEPS], bs[STEPS];
     tokens(a, b0, bs);
     const int ka = kk.x, kb = kk.y, kt = ka + kb;
-    bool is_edge = false;
-    if (kt <= VERIFY_MAX_TOKENS) {  // longer pairs: k_verify_long
+    const bool small = kt <= verify_max_tokens(STEPS);  // the exact count fits a group table
+    int verdict = -1;
+    if (small || max(ka, kb) <= 16 * STEPS) {  // (both rows are in the registers in full)
         // Certificate first.  Profiles list their mutations in a fixed order (by genome position), so two
         // rows within d of each other are almost always the same sequence with a few tokens inserted: with
         // t = first position where the rows differ and s = k_b - k_a, the pairs (i, i) for i < t and
@@ -1112,14 +1122,14 @@ __device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int l
         int dist = kt - 2 * matched;  // upper bound
         // not certified: count exactly
         if (WAVE_TABLE) {  // the wave's groups that need the table take turns
-            unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d);
+            unsigned long long want = __builtin_amdgcn_ballot_w64(dist > pa.d && small);
             while (want != 0ull) {
                 const int g = (int)(__builtin_ctzll(want) >> 4);
                 if ((lane >> 4) == g) dist = table_distance<STEPS, false>(mt, l16, a, b0, ka, kb);
                 want &= ~(0xFFFFull << (g * 16));
             }
         } else if (dist > pa.d && pa.d > 3) {
-            dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
+            if (small) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
         } else if (dist > pa.d) {
             // Second certificate (d = 2, 3; with more edits allowed it rarely holds and only costs): pairs with two separate edits — e.g. one token inserted near
             // the front and one near the end — match under shift 0 before the first edit, under shift s
@@ -1148,11 +1158,11 @@ __device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int l
             }
             const int matched2 = t + max(row16_allsum(cm), row16_allsum(cp)) + (ka - 1 - r);
             dist = min(dist, kt - 2 * matched2);
-            if (dist > pa.d) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
+            if (dist > pa.d && small) dist = table_distance<STEPS, true>(mt, l16, a, b0, ka, kb);  // exact
         }
-        is_edge = dist <= pa.d;
+        verdict = dist <= pa.d ? 1 : (small ? 0 : -1);  // (without the exact count a bound above d decides nothing)
     }
-    return is_edge;
+    return verdict;
 }
 
 // STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
@@ -1162,8 +1172,8 @@ __device__ __forceinline__ bool verify_pair(const PairArgs &pa, uint2 *mt, int l
 // separate insertions fail the single-shift certificate).
 template <int STEPS, bool WAVE_TABLE>
 __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int edge_cap, int *blk_stats) {
-    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}: exactly 32 KiB per block with group tables,
-                                                              // five blocks per CU (the block's two counters live in it at the end)
+    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][verify_table(STEPS)];  // {token, signed count}: exactly 32 KiB per block with group tables of
+                                                                     // 256 slots, five blocks per CU (the block's two counters live in it at the end)
     const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;  // 0..15 in the block
     uint2 *mt = tab[WAVE_TABLE ? (threadIdx.x >> 6) : grp];
@@ -1206,7 +1216,9 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
             const int e2 = min(e + 2 * jstep, last);
             const int4 rec_nn = pa.cand[base + e2];
             const int2 kk_nn = pa.candk[base + e2];
-            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, rec, kk);
+            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, rec, kk) == 1;
+            // a pair k_verify_long would take (too many tokens for a group table) that is settled here: out of its way
+            if (is_edge && l16 == 0 && kk.x + kk.y > verify_max_tokens(STEPS)) pa.candk[base + e] = make_int2(0, 0);
             if (is_edge) {  // group-uniform
                 if (l16 == (nkept & ubm)) {
                     my_a = rec.x;
@@ -1255,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
 // depend on which edges were used.
 template <int STEPS, bool WAVE_TABLE>
 __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_stats) {
-    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][VERIFY_TABLE];  // {token, signed count}
+    __shared__ uint2 tab[WAVE_TABLE ? 4 : 16][verify_table(STEPS)];  // {token, signed count}
     __shared__ int4 s_rec[4][64];                              // the round's survivors of each wave
     __shared__ int2 s_kk[4][64];
     __shared__ unsigned int blk_edges, blk_cands, blk_conn;
@@ -1288,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     struct Slot {
         int4 rec;
         int2 kk;
-        int p0, p1;
+        int p0, p1, e;
         bool have, more;
     };
     auto next_slot = [&]() {  // the next piece of the group's records; its queue record is requested
@@ -1306,6 +1318,7 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
         sl.rec = make_int4(0, 0, 0, 0);
         sl.kk = make_int2(0, 0);
         sl.p0 = sl.p1 = 0;
+        sl.e = e;
         if (sl.have) {
             sl.rec = pa.cand[base + e];
             sl.kk = pa.candk[base + e];
@@ -1313,8 +1326,9 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
         return sl;
     };
     auto ask_parents = [&](Slot &sl) {
-        // (pairs longer than a group table are k_verify_long's, which looks their roots up itself)
-        sl.have = sl.have && sl.kk.x + sl.kk.y <= VERIFY_MAX_TOKENS;
+        // (pairs whose rows do not fit the registers are k_verify_long's, which looks their roots up itself; those with too many
+        // tokens for a group table are looked up and tried by the certificates here — what that settles is taken out of its way)
+        sl.have = sl.have && (sl.kk.x + sl.kk.y <= verify_max_tokens(STEPS) || max(sl.kk.x, sl.kk.y) <= 16 * STEPS);
         if (sl.have) {
             sl.p0 = ld_agent(pa.parent + sl.rec.x);
             sl.p1 = ld_agent(pa.parent + sl.rec.y);
@@ -1349,12 +1363,14 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
             const bool valid = i + gw < ns;
             const int4 r = valid ? s_rec[wave][i + gw] : make_int4(0, 0, 0, 0);
             const int2 k = valid ? s_kk[wave][i + gw] : make_int2(0, 0);
-            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, r, k) && valid;
+            const bool is_edge = verify_pair<STEPS, WAVE_TABLE>(pa, mt, lane, l16, r, k) == 1 && valid;
             const unsigned long long b = __builtin_amdgcn_ballot_w64(is_edge);
             em |= ((b & 1ull) | ((b >> 15) & 2ull) | ((b >> 30) & 4ull) | ((b >> 45) & 8ull)) << i;
         }
         __builtin_amdgcn_wave_barrier();
         n_edges += (unsigned)__popcll(em);
+        if (cur.have && kk.x + kk.y > verify_max_tokens(STEPS) && (conn || (todo && ((em >> rank) & 1ull))))
+            pa.candk[base + cur.e] = make_int2(0, 0);  // settled here: nothing left for k_verify_long
         if (todo && ((em >> rank) & 1ull)) {  // one edge per lane: the chains of the wave's edges overlap
             if (pa.use_link == 1) uf_link(pa.parent, rec.x, rec.y); else if (pa.use_link == 2) uf_link_checked(pa.parent, rec.x, rec.y); else uf_union(pa.parent, rec.x, rec.y);
         }
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_verify_long(PairArgs pa, uint32_t *gkey
         const size_t slot = shard_slot(spre, pa, c);
         const int2 kk = pa.candk[slot];
         const int ka = kk.x, kb = kk.y, kt = ka + kb;
-        if (kt <= VERIFY_MAX_TOKENS) continue;  // done by k_verify
+        if (kt <= pa.max_tokens) continue;  // done by k_verify (its group tables hold that many)
         int4 rec = pa.cand[slot];
         if (rec.w < 0) rec.w = pa.indptr[rec.y];  // (k_pgwalk16)
         if (pa.skip_connected) {  // one thread decides for the block (trees merge while the block looks)
@@ -2915,6 +2931,7 @@ static PairArgs make_pair_args(const Plan &pl) {
     // redundant there and find + hook ends them with two loads (equal parents), splicing walks up with atomics
     pa.use_link = pl.d <= 2 ? 1 : 0;
     if (const char *e = getenv("BFK_UF_LINK")) pa.use_link = atoi(e) != 0;
+    pa.sel = pl.edges ? pl.edge_sel : nullptr;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
     pa.candk = pl.candk;
@@ -2924,10 +2941,15 @@ static PairArgs make_pair_args(const Plan &pl) {
     return pa;
 }
 
+// the STEPS instantiation that serves rows of `steps` 16-token steps
+static int verify_steps(int steps) { return steps <= 3 ? 3 : steps <= 4 ? 4 : steps <= 5 ? 5 : steps <= 6 ? 6 : steps <= 8 ? 8 : steps <= 12 ? 12 : 16; }
+
 // exact check + union of everything in the candidate queue
-static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, hipEvent_t *ev) {
+static int launch_verify(const Plan &pl, const PairArgs &pa_in0, hipStream_t st, hipEvent_t *ev) {
     // 16-token steps covering the longest row a pair of k_verify can have
-    const int steps = (std::min(pl.kcap, VERIFY_MAX_TOKENS - 1) + 15) / 16;
+    const int steps = (std::min(pl.kcap, 16 * 16) + 15) / 16;  // (rows of up to 256 tokens in the registers; longer ones: k_verify_long)
+    PairArgs pa_in = pa_in0;
+    pa_in.max_tokens = verify_max_tokens(verify_steps(steps));
     auto one = [&](const PairArgs &pa) {
 #define VF_CASE(S)                                                                                                        \
     if (pa.skip_connected && pl.d <= pl.wave_table_d)                                                                     \
@@ -2945,7 +2967,8 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
         else if (steps <= 5) { VF_CASE(5); }
         else if (steps <= 6) { VF_CASE(6); }
         else if (steps <= 8) { VF_CASE(8); }
-        else { VF_CASE(12); }
+        else if (steps <= 12) { VF_CASE(12); }
+        else { VF_CASE(16); }
 #undef VF_CASE
     };
     const PairArgs &pa = pa_in;
@@ -2971,9 +2994,10 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in, hipStream_t st, 
         one(pa);
     }
     LAUNCH_CHECK();
-    if (2 * pl.kcap > VERIFY_MAX_TOKENS) {  // some pair may exceed a group table
-        hipLaunchKernelGGL(k_verify_long, dim3(LONG_BLOCKS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey, pl.gcnt,
-                           pl.gslots, pl.edges, pl.edge_cap);
+    if (2 * pl.kcap > verify_max_tokens(verify_steps(steps))) {  // some pair may exceed a group table
+        // (a block per pair; with a global scratch table — rows of thousands of tokens — only LONG_BLOCKS slices of it exist)
+        hipLaunchKernelGGL(k_verify_long, dim3(pl.gslots ? LONG_BLOCKS : LONG_BLOCKS_LDS), dim3(256), (size_t)LONG_TABLE * 8, st, pa, pl.gkey,
+                           pl.gcnt, pl.gslots, pl.edges, pl.edge_cap);
         LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[3], st);

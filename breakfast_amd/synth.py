@@ -55,6 +55,76 @@ def generate_profiles(
     return [" ".join(p[k] for k in sorted(p)) for p in profiles]
 
 
+# ---- other workload shapes (round 4): the dispatch thresholds of libbfk were fitted on generate_profiles() alone ------------
+# Each family keeps the tree process and changes what the thresholds could be sensitive to: the row length, the shape of the
+# phylogeny, the tokens' byte shape.  tools/family_matrix.py times every candidate generator on them
+# (profiles/r04_family_matrix.txt); tests/test_gpu_parity.py compares each with the oracle.
+AA_GENES = ["S", "N", "M", "E", "ORF1a", "ORF1b", "ORF3a", "ORF6", "ORF7a", "ORF7b", "ORF8", "ORF9b"]
+AA_LETTERS = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def generate_family(family: str, n: int, seed: int = DEFAULT_SEED) -> list[str]:
+    """`long`: 75-mutation root, 1 + Poisson(1.5) new mutations per generation, indels kept — rows of 100+ tokens (beyond the
+    128 tokens the variant join decides by itself).  `star`: ten hub profiles; 6 % of all rows are a hub plus ONE mutation
+    (a hub row has thousands of neighbours at distance 1), the others grow a tree as usual.  `aa`: amino-acid tokens
+    (S:N501Y, ORF1a:T3255I, S:H69-: 7-13 bytes, most of them over the 7 bytes a vocabulary slot holds inline), 30-token root."""
+    if family == "long":
+        return generate_profiles(n, seed=seed, root_k=75, lam=1.5, p_del=0.05, p_ins=0.01)
+    rng = np.random.default_rng(seed)
+    if family == "star":
+        base = generate_profiles(max(n // 10, 50), seed=seed + 1)
+        hubs = [base[i] for i in rng.choice(len(base), size=10, replace=False)]
+        refg = rng.integers(0, 4, size=29904)
+
+        def newmut():
+            pos = int(rng.integers(265, 29675))
+            ref = int(refg[pos])
+            return pos, f"{BASES[ref]}{pos}{BASES[(ref + int(rng.integers(1, 4))) % 4]}"
+
+        def parse(row):
+            return {int(t[1:-1]): t for t in row.split(" ")} if row else {}
+
+        profiles = [parse(h) for h in hubs]
+        hubs_d = list(profiles)
+        while len(profiles) < n:
+            if rng.random() < 0.06:
+                prof = dict(hubs_d[int(rng.integers(0, len(hubs_d)))])
+                k = 1
+            else:
+                prof = dict(profiles[int(rng.integers(0, len(profiles)))])
+                k = 1 + int(rng.poisson(0.4))
+            for _ in range(k):
+                pos, tok = newmut()
+                prof[pos] = tok
+            profiles.append(prof)
+        return [" ".join(p[k] for k in sorted(p)) for p in profiles[:n]]
+    if family == "aa":
+        lengths = {g: int(rng.integers(60, 4400)) for g in AA_GENES}
+
+        def newmut():
+            g = AA_GENES[int(rng.integers(0, len(AA_GENES)))]
+            pos = int(rng.integers(1, lengths[g]))
+            a = AA_LETTERS[int(rng.integers(0, 20))]
+            r = rng.random()
+            b = "-" if r < 0.05 else ("*" if r < 0.06 else AA_LETTERS[int(rng.integers(0, 20))])
+            return (AA_GENES.index(g), pos), f"{g}:{a}{pos}{b}"
+
+        profiles = []
+        root = {}
+        for _ in range(30):
+            key, tok = newmut()
+            root[key] = tok
+        profiles.append(root)
+        for i in range(1, n):
+            prof = dict(profiles[int(rng.integers(0, i))])
+            for _ in range(1 + int(rng.poisson(0.4))):
+                key, tok = newmut()
+                prof[key] = tok
+            profiles.append(prof)
+        return [" ".join(p[k] for k in sorted(p)) for p in profiles]
+    raise ValueError(f"unknown family {family!r}")
+
+
 def generate_tsv(path, n: int, **kw) -> None:
     """Write ``accession\\tdna_profile`` TSV (LF line ends, ids ``seq%07d``)."""
     rows = generate_profiles(n, **kw)

@@ -772,6 +772,32 @@ def fuzz_case(rng):
     return rows, indptr, indices, d, alphabet
 
 
+@pytest.mark.parametrize("d,indels,path", [(1, False, "auto"), (1, True, "allpairs"), (2, True, "auto"), (5, True, "prefix")])
+def test_neighbours_of_selected_rows_equal_the_full_lists(d, indels, path, monkeypatch):
+    """bfk_neighbours_csr(select_ind): the kernels record only edges with a selected end (a bit per row on the device) and
+    the lists are built for the selected rows alone — each equal to the row's list of the full call, in the caller's order,
+    for sorted, unsorted and repeated selections, on every candidate generator (get_neighbours_batch's select_ind,
+    breakfast.py:241-245)"""
+    kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
+    rows = list(dict.fromkeys(generate_profiles(12000, **kw)))
+    indptr, indices, _ = _lib.build_csr(rows, " ")
+    if path == "allpairs":
+        monkeypatch.setenv("BFK_JOIN", "0")
+    if path == "prefix":
+        monkeypatch.setenv("BFK_PG", "1")
+    full_ptr, full_idx = _lib.neighbours_csr(indptr, indices, d)
+    full = [full_idx[full_ptr[i]: full_ptr[i + 1]] for i in range(len(rows))]
+    assert sum(len(x) for x in full) > 2 * len(rows)
+    rng = np.random.default_rng(d)
+    for sel in (np.sort(rng.choice(len(rows), 1200, replace=False)), rng.choice(len(rows), 500, replace=True),
+                np.array([len(rows) - 1, 0, 0, 7]), np.zeros(0, np.int64), np.arange(len(rows))[::-1].copy()):
+        sel = sel.astype(np.int64)
+        ptr, idx = _lib.neighbours_csr(indptr, indices, d, sel)
+        assert len(ptr) == len(sel) + 1
+        for s, i in enumerate(sel.tolist()):
+            assert np.array_equal(idx[ptr[s]: ptr[s + 1]], full[i]), (s, i)
+
+
 @pytest.mark.exact_edges
 @pytest.mark.parametrize("generator", ["band", "prefix", "prefix_pos"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
@@ -927,6 +953,39 @@ def oracle_labels_indel(n, d):
         indptr, indices, _ = _lib.build_csr(uf, " ")
         _ORACLE_LABELS[(n, d)] = orc.cluster_csr(indptr, indices, d, n_threads=16)["labels"]
     return _ORACLE_LABELS[(n, d)]
+
+
+@pytest.mark.parametrize("family,d", [("long", 1), ("long", 3), ("star", 1), ("star", 2), ("star", 5), ("aa", 1), ("aa", 3)])
+def test_other_workload_families_equal_the_oracle_at_20k_rows(family, d):
+    """workload shapes the dispatch thresholds were not fitted on (breakfast_amd/synth.py: generate_family — rows of 100+
+    tokens, a star phylogeny whose hubs have thousands of neighbours, amino-acid tokens): the default configuration and every
+    forced candidate generator against the FULL oracle at 20k rows; tools/family_matrix.py times them"""
+    from breakfast_amd.synth import generate_family
+
+    uf = list(dict.fromkeys(generate_family(family, 20000)))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    want = orc.cluster_csr(indptr, indices, d, n_threads=16)["labels"]
+    labels, st = _lib.cluster_csr(indptr, indices, d)
+    assert np.array_equal(labels, want)
+    assert st["n_retry_slices"] == 0
+    for path in ("allpairs", "join" if d == 1 else "prefix"):
+        ctx = _lib.Context(0)
+        ctx.set_candidate_path(path)
+        ctx.set_exact_edges(True)
+        ctx.upload_csr(indptr, indices)
+        d_out = ctx.alloc(4 * len(uf))
+        ctx.cluster(d, d_out)
+        st2 = ctx.sync()
+        assert np.array_equal(ctx.download_i32(d_out, len(uf)), want), path
+        if path == "allpairs":
+            n_edges = st2["n_edges"]
+        else:
+            assert st2["n_edges"] == n_edges  # every generator finds the same edge set
+        ctx.close()
+    # the text entry on the same rows (long rows: a device-driven step redone by the host; aa: tokens beyond the inline key)
+    buf, off = _lib.pack_rows(uf)
+    lab_t, _, nnz, _ = _lib.cluster_text(buf, off, " ", d)
+    assert nnz == len(indices) and np.array_equal(lab_t, want)
 
 
 @pytest.mark.parametrize("d", [3, 5])
