@@ -83,6 +83,8 @@ struct Plan {
     int verify_phases, verify_phase2_union;  // > 1: two-phase verify (first 1/phases of every shard, compress, the rest)
     int skip_connected;  // labels-only step: k_verify_connected drops candidates whose rows are connected already
     int verify_grid, wave_table_d;  // k_verify: per-wave hash table up to this max_dist, per-group tables beyond
+    int verify_adaptive, verify_grid2;  // max_dist 2, labels only: k_verify AND k_verify_connected (grid2) are launched, the queue's
+    long long verify_density_thr;       // fill against this many candidates decides on the device which of them works
     int tile_cap, tile_hint, pf_blocks, pf_waves, cand_cap_shard, edge_cap, dbg;
     unsigned gslots;  // slots per block of the global scratch table of k_verify_long (0 = none)
     const int *indptr;

@@ -944,8 +944,13 @@ static bool join_wanted(const bfk_ctx *c, int max_dist) {
     if (c->path_mode) return c->path_mode == 2;
     if (const char *e = getenv("BFK_JOIN")) return atoi(e) != 0;
     // measured (ms per step, join vs all-pairs): 100k rows 0.061 / 0.074, 300k 0.153 / 0.172, 600k 0.325 / 0.360,
-    // 1M 0.537 / 0.505 — both grow about linearly there, the join's cost is the instruction stream per row
-    return c->n <= 800000;
+    // 1M 0.537 / 0.505 — both grow about linearly there, the join's cost is the instruction stream per row.
+    // Round 4, other workload shapes at 1M rows (profiles/r04_family_matrix.txt), join / all-pairs: default 0.480 / 0.475,
+    // amino-acid tokens 0.511 / 0.486, rows of ~110 tokens 1.04 / 0.59 (the join's lookups are per token), a star phylogeny
+    // 0.51 / 1.47 (the hubs' neighbours fill a few cells of the band kernels' sort key: tiles of thousands of rows).  Hence the
+    // join beyond 800k rows too while rows are short — it never loses much there and is the one the hubs do not hurt.
+    if (c->n <= 800000) return true;
+    return c->n <= 1200000 && c->nnz <= 64 * c->n;
 }
 
 static int ctx_size_join(bfk_ctx *c) {
@@ -1117,6 +1122,15 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         // was 0.93 ms against 1.05 (2048 blocks) / 1.09 (8192) at 1M rows, max_dist 5
         if (pl.skip_connected && !getenv("BFK_VERIFY_GRID")) pl.verify_grid = std::min(VERIFY_GRID_MAX, c->n_cus * 4);
     }
+    {   // max_dist 2, labels only: sparse or dense is decided on the device from the candidate queue's fill (launch_verify)
+        int exact = 0;
+        if (const char *e = getenv("BFK_EXACT_EDGES")) exact = atoi(e) != 0;
+        if (c->exact_edges >= 0) exact = c->exact_edges;
+        pl.verify_adaptive = max_dist == 2 && !exact && !c->edge_capture && !getenv("BFK_SKIP_CONNECTED") && !getenv("BFK_VERIFY_PHASES");
+        if (const char *e = getenv("BFK_VERIFY_ADAPTIVE")) pl.verify_adaptive = pl.verify_adaptive && atoi(e) != 0;
+        pl.verify_grid2 = std::min(VERIFY_GRID_MAX, c->n_cus * 4);
+        pl.verify_density_thr = 8 * (long long)c->n;
+    }
     // (with the pruning kernel one phase is better: 100k rows d = 3: 0.217 / 0.241 ms, d = 4: 0.262 / 0.271, 300k d = 4: 0.431 / 0.479)
     pl.verify_phases = ((max_dist == 3 || max_dist == 4) && c->n < 400000 && !pl.skip_connected) ? 8 : 1;
     pl.verify_phase2_union = 0;
@@ -1285,7 +1299,9 @@ extern "C" int bfk_ctx_merge_labels(bfk_ctx *c, const void *d_gathered, int32_t 
 // k_verify leaves its per-block edge / candidate counts in plain stores (no same-word atomics): add them to
 // the counters read back from the device (n_edges already holds the edges of the long-pair kernel)
 static int ctx_pair_stats(bfk_ctx *c, Counters *h) {
-    std::vector<int> v((size_t)2 * c->plan.verify_grid * (c->plan.verify_phases > 1 ? 2 : 1));
+    std::vector<int> v(c->plan.verify_adaptive && c->plan.verify_phases <= 1 && !c->plan.join
+                           ? (size_t)2 * c->plan.verify_grid + (size_t)2 * c->plan.verify_grid2
+                           : (size_t)2 * c->plan.verify_grid * (c->plan.verify_phases > 1 ? 2 : 1));
     if (c->plan.join && c->plan.join_skip_verify) v.clear();  // k_verify did not run: its counts are another step's
     if (!v.empty()) HIP_TRY(hipMemcpy(v.data(), c->d_blk_stats, v.size() * 4, hipMemcpyDeviceToHost));
     unsigned long long e = 0, k = 0;

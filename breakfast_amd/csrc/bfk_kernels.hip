@@ -555,6 +555,11 @@ struct PairArgs {
     int part_lo, part_hi, part_den;  // k_verify works on entries [cnt * lo / den, cnt * hi / den) of every queue shard
     int stats_off;                   // ... and leaves its per-block counts at blk_stats + stats_off
     int skip_connected;              // labels-only step: candidates whose rows are in one tree already are dropped unchecked
+    int density_mode;                // 0: the kernel runs.  max_dist 2, labels only: BOTH verify kernels are launched and the queue's fill
+    long long density_thr;           // decides which of them works — 1: only when it holds at most density_thr candidates (k_verify: a
+                                     // sparse forest, nearly every candidate joins two trees), 2: only when it holds more
+                                     // (k_verify_connected: hubs with thousands of neighbours make the graph dense, most candidates are
+                                     // between rows that are connected already)
     int max_tokens;                  // tokens (both rows) whose exact count fits a group table of the k_verify instantiation that runs
     const uint32_t *sel;             // edge capture: a bit per row — only edges with a selected end are recorded (NULL: all)
     Counters *ctr;
@@ -1165,6 +1170,21 @@ __device__ __forceinline__ int verify_pair(const PairArgs &pa, uint2 *mt, int la
     return verdict;
 }
 
+// density-adaptive verify (PairArgs::density_mode): does this kernel sit the step out?  Block-uniform; one barrier.
+__device__ __forceinline__ bool verify_sits_out(const PairArgs &pa) {
+    __shared__ unsigned long long s_total;
+    if (!pa.density_mode) return false;
+    if (threadIdx.x < 64) {
+        unsigned long long t = 0;
+        for (int sh = threadIdx.x; sh < CAND_SHARDS; sh += 64) t += min(pa.ctr->ncand[sh], (unsigned)pa.cand_cap_shard);
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (threadIdx.x == 0) s_total = t;
+    }
+    __syncthreads();
+    const bool dense = s_total > (unsigned long long)pa.density_thr;
+    return (pa.density_mode == 1) == dense;
+}
+
 // STEPS x 16 >= longest row a pair of this kernel can have (pairs with more than VERIFY_MAX_TOKENS tokens in
 // all are left to k_verify_long).  WAVE_TABLE: one hash table per wave, its groups take turns (d <= 1: nearly
 // every candidate is certified without the table, and 8 KiB of LDS per block keeps 6+ blocks per CU resident);
@@ -1177,6 +1197,10 @@ __global__ __launch_bounds__(256) void k_verify(PairArgs pa, int2 *edges, int ed
     const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;  // 0..15 in the block
     uint2 *mt = tab[WAVE_TABLE ? (threadIdx.x >> 6) : grp];
+    if (verify_sits_out(pa)) {  // (the other verify kernel of the step takes the queue)
+        if (threadIdx.x == 0) blk_stats[pa.stats_off + 2 * blockIdx.x] = blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = 0;
+        return;
+    }
     // Group u of U (a multiple of CAND_SHARDS) works on queue shard u % CAND_SHARDS, entries j0, j0 + jstep, ..:
     // the slot is computed, not searched, and the shards fill evenly (the prefilter rotates over them).
     const int u = blockIdx.x * 16 + grp, U = gridDim.x * 16;
@@ -1275,6 +1299,10 @@ __global__ __launch_bounds__(256) void k_verify_connected(PairArgs pa, int *blk_
     const int grp = threadIdx.x >> 4;  // 0..15 in the block
     const int wave = threadIdx.x >> 6, gw = (threadIdx.x >> 4) & 3;
     uint2 *mt = tab[WAVE_TABLE ? wave : grp];
+    if (verify_sits_out(pa)) {  // (the other verify kernel of the step takes the queue)
+        if (threadIdx.x == 0) blk_stats[pa.stats_off + 2 * blockIdx.x] = blk_stats[pa.stats_off + 2 * blockIdx.x + 1] = 0;
+        return;
+    }
     if (threadIdx.x == 0) blk_edges = blk_cands = blk_conn = 0;
     __syncthreads();
     // the same map of groups to queue entries as k_verify: group u works on shard u % CAND_SHARDS, entries j0, j0 + jstep, ..
@@ -2932,6 +2960,8 @@ static PairArgs make_pair_args(const Plan &pl) {
     pa.use_link = pl.d <= 2 ? 1 : 0;
     if (const char *e = getenv("BFK_UF_LINK")) pa.use_link = atoi(e) != 0;
     pa.sel = pl.edges ? pl.edge_sel : nullptr;
+    pa.density_mode = 0;
+    pa.density_thr = 0;
     pa.parent = pl.parent;
     pa.cand = pl.cand;
     pa.candk = pl.candk;
@@ -2950,17 +2980,17 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in0, hipStream_t st,
     const int steps = (std::min(pl.kcap, 16 * 16) + 15) / 16;  // (rows of up to 256 tokens in the registers; longer ones: k_verify_long)
     PairArgs pa_in = pa_in0;
     pa_in.max_tokens = verify_max_tokens(verify_steps(steps));
-    auto one = [&](const PairArgs &pa) {
+    auto one = [&](const PairArgs &pa, int grid) {
 #define VF_CASE(S)                                                                                                        \
     if (pa.skip_connected && pl.d <= pl.wave_table_d)                                                                     \
-        hipLaunchKernelGGL((k_verify_connected<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.blk_stats);      \
+        hipLaunchKernelGGL((k_verify_connected<S, true>), dim3(grid), dim3(256), 0, st, pa, pl.blk_stats);                \
     else if (pa.skip_connected)                                                                                           \
-        hipLaunchKernelGGL((k_verify_connected<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.blk_stats);     \
+        hipLaunchKernelGGL((k_verify_connected<S, false>), dim3(grid), dim3(256), 0, st, pa, pl.blk_stats);               \
     else if (pl.d <= pl.wave_table_d)                                                                                     \
-        hipLaunchKernelGGL((k_verify<S, true>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,        \
+        hipLaunchKernelGGL((k_verify<S, true>), dim3(grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,                  \
                            pl.blk_stats);                                                                                 \
     else                                                                                                                  \
-        hipLaunchKernelGGL((k_verify<S, false>), dim3(pl.verify_grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,       \
+        hipLaunchKernelGGL((k_verify<S, false>), dim3(grid), dim3(256), 0, st, pa, pl.edges, pl.edge_cap,                 \
                            pl.blk_stats)
         if (steps <= 3) { VF_CASE(3); }
         else if (steps <= 4) { VF_CASE(4); }
@@ -2985,13 +3015,28 @@ static int launch_verify(const Plan &pl, const PairArgs &pa_in0, hipStream_t st,
         b.part_hi = b.part_den = pl.verify_phases;
         b.use_link = pl.verify_phase2_union;
         b.stats_off = 2 * pl.verify_grid;
-        one(a);
+        one(a, pl.verify_grid);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_compress, dim3((pl.n + 255) / 256), dim3(256), 0, st, pl.parent, pl.n);
         LAUNCH_CHECK();
-        one(b);
+        one(b, pl.verify_grid);
+    } else if (pl.verify_adaptive) {
+        // max_dist 2, labels only: whether the graph is a sparse forest (k_verify, splicing: the default generator's data, 2-3
+        // candidates per row) or dense (a star phylogeny: a hub with thousands of neighbours at distance 1 makes all of THEM
+        // neighbours at distance 2 — 180 candidates per row at 1M rows, 67-73 ms for k_verify) is known on the device when the
+        // queue is full: both kernels are launched, the queue's fill decides which one works (the other costs ~5 us)
+        PairArgs sp = pa_in, dn = pa_in;
+        sp.density_mode = 1;
+        dn.density_mode = 2;
+        sp.density_thr = dn.density_thr = pl.verify_density_thr;
+        dn.skip_connected = 1;
+        dn.use_link = 0;
+        dn.stats_off = 2 * pl.verify_grid;
+        one(sp, pl.verify_grid);
+        LAUNCH_CHECK();
+        one(dn, pl.verify_grid2);
     } else {
-        one(pa);
+        one(pa, pl.verify_grid);
     }
     LAUNCH_CHECK();
     if (2 * pl.kcap > verify_max_tokens(verify_steps(steps))) {  // some pair may exceed a group table

@@ -42,6 +42,31 @@ def test_golden_labels_with_pruning(name, force, monkeypatch):
     _invariants(st, labels)
 
 
+def test_dense_max_dist_2_graphs_are_verified_by_the_pruning_kernel_by_themselves():
+    """max-dist 2, labels only: both verify kernels are launched and the candidate queue's fill decides on the device which one
+    works — a star phylogeny (hubs with hundreds of neighbours at distance 1: all of them within 2 of each other) takes the
+    pruning kernel (n_connected > 0), the default generator's sparse forest the exact one; labels equal the oracle's either way
+    and equal the exact mode's"""
+    from breakfast_amd.synth import generate_family
+
+    for fam, dense in (("star", True), ("default", False)):  # (star, 60k rows: ~11 candidates per row; default: ~2)
+        uf = list(dict.fromkeys(generate_family(fam, 60000) if fam != "default" else generate_profiles(20000)))
+        indptr, indices, _ = _lib.build_csr(uf, " ")
+        want = orc.cluster_csr(indptr, indices, 2, n_threads=16)["labels"]
+        got, st = _lib.cluster_csr(indptr, indices, 2)
+        assert np.array_equal(got, want) and st["n_retry_slices"] == 0
+        assert (st["n_connected"] > 0) == dense, (fam, st)
+        assert st["n_edges"] + st["n_connected"] <= st["n_candidates"]
+        ctx = _lib.Context(0)
+        ctx.set_exact_edges(True)
+        ctx.upload_csr(indptr, indices)
+        d_out = ctx.alloc(4 * len(uf))
+        ctx.cluster(2, d_out)
+        stx = ctx.sync()
+        assert stx["n_connected"] == 0 and np.array_equal(ctx.download_i32(d_out, len(uf)), want)
+        ctx.close()
+
+
 @pytest.mark.parametrize("generator", ["band", "prefix", "prefix_pos"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
 def test_fuzz_vs_oracle_with_pruning(seed, generator, monkeypatch):

@@ -107,7 +107,7 @@ def test_config3_one_million_rows_max_dist_1(million):
     uf, indptr, indices = _csr(million)
     assert len(uf) > 990_000
     l1, st1 = _lib.cluster_csr(indptr, indices, 1)
-    assert st1["n_work_items"] > 0          # beyond 800k rows max-dist 1 runs the all-pairs kernels (third sort key)
+    assert st1["path"] == 1                 # short rows: the variant join up to 1.2M rows (round 4; the band kernels beyond)
     assert st1["n_retry_slices"] == 0
     assert st1["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
     _check_fix_point(l1)
@@ -119,14 +119,14 @@ def test_config3_one_million_rows_max_dist_1(million):
     got8, edges8 = _sharded_labels(indptr, indices, 1, 8)  # configs[3]: row-sharded over 8 ranks, label merge
     assert np.array_equal(got8, l1)
     assert edges8 == st1["n_edges"]         # every edge found by exactly one shard
-    # the forced variant join (it is the default up to 800k rows) agrees at this size too
+    # the band kernels with the third sort key (north_star's all-pairs design) agree at this size: an independent generator
     ctx = _lib.Context(0)
-    ctx.set_candidate_path("join")
+    ctx.set_candidate_path("allpairs")
     ctx.upload_csr(indptr, indices)
     d_out = ctx.alloc(4 * len(uf))
     ctx.cluster(1, d_out)
-    stj = ctx.sync()
-    assert stj["n_work_items"] == 0 and stj["n_edges"] == st1["n_edges"]
+    stb = ctx.sync()
+    assert stb["path"] == 0 and stb["n_work_items"] > 0 and stb["n_edges"] == st1["n_edges"]
     assert np.array_equal(ctx.download_i32(d_out, len(uf)), l1)
     ctx.close()
 
@@ -175,13 +175,14 @@ def test_config4_one_million_rows_max_dist_5_indels(million_indels, monkeypatch)
 
 @pytest.mark.exact_edges
 @pytest.mark.parametrize("n_rows,join,third_key", [(590_000, True, False), (610_000, True, True), (790_000, True, True),
-                                                   (815_000, False, True)])
+                                                   (815_000, True, True)])
 def test_size_switches_without_knobs(million, n_rows, join, third_key):
-    """either side of the 600k third-key switch (the all-pairs kernels, max-dist 2) and of the 800k join switch
-    (max-dist 1); the paths must agree with each other and with sampled oracle rows"""
+    """either side of the 600k third-key switch (the all-pairs kernels, max-dist 2) and of 800k rows, where the device-driven
+    text step ends and — for rows of more than 64 tokens on average — the variant join (max-dist 1); the paths must agree
+    with each other and with sampled oracle rows"""
     uf, indptr, indices = _csr(million[:n_rows])
     n = len(uf)
-    assert (n >= 600_000) == third_key and (n <= 800_000) == join
+    assert (n >= 600_000) == third_key
     l1, st = _lib.cluster_csr(indptr, indices, 1)
     assert (st["n_work_items"] == 0) == join
     _check_fix_point(l1)
