@@ -234,7 +234,9 @@ int launch_collapse(const PrepArgs &a, hipStream_t st);
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip
-int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
+int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st, int *host_out = nullptr);
+int launch_tok_clear(void *zero, size_t zero_bytes, void *ones, size_t ones_bytes, uint8_t *pad, uint32_t pad_bytes, uint8_t pad_byte, int *small,
+                     hipStream_t st);  // bfk_text.hip
 int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev);

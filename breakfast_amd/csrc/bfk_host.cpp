@@ -148,6 +148,7 @@ struct bfk_ctx {
     bfk_text_stats tk_stats{};
     bool tok_pending = false;  // the tokeniser's counters (d_small[8..15]) are to come back with the next bind's copy
     int tok_host[8] = {0};
+    int *h_small_dev = nullptr;  // the same memory as the device addresses it (hipHostGetDevicePointer)
     int *h_small = nullptr;    // pinned host copies of d_small (16 ints each): slot 0 for binds the host waits for, slots 1 .. SPEC_RING for open text steps
     // Text steps whose bind the host has not completed yet: bfk_ctx_cluster_text_device enqueued the clustering kernels behind
     // the tokeniser with the token count and the longest row read ON THE DEVICE (JoinArgs::dyn) and returned.  Up to SPEC_RING
@@ -227,12 +228,13 @@ extern "C" int bfk_ctx_create(int device, bfk_ctx **ctx_out) {
         return fail(BFK_EHIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess || hipHostMalloc((void **)&c->h_small, 64 * (bfk_ctx::SPEC_RING + 1), hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_small, 64) != hipSuccess || hipHostMalloc((void **)&c->h_small, 64 * (bfk_ctx::SPEC_RING + 1), hipHostMallocMapped) != hipSuccess ||
         hipMalloc((void **)&c->d_blk_stats, (size_t)VERIFY_GRID_MAX * 4 * sizeof(int)) != hipSuccess) {
         delete c;
         return fail(BFK_ENOMEM, "hipMalloc failed");
     }
     (void)hipMemset(c->d_blk_stats, 0, (size_t)VERIFY_GRID_MAX * 4 * sizeof(int));
+    if (hipHostGetDevicePointer((void **)&c->h_small_dev, c->h_small, 0) != hipSuccess) c->h_small_dev = c->h_small;
     *ctx_out = c;
     return BFK_OK;
 }
@@ -505,7 +507,6 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     if (int rc = dev_realloc(&c->own_indices, &c->own_nnz_cap, nnz_alloc, 1.05)) return rc;
     if (int rc = dev_realloc(&c->own_indptr, &c->own_n_cap, n_rows + 1, 1.05)) return rc;
     hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr;
-    if (attempt == 0) HIP_TRY(hipMemsetAsync(tp.d_text + T, (unsigned char)tp.sep, (size_t)(T_pad + TOK_TEXT_SLACK - T), c->stream));
     // vocabulary table: 1/32 slot per possible token (real inputs: ~8 bytes per token — a quarter of the bound — and a
     // vocabulary of a few % of the tokens: load below 20%); an input with more distinct tokens overflows the probe
     // limit, the table grows 8x (twice at most: 2 slots per possible token) and the kernels run again on the
@@ -516,9 +517,11 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     if (const char *e = getenv("BFK_TOK_SLOTS_SHIFT")) slots = atoi(e) >= 0 ? slots << atoi(e) : std::max<int64_t>(1 << 12, slots >> -atoi(e));  // (experiments)
     if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
     if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
-    HIP_TRY(hipMemsetAsync(c->tk_zero, 0, (size_t)z_bytes, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_small, 0, 64, c->stream));  // k_maxlen's outputs [0..7] and the tokeniser's counters [8..15]
-    HIP_TRY(hipMemsetAsync(c->tk_table, 0xFF, (size_t)slots * sizeof(TokSlot), c->stream));
+    // bit arrays zero, table all ones, separator padding behind the text, k_maxlen's outputs [0..7] and the tokeniser's counters
+    // [8..15]: one launch
+    if (int e = launch_tok_clear(c->tk_zero, (size_t)z_bytes, c->tk_table, (size_t)slots * sizeof(TokSlot), tp.d_text + T,
+                                 (uint32_t)(T_pad + TOK_TEXT_SLACK - T), (uint8_t)tp.sep, c->d_small, c->stream))
+        return fail(BFK_EHIP, std::string("k_tok_clear launch: ") + hipGetErrorString((hipError_t)e));
     TokArgs a{};
     a.text = tp.d_text;
     a.row_off = tp.d_rowoff;
@@ -559,11 +562,12 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     c->d_indptr = c->own_indptr;
     c->d_indices = c->own_indices;
     c->n = n_rows;
-    if (n_rows > 0) {
-        if (int e = launch_maxlen(c->d_indptr, (int)n_rows, c->d_small, c->stream))
+    if (n_rows > 0) {  // (its last block stores the 16 counter words to the pinned host slot itself: no copy of their own)
+        if (int e = launch_maxlen(c->d_indptr, (int)n_rows, c->d_small, c->stream, c->h_small_dev + 16 * h_slot))
             return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_small + 16 * h_slot, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_small + 16 * h_slot, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
     if (done_ev) HIP_TRY(hipEventRecord(done_ev, c->stream));
     return BFK_OK;
 }

@@ -1,22 +1,15 @@
 #!/bin/bash
-# rocprofv3 kernel stats of `bench.py --quick <args>` -> gpurun_out/prof_q_<tag>/kernel_stats.csv (+ the top kernels on stdout)
-# usage (through gpurun): tools/prof_quick.sh <tag> [bench args...]
-set -eo pipefail
-tag=${1:?tag}; shift
+# kernel trace summary of `bench.py --quick` (per-kernel calls and mean duration); run through gpurun
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/gpurun_out/prof_q_$tag
-mkdir -p "$out"
-cd /tmp
-export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- \
-    python3 "$root/bench.py" --quick "$@" > "$out/line.json" 2> "$out/err.log"
-python3 - "$out" <<'PY'
+cd /tmp && export TMPDIR=/tmp
+rm -rf $root/gpurun_out/prof_q
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_q -o q -- python3 $root/bench.py --steps 100 --warmup 10 --quick "$@" > $root/gpurun_out/prof_q.json 2>/dev/null
+python3 - $root <<'PY'
 import csv, glob, sys, json
-out = sys.argv[1]
-st = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)[0]
-open(out + "/kernel_stats.csv", "w").write(open(st).read())
-b = json.loads(open(out + "/line.json").read().strip().splitlines()[-1])
-print("ms_per_step", round(b["ms_per_step"], 4), b["phases_ms"])
-for r in list(csv.DictReader(open(st)))[:14]:
-    print(f'{r["Name"].split("(")[0][:44]:46s} calls {r["Calls"]:>5s}  avg {float(r["AverageNs"]) / 1000:9.2f} us')
+root = sys.argv[1]
+f = glob.glob(root + "/gpurun_out/prof_q/**/*kernel_stats.csv", recursive=True)[0]
+b = json.loads(open(root + "/gpurun_out/prof_q.json").read().strip().splitlines()[-1])
+print("ms_per_step", round(b["ms_per_step"], 4), "resident", round(b["resident_csr"]["ms_per_step"], 4))
+for r in list(csv.DictReader(open(f)))[:22]:
+    print(r["Name"].split("(")[0][:44].ljust(46), r["Calls"].rjust(6), f"{float(r['AverageNs']) / 1000:8.2f} us", r["Percentage"])
 PY
