@@ -186,6 +186,7 @@ struct TokArgs {
     uint32_t *blkbase, *vocblk; // [T_pad / TOK_PAD_BYTES + 1]: ... in front of every scan block (k_scan_single)
     TokSlot *table;            // tmask + 1 slots of 16 bytes
     uint32_t tmask;
+    int *tabid;                // first-appearance id per slot (4 bytes per slot: what k_tok_ids gathers from)
     uint32_t *tokslot;         // per token: its slot (aliases `indices`)
     uint32_t *indices;
     int *indptr;

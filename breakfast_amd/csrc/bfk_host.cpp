@@ -127,6 +127,8 @@ struct bfk_ctx {
     char *tk_zero = nullptr;  // [TokCounters | rowbits | firstbits]: zeroed by ONE memset per build
     uint32_t *tk_bits = nullptr, *tk_winbase = nullptr;
     TokSlot *tk_table = nullptr;
+    int *tk_tabid = nullptr;  // first-appearance id per slot
+    int64_t tk_tabid_cap = 0;
     // device prepare of a table (filter + collapse, bfk_prep.hip): span lengths, row hashes, the hash table, representatives,
     // prefix sums, group index / first row of the unique rows, their CSR, {totals, failure flags}
     int *pr_spanlen = nullptr, *pr_rep = nullptr, *pr_group = nullptr, *pr_first = nullptr, *pr_uindptr = nullptr, *pr_small = nullptr;
@@ -251,7 +253,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_tile_slots, c->d_cand,    c->d_candk,      c->d_edges,  c->d_small, c->d_sigu2, c->d_chain,
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
-                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_slots, c->d_edge_sel, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
+                    c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid, c->tk_slots, c->d_edge_sel, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
                     c->pr_uindptr, c->pr_small, c->pr_rowhash, c->pr_table, c->pr_val, c->pr_blk, c->pr_uindices};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -517,6 +519,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     if (const char *e = getenv("BFK_TOK_SLOTS_SHIFT")) slots = atoi(e) >= 0 ? slots << atoi(e) : std::max<int64_t>(1 << 12, slots >> -atoi(e));  // (experiments)
     if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
     if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
+    if (int rc = dev_realloc(&c->tk_tabid, &c->tk_tabid_cap, slots)) return rc;
     // bit arrays zero, table all ones, separator padding behind the text, k_maxlen's outputs [0..7] and the tokeniser's counters
     // [8..15]: one launch
     if (int e = launch_tok_clear(c->tk_zero, (size_t)z_bytes, c->tk_table, (size_t)slots * sizeof(TokSlot), tp.d_text + T,
@@ -546,6 +549,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     a.flt = tp.flt;
     a.span_len = tp.d_span_len;
     a.table = c->tk_table;
+    a.tabid = c->tk_tabid;
     a.tmask = (uint32_t)(slots - 1);
     a.tokslot = tp.flt.on ? c->tk_slots : c->own_indices;  // (in place without the filter: the slot array IS the indices array)
     a.indices = c->own_indices;

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
         uint32_t cnt = a.vocblk[w / TOK_SCAN_WINS] + a.vocwin[w];
         for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.firstbits[q]);
         cnt += (uint32_t)__popc(a.firstbits[o >> 5] & ((1u << (o & 31u)) - 1u));
-        a.table[s].id = (int)cnt;
+        a.tabid[s] = (int)cnt;  // (an array of its own: k_tok_ids gathers from 4 bytes per slot, not from the 16-byte slots)
     }
 }
 
@@ -720,10 +720,10 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     if (g0 >= nnz) return;
     const uint4 s = *reinterpret_cast<const uint4 *>(a.tokslot + g0);
     uint4 o;
-    o.x = (uint32_t)a.table[s.x].id;
-    o.y = g0 + 1 < nnz ? (uint32_t)a.table[s.y].id : 0u;
-    o.z = g0 + 2 < nnz ? (uint32_t)a.table[s.z].id : 0u;
-    o.w = g0 + 3 < nnz ? (uint32_t)a.table[s.w].id : 0u;
+    o.x = (uint32_t)a.tabid[s.x];
+    o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y] : 0u;
+    o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z] : 0u;
+    o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w] : 0u;
     *reinterpret_cast<uint4 *>(a.indices + g0) = o;
 }
 
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_tok_ids_kept(TokArgs a, uint32_t n_unit
         const uint32_t s = g + lane < g1 ? a.tokslot[g + lane] : TOK_NONE;
         const bool keep = s != TOK_NONE;
         const unsigned long long bal = __ballot(keep);
-        if (keep) a.indices[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)a.table[s].id;
+        if (keep) a.indices[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)a.tabid[s];
         o += (uint32_t)__popcll(bal);
     }
 }
