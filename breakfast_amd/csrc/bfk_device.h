@@ -66,7 +66,10 @@ struct JoinArgs {
     int *stats;  // per block of k_join: {edges certified and hooked there, candidates}
     uint32_t mask, bmask;
     int dup_cap;
-    const int *dyn;    // NULL, or the device words of a bind the host has not completed yet (k_maxlen's outputs + the tokeniser's
+    int *dyn_host;     // with dyn: 16 ints of pinned host memory — block 0 of k_jhash copies dyn[0..15] there before anything else (the
+                       // host reads the counters of the step when it completes the bind; a copy of their own is ~9 us of stream time, a
+                       // store at the END of a kernel ~5: at the start of one it is under the kernel's own work)
+    const int *dyn;    // NULL, or the device words of a bind the host has not completed yet (the row statistics k_tok_rows leaves + the tokeniser's
                        // counters: [0] longest row, [1] negative row length seen, [3] nnz, [10] tokeniser failure flags): the kernels
                        // take nnz and the longest row from there, and do nothing when the CSR is unusable or outside what the host
                        // assumed (a row over JOIN_INLINE_ROW tokens, no token at all: Counters::join_fail = 2, the host redoes the step)
@@ -235,7 +238,7 @@ int launch_collapse(const PrepArgs &a, hipStream_t st);
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip
-int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st, int *host_out = nullptr);
+int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 int launch_tok_clear(void *zero, size_t zero_bytes, void *ones, size_t ones_bytes, uint8_t *pad, uint32_t pad_bytes, uint8_t pad_byte, int *small,
                      hipStream_t st);  // bfk_text.hip
 int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st);

@@ -178,6 +178,7 @@ struct bfk_ctx {
     static constexpr int SPEC_RING = 4;
     SpecStep spec_ring[SPEC_RING];
     int spec_head = 0, spec_count = 0;  // oldest open step, number of open steps
+    int *spec_host = nullptr;           // ... and the pinned slot its counters go to
     bool spec_enqueueing = false;       // ctx_enqueue is being called for a device-driven step (JoinArgs::dyn is set)
     // last run
     bool ran = false;
@@ -485,11 +486,12 @@ extern "C" int64_t bfk_text_device_bytes(int64_t text_bytes) {
 // d_rowoff = int64[n_rows + 1] on the device, offsets relative to `base`.  `n_pieces` > 1: the text is still arriving on the copy
 // stream, piece by piece (host wrapper below).  `strict`: the offsets come from the caller's device memory, the kernels also
 // check row_off[0] == base and row_off[n_rows] == base + T (the host wrapper has checked its own).
-//   ctx_tok_launch  allocations, clearing, the tokenising kernels, k_maxlen over the new indptr, and ONE small copy of the
-//                   counters (token count, longest row, failure flags) into pinned host memory — all enqueued, no wait
+//   ctx_tok_launch  allocations, clearing, the tokenising kernels (k_tok_rows leaves the row statistics of the new indptr), and
+//                   ONE small copy of the counters (token count, longest row, failure flags) into pinned host memory — all
+//                   enqueued, no wait
 //   ctx_tok_finish  waits for the stream and completes the bind from those counters (workspace sized by the longest row);
 //                   *retry: the vocabulary table was too small, it has been enlarged, launch again
-static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, int h_slot = 0, hipEvent_t done_ev = nullptr) {
+static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, bool copy_counters = true) {
     const int64_t T = tp.T, n_rows = tp.n_rows;
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     // every token but the last of a row is followed by a separator: at most T/2 + n_rows + 1 tokens
@@ -562,23 +564,19 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, i
     const bool pieces = tp.n_pieces > 1 && attempt == 0;
     if (int e = launch_tokenize(a, c->stream, ev, pieces ? tp.n_pieces : 1, tp.piece_blk, pieces ? c->tk_piece_ev : nullptr))
         return fail(BFK_EHIP, std::string("tokeniser launch: ") + hipGetErrorString((hipError_t)e));
-    // the bind's device half: longest row, token count (k_maxlen over the new indptr), then the counters on their way to the host
+    // the bind's device half — longest row, token count: k_tok_rows left them in d_small[0..4] — is done; the counters go to
+    // the host with a copy of their own (slot 0) when the host is about to wait for them anyway, and with the first clustering
+    // kernel's own stores when the step is device-driven (JoinArgs::dyn_host)
     c->d_indptr = c->own_indptr;
     c->d_indices = c->own_indices;
     c->n = n_rows;
-    if (n_rows > 0) {  // (its last block stores the 16 counter words to the pinned host slot itself: no copy of their own)
-        if (int e = launch_maxlen(c->d_indptr, (int)n_rows, c->d_small, c->stream, c->h_small_dev + 16 * h_slot))
-            return fail(BFK_EHIP, std::string("k_maxlen launch: ") + hipGetErrorString((hipError_t)e));
-    } else {
-        HIP_TRY(hipMemcpyAsync(c->h_small + 16 * h_slot, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
-    }
-    if (done_ev) HIP_TRY(hipEventRecord(done_ev, c->stream));
+    if (copy_counters) HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
     return BFK_OK;
 }
 
 static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, int h_slot = 0, hipEvent_t done_ev = nullptr) {
     *retry = false;
-    if (done_ev) HIP_TRY(hipEventSynchronize(done_ev));  // (the step's counters have landed; its clustering kernels may still run)
+    if (done_ev) HIP_TRY(hipEventSynchronize(done_ev));  // (recorded behind the step's last kernel)
     else HIP_TRY(hipStreamSynchronize(c->stream));
     int h[16];
     memcpy(h, c->h_small + 16 * h_slot, sizeof h);
@@ -676,7 +674,8 @@ static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_
     st.tp = tp;
     st.d = max_dist;
     st.labels = d_labels_out;
-    if (int rc = ctx_tok_launch(c, tp, 0, 1 + idx, st.ev)) return rc;
+    if (int rc = ctx_tok_launch(c, tp, 0, false)) return rc;
+    c->spec_host = c->h_small_dev + 16 * (1 + idx);  // (k_jhash stores the counters there)
     // what the host assumes until the counters are back: the most tokens the text can hold, no row over JOIN_INLINE_ROW
     c->nnz = tp.T / 2 + tp.n_rows + 1;
     c->kcap = JOIN_INLINE_ROW;
@@ -694,6 +693,7 @@ static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_
         c->n = -1;
         return rc;
     }
+    HIP_TRY(hipEventRecord(st.ev, c->stream));  // (behind the step's last kernel: the counters AND the labels are there when it fires)
     c->spec_count++;
     return BFK_OK;
 }
@@ -1240,6 +1240,7 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         pl.ja.dbg = getenv("BFK_JOIN_DEBUG") ? atoi(getenv("BFK_JOIN_DEBUG")) : 0;
         // a text step whose bind is still open: token count, longest row and the tokeniser's failure flags are read on the device
         pl.ja.dyn = c->spec_enqueueing ? c->d_small : nullptr;
+        pl.ja.dyn_host = c->spec_enqueueing ? c->spec_host : nullptr;
     }
     if (c->spec_enqueueing && !pl.join) return fail(BFK_ESTATE, "internal: a device-driven text step needs the variant join");
     pl.pg = 0;

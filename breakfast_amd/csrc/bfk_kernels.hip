@@ -146,11 +146,7 @@ __device__ __forceinline__ uint32_t hash3(uint32_t x) {
 // ------------------------------------------------------------------------------------------------
 // k_maxlen: validate indptr, find the longest row (bind time only)
 // ------------------------------------------------------------------------------------------------
-// host_out (may be NULL): 16 ints of pinned host memory — the block that finishes last (ticket in out[5]) copies out[0..15]
-// there itself: the bind's counters reach the host with the kernel's own stores instead of a 64-byte copy of their own (a
-// tiny device-to-host copy is ~9 us of stream time between the tokeniser and the clustering kernels).
-__global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens, [3]=indptr[n], [4]=indptr[0]*/,
-                                                int *host_out) {
+__global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, int n, int *out /*[0]=max k, [1]=err, [2]=rows of <= 2*PG_MAX_DIST tokens, [3]=indptr[n], [4]=indptr[0]*/) {
     __shared__ int s_k[4], s_short[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[3] = indptr[n];
@@ -180,18 +176,6 @@ __global__ __launch_bounds__(256) void k_maxlen(const int *__restrict__ indptr, 
         n_short = s_short[0] + s_short[1] + s_short[2] + s_short[3];
         if (kmax > 0) atomicMax(out, kmax);
         if (n_short > 0) atomicAdd(out + 2, n_short);
-    }
-    if (host_out) {  // (block-uniform)
-        __shared__ int s_last;
-        if (threadIdx.x == 0) {
-            __threadfence();
-            s_last = atomicAdd(reinterpret_cast<unsigned *>(out + 5), 1u) == gridDim.x - 1 ? 1 : 0;  // every block's atomics are in
-        }
-        __syncthreads();
-        if (s_last && threadIdx.x < 16) {  // ONE 64-byte store across PCIe (sixteen stores one after the other: 11 us)
-            __threadfence();
-            host_out[threadIdx.x] = __hip_atomic_load(out + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -1567,6 +1551,9 @@ __global__ __launch_bounds__(1024) void k_jhash(const int *__restrict__ indptr, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (ja.dyn) {  // a text step whose bind the host has not completed: counts from the device (JoinArgs::dyn)
+        // the step's counters to the host, first thing (also when the step is unusable: the host learns it from them) — ONE
+        // 64-byte store across PCIe, acknowledged while the kernel works
+        if (ja.dyn_host && blockIdx.x == 0 && threadIdx.x < 16) ja.dyn_host[threadIdx.x] = ja.dyn[threadIdx.x];
         if (join_dyn_unusable(ja.dyn)) return;
         nnz = ja.dyn[3];
         kcap = ja.dyn[0];
@@ -2942,9 +2929,9 @@ __global__ void k_changed(const int *__restrict__ labels, const int *__restrict_
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
-int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st, int *host_out) {
+int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_maxlen, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, st, indptr, n, out, host_out);
+    hipLaunchKernelGGL(k_maxlen, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, st, indptr, n, out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -631,20 +631,67 @@ __global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uin
 // k_tok_rows: thread r <= n_rows: indptr[r] = token starts in front of row_off[r] (the window's prefix + the bits of the
 // window in front of the offset).  The same grid then walks the table: a slot in use sets the bit `first occurrence`
 // at the byte offset it holds.
+// The bind's row statistics come out of the same pass (a k_maxlen launch over the new indptr was 11 us of a 220 us step):
+// small[0] = longest row, [1] = a negative row length was seen, [2] = rows of <= 2 * PG_MAX_DIST tokens, [3] = indptr[n_rows],
+// [4] = indptr[0] — the words in front of the tokeniser's counters (k_maxlen's layout; cleared by k_tok_clear).  A row's length
+// is the next lane's count minus its own; the last lane of a wave counts its right neighbour's offset itself.
 __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
+    __shared__ int s_k[4], s_short[4], s_bad[4];
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+    const int lane = threadIdx.x & 63;
     // (filter mode: the CSR holds the tokens the filter kept — their bits and prefixes instead of the token starts')
     const uint32_t *bits = a.flt.on ? a.keptbits : a.startbits;
     const uint32_t *win = a.flt.on ? a.keptwin : a.winbase, *blk = a.flt.on ? a.keptblk : a.blkbase;
-    for (uint32_t r = tid; r <= (uint32_t)a.n_rows; r += nth) {
+    int *small = reinterpret_cast<int *>(a.tc) - 8;
+    auto count_at = [&](uint32_t r) -> uint32_t {
         long long ol = a.row_off[r] - a.base;
         ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported by k_tok_rowbits)
         const uint32_t o = (uint32_t)ol;
         const uint32_t w = o / TOK_WIN;
         uint32_t cnt = blk[w / TOK_SCAN_WINS] + win[w];
         for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(bits[q]);
-        cnt += (uint32_t)__popc(bits[o >> 5] & ((1u << (o & 31u)) - 1u));
-        a.indptr[r] = (int)cnt;
+        return cnt + (uint32_t)__popc(bits[o >> 5] & ((1u << (o & 31u)) - 1u));
+    };
+    int kmax = 0, n_short = 0, bad = 0;
+    const uint32_t n_rows = (uint32_t)a.n_rows;
+    for (uint32_t rb = tid - (uint32_t)lane; rb <= n_rows; rb += nth) {  // (wave-uniform trips: the lanes exchange their counts)
+        const uint32_t r = rb + (uint32_t)lane;
+        const bool in = r <= n_rows;
+        const uint32_t cnt = in ? count_at(r) : 0u;
+        if (in) a.indptr[r] = (int)cnt;
+        uint32_t nxt = (uint32_t)__shfl_down((int)cnt, 1);
+        if (lane == 63 && r < n_rows) nxt = count_at(r + 1);
+        if (r < n_rows) {
+            int k = (int)(nxt - cnt);
+            if (k < 0) {
+                bad = 1;
+                k = 0;
+            }
+            n_short += k <= 2 * PG_MAX_DIST ? 1 : 0;
+            kmax = max(kmax, k);
+        }
+        if (r == n_rows) small[3] = (int)cnt;
+        if (r == 0) small[4] = (int)cnt;
+    }
+    if (blockIdx.x * 256u <= n_rows) {  // (block-uniform: the block had rows)
+        for (int s = 32; s > 0; s >>= 1) {
+            kmax = max(kmax, __shfl_xor(kmax, s));
+            n_short += __shfl_xor(n_short, s);
+            bad |= __shfl_xor(bad, s);
+        }
+        if (lane == 0) {
+            s_k[threadIdx.x >> 6] = kmax;
+            s_short[threadIdx.x >> 6] = n_short;
+            s_bad[threadIdx.x >> 6] = bad;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {  // one set of atomics per block, and only where they change something
+            kmax = max(max(s_k[0], s_k[1]), max(s_k[2], s_k[3]));
+            n_short = s_short[0] + s_short[1] + s_short[2] + s_short[3];
+            if (kmax > __hip_atomic_load(small, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(small, kmax);
+            if (n_short > 0) atomicAdd(small + 2, n_short);
+            if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(small + 1, 1);
+        }
     }
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
         const TokSlot e = a.table[s];
