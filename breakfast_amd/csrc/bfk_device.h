@@ -195,6 +195,7 @@ struct TokArgs {
     int *indptr;
     TokCounters *tc;
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
+    int rows_fused;            // the row-start bits were set by k_tok_clear (no k_tok_rowbits launch)
     int head_units;            // > 0: k_tok_hash runs the first so many units in a launch of their own before the rest
     int sample;                // > 1: then every sample-th unit, then the others (three launches in all)
     int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 1 no atomicMin of a found token's first offset,
@@ -239,8 +240,16 @@ int launch_collapse(const PrepArgs &a, hipStream_t st);
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
                  int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
+// rows of a build for k_tok_clear (rowbits == NULL: the bits are set by a k_tok_rowbits launch of their own)
+struct TokRows {
+    const long long *row_off;
+    long long base;
+    uint32_t T;
+    int n_rows;
+    uint32_t *rowbits;
+};
 int launch_tok_clear(void *zero, size_t zero_bytes, void *ones, size_t ones_bytes, uint8_t *pad, uint32_t pad_bytes, uint8_t pad_byte, int *small,
-                     hipStream_t st);  // bfk_text.hip
+                     hipStream_t st, const TokRows &rows);  // bfk_text.hip
 int launch_maxtok(const uint32_t *indices, int nnz, int *out, hipStream_t st);
 int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev);
 int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEvent_t *ev);

@@ -178,6 +178,7 @@ struct bfk_ctx {
     static constexpr int SPEC_RING = 4;
     SpecStep spec_ring[SPEC_RING];
     int spec_head = 0, spec_count = 0;  // oldest open step, number of open steps
+    int64_t tk_rowbits_clean = 0;       // words of tk_zero's row-start bits that are zero when the stream gets to the next build
     int *spec_host = nullptr;           // ... and the pinned slot its counters go to
     bool spec_enqueueing = false;       // ctx_enqueue is being called for a device-driven step (JoinArgs::dyn is set)
     // last run
@@ -502,7 +503,9 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     // zeroed region: rowbits | firstbits (the counters live in d_small[8..15] and travel with the bind's copy)
     const int64_t bit_words = T_pad / 32 + 16;
     const int64_t z_rowbits = 0, z_firstbits = z_rowbits + bit_words * 4, z_bytes = z_firstbits + bit_words * 4;
+    const int64_t zero_cap_before = c->tk_zero_cap;
     if (int rc = dev_realloc(&c->tk_zero, &c->tk_zero_cap, z_bytes, 1.05)) return rc;
+    if (c->tk_zero_cap != zero_cap_before) c->tk_rowbits_clean = 0;  // (new memory)
     if (int rc = dev_realloc(&c->tk_bits, &c->tk_bits_cap, 3 * bit_words, 1.05)) return rc;  // start | bound | kept
     const int64_t n_blk = round_up(T_pad / TOK_PAD_BYTES + 1, 4) + 4;  // (+ the total behind the last block; 16-byte pieces)
     if (int rc = dev_realloc(&c->tk_winbase, &c->tk_winbase_cap, 3 * (n_win + n_blk), 1.05)) return rc;
@@ -522,11 +525,6 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
     if (int rc = dev_realloc(&c->tk_table, &c->tk_table_cap, slots)) return rc;
     if (int rc = dev_realloc(&c->tk_tabid, &c->tk_tabid_cap, slots)) return rc;
-    // bit arrays zero, table all ones, separator padding behind the text, k_maxlen's outputs [0..7] and the tokeniser's counters
-    // [8..15]: one launch
-    if (int e = launch_tok_clear(c->tk_zero, (size_t)z_bytes, c->tk_table, (size_t)slots * sizeof(TokSlot), tp.d_text + T,
-                                 (uint32_t)(T_pad + TOK_TEXT_SLACK - T), (uint8_t)tp.sep, c->d_small, c->stream))
-        return fail(BFK_EHIP, std::string("k_tok_clear launch: ") + hipGetErrorString((hipError_t)e));
     TokArgs a{};
     a.text = tp.d_text;
     a.row_off = tp.d_rowoff;
@@ -558,6 +556,22 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     a.indptr = c->own_indptr;
     a.nnz_cap = nnz_cap;
     a.dbg = getenv("BFK_TOK_DEBUG") ? atoi(getenv("BFK_TOK_DEBUG")) : 0;
+    // The row-start bits: the build before this one left them zero (k_voc_ids clears them when the scan has used them) over
+    // tk_rowbits_clean words — then k_tok_clear sets this build's bits itself and there is no k_tok_rowbits launch.  Otherwise
+    // (first build, a longer text than any before, new memory, a build that was not enqueued to its end) they are zeroed with
+    // the rest and set by their own launch.  BFK_TOK_ROWBITS=0: always the latter.
+    const bool rows_fused = n_rows > 0 && bit_words <= c->tk_rowbits_clean && a.dbg == 0 && !(getenv("BFK_TOK_ROWBITS") && atoi(getenv("BFK_TOK_ROWBITS")) == 0);
+    c->tk_rowbits_clean = 0;  // (until this build is enqueued to its end)
+    a.rows_fused = rows_fused ? 1 : 0;
+    // bit arrays zero, table all ones, separator padding behind the text, the row statistics [0..7] and the tokeniser's counters
+    // [8..15]: one launch
+    {
+        const TokRows rows{tp.d_rowoff, tp.base, (uint32_t)T, (int)n_rows, rows_fused ? a.rowbits : nullptr};
+        char *zero = rows_fused ? c->tk_zero + z_firstbits : c->tk_zero;
+        if (int e = launch_tok_clear(zero, (size_t)(rows_fused ? z_bytes - z_firstbits : z_bytes), c->tk_table, (size_t)slots * sizeof(TokSlot), tp.d_text + T,
+                                     (uint32_t)(T_pad + TOK_TEXT_SLACK - T), (uint8_t)tp.sep, c->d_small, c->stream, rows))
+            return fail(BFK_EHIP, std::string("k_tok_clear launch: ") + hipGetErrorString((hipError_t)e));
+    }
     a.head_units = getenv("BFK_TOK_HEAD_UNITS") ? atoi(getenv("BFK_TOK_HEAD_UNITS")) : 16;
     a.sample = getenv("BFK_TOK_SAMPLE") ? atoi(getenv("BFK_TOK_SAMPLE")) : 16;
     // (a second attempt — the table grew — finds the text resident: no pieces to wait for)
@@ -570,6 +584,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     c->d_indptr = c->own_indptr;
     c->d_indices = c->own_indices;
     c->n = n_rows;
+    c->tk_rowbits_clean = a.dbg == 0 ? bit_words : 0;  // (k_voc_ids has been enqueued: the row bits are zero for the next build)
     if (copy_counters) HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
     return BFK_OK;
 }

@@ -643,9 +643,8 @@ __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
     const uint32_t *bits = a.flt.on ? a.keptbits : a.startbits;
     const uint32_t *win = a.flt.on ? a.keptwin : a.winbase, *blk = a.flt.on ? a.keptblk : a.blkbase;
     int *small = reinterpret_cast<int *>(a.tc) - 8;
-    auto count_at = [&](uint32_t r) -> uint32_t {
-        long long ol = a.row_off[r] - a.base;
-        ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported by k_tok_rowbits)
+    auto count_at = [&](long long ol) -> uint32_t {
+        ol = ol < 0 ? 0 : (ol > (long long)a.T ? (long long)a.T : ol);  // (malformed offsets are reported below)
         const uint32_t o = (uint32_t)ol;
         const uint32_t w = o / TOK_WIN;
         uint32_t cnt = blk[w / TOK_SCAN_WINS] + win[w];
@@ -657,11 +656,21 @@ __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
     for (uint32_t rb = tid - (uint32_t)lane; rb <= n_rows; rb += nth) {  // (wave-uniform trips: the lanes exchange their counts)
         const uint32_t r = rb + (uint32_t)lane;
         const bool in = r <= n_rows;
-        const uint32_t cnt = in ? count_at(r) : 0u;
+        const long long off = in ? a.row_off[r] - a.base : 0ll;
+        const uint32_t cnt = in ? count_at(off) : 0u;
         if (in) a.indptr[r] = (int)cnt;
         uint32_t nxt = (uint32_t)__shfl_down((int)cnt, 1);
-        if (lane == 63 && r < n_rows) nxt = count_at(r + 1);
+        long long nxt_off = __shfl_down(off, 1);
+        if (lane == 63 && r < n_rows) {
+            nxt_off = a.row_off[r + 1] - a.base;
+            nxt = count_at(nxt_off);
+        }
         if (r < n_rows) {
+            // the offsets are validated here as well (k_tok_rowbits does it where it runs; a build whose row bits were set by
+            // k_tok_clear has nobody else to do it): monotone, inside the text, and — strict — covering all of it
+            if (off < 0 || nxt_off < off || nxt_off > (long long)a.T ||
+                (a.strict && ((r == 0 && off != 0) || (r == n_rows - 1 && nxt_off != (long long)a.T))))
+                atomicOr(&a.tc->fail, TOK_FAIL_ROWOFF);
             int k = (int)(nxt - cnt);
             if (k < 0) {
                 bad = 1;
@@ -759,6 +768,10 @@ __global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
         cnt += (uint32_t)__popc(a.firstbits[o >> 5] & ((1u << (o & 31u)) - 1u));
         a.tabid[s] = (int)cnt;  // (an array of its own: k_tok_ids gathers from 4 bytes per slot, not from the 16-byte slots)
     }
+    // the row-start bits have been used (k_tok_scan): cleared here, so that the NEXT build finds them zero and sets its own in
+    // k_tok_clear — no k_tok_rowbits launch between the clearing and the scan (4.9 + 1.3 us of a 212 us step)
+    uint4 *rb4 = reinterpret_cast<uint4 *>(a.rowbits);
+    for (uint32_t i = tid, n16 = (a.T_pad / 32u + 16u) / 4u; i < n16; i += nth) rb4[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
@@ -807,8 +820,16 @@ __global__ __launch_bounds__(256) void k_tok_ids_kept(TokArgs a, uint32_t n_unit
 // free slots), the separator padding behind the text, the 16 counter words.  (Four memsets of the runtime, ~5 us of stream
 // time each whatever their size: 21-26 of a 230 us step at 100k rows.)
 __global__ __launch_bounds__(256) void k_tok_clear(uint4 *zero, size_t n_zero16, uint4 *ones, size_t n_ones16, uint8_t *pad, uint32_t pad_bytes,
-                                                   uint8_t pad_byte, int *small) {
+                                                   uint8_t pad_byte, int *small, TokRows rows) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    // rows.rowbits != NULL: the row-start bits are zero already (the build before this one cleared them when it was done with
+    // them, k_voc_ids) and are NOT part of `zero`: this launch sets them — first, so that the atomics are under the streaming
+    // stores.  Malformed offsets are skipped here and reported by k_tok_rows.
+    if (rows.rowbits)
+        for (size_t r = tid; r < (size_t)rows.n_rows; r += nth) {
+            const long long o = rows.row_off[r] - rows.base, e = rows.row_off[r + 1] - rows.base;
+            if (o >= 0 && e >= o && e <= (long long)rows.T) atomicOr(&rows.rowbits[(uint32_t)o >> 5], 1u << ((uint32_t)o & 31u));
+        }
     for (size_t i = tid; i < n_zero16; i += nth) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = tid; i < n_ones16; i += nth) ones[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     for (size_t i = tid; i < pad_bytes; i += nth) pad[i] = pad_byte;
@@ -816,11 +837,11 @@ __global__ __launch_bounds__(256) void k_tok_clear(uint4 *zero, size_t n_zero16,
 }
 
 int launch_tok_clear(void *zero, size_t zero_bytes, void *ones, size_t ones_bytes, uint8_t *pad, uint32_t pad_bytes, uint8_t pad_byte, int *small,
-                     hipStream_t st) {
+                     hipStream_t st, const TokRows &rows) {
     const size_t n16 = zero_bytes / 16 + ones_bytes / 16;
     const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 255) / 256 / 4));
     hipLaunchKernelGGL(k_tok_clear, dim3(blocks), dim3(256), 0, st, (uint4 *)zero, zero_bytes / 16, (uint4 *)ones, ones_bytes / 16, pad, pad_bytes,
-                       pad_byte, small);
+                       pad_byte, small, rows);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -835,7 +856,7 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
     const unsigned table_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)a.tmask + 256) / 256, 8192);
     constexpr unsigned UNITS_PER_BLK = TOK_SCAN_WINS / TOK_WPW;  // hash units (4 KiB) per scan block (64 KiB)
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (a.n_rows > 0) {
+    if (a.n_rows > 0 && !a.rows_fused) {  // (rows_fused: k_tok_clear has set the bits)
         hipLaunchKernelGGL(k_tok_rowbits, dim3((a.n_rows + 255) / 256), dim3(256), 0, st, a);
         LAUNCH_CHECK();
     }

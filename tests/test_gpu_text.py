@@ -202,6 +202,33 @@ def test_text_resident_in_hbm_gives_the_same_csr_and_labels(case):
     ctx.close()
 
 
+def test_builds_of_changing_size_on_one_context_leave_no_row_bits_behind():
+    """the row-start bits of a build are cleared by the build itself when it is done with them, and the next build sets its
+    own in k_tok_clear (no k_tok_rowbits launch) — as long as it is no longer than what was cleared: texts that shrink, grow,
+    shift their row starts by a byte, and a failed build in between must all tokenise as a fresh context does"""
+    import torch
+
+    base = list(dict.fromkeys(generate_profiles(6000)))
+    seqs = [base[:2000], base[:5000], ["X" + r for r in base[:1500]], base[100:101], base, [r[1:] for r in base[:5999]], [], base[:3]]
+    ctx = _lib.Context(0)
+    keep = []
+    for k, rows in enumerate(seqs):
+        buf, off, d_text, d_off = _device_text(rows)
+        keep.append((d_text, d_off))
+        nnz, nv = ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ")
+        want = orc.sparse_feature_matrix(rows, " ")
+        assert (nnz, nv) == (len(want[1]), want[2]), k
+        d_ip, d_ix = ctx.download_csr()
+        assert np.array_equal(d_ip, want[0]) and np.array_equal(d_ix, want[1]), k
+        if k == 2:  # a build that fails (offsets decrease) between two good ones
+            o = off.copy()
+            o[5] = o[4] - 1
+            d_bad = torch.from_numpy(o).cuda()
+            with pytest.raises(_lib.BfkError):
+                ctx.build_csr_device(d_text.data_ptr(), len(buf), d_bad.data_ptr(), len(rows), " ")
+    ctx.close()
+
+
 def test_text_resident_in_hbm_checks_the_offsets_on_the_device():
     import torch
 
