@@ -28,6 +28,7 @@ constexpr int JOIN_TPW = 512;           // tokens (entries of `indices`) per wav
 constexpr int JOIN_INLINE_ROW = 128;    // longest row k_join's own exact check takes (two tokens per lane); beyond: k_verify's queue
 constexpr int JOIN_MAX_PROBE = 256;     // longest probe chain of the variant join before it gives up (-> all-pairs path)
 
+constexpr long long TOK_FUSE_ROWBITS_BYTES = 64ll << 20;  // texts up to this size: row-start bits set by k_tok_clear, cleared by k_voc_ids
 constexpr int PG_MAX_DIST = 7;          // prefix-group path: max_dist + 1 prefix elements per row, at most 8
 constexpr int PG_CNT_BITS = 20;         // hashed counters of the sampled token count
 constexpr int PG_GIVE_UP = 4096;        // group members behind a row's records, per row (sampled), beyond which the band path is used
@@ -117,6 +118,7 @@ struct Plan {
     int pg_tb;                                // key bits of a token: bits of (largest token id + 2)
     int pg_dense;                             // the token counters are indexed by the token id (largest id < 2^PG_CNT_BITS)
     int pg_walk16;                            // the groups are walked by k_pgwalk16 (16 lanes per row); 0: k_pgjoin, a wave per row
+    int pg_has_short;                         // 0: no row has <= 2 * PG_MAX_DIST tokens and the records are position-major: the SHORT slot is left out of the sorted order
     int pg_pb;                                // position bits of the composite key k_pgplace bisects on (3; 0 = positional filter off)
     uint32_t *pg_keys_pm;                     // [recs][n] record keys position-major (the sort's input)
     int *pg_rows, *pg_rows_s;                 // the records' (row * recs + slot); sorted along
@@ -195,6 +197,7 @@ struct TokArgs {
     int *indptr;
     TokCounters *tc;
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
+    int rows_clear_after;      // k_voc_ids clears the row-start bits for the next build (texts up to TOK_FUSE_ROWBITS_BYTES)
     int rows_fused;            // the row-start bits were set by k_tok_clear (no k_tok_rowbits launch)
     int head_units;            // > 0: k_tok_hash runs the first so many units in a launch of their own before the rest
     int sample;                // > 1: then every sample-th unit, then the others (three launches in all)
@@ -238,7 +241,7 @@ int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, i
 int launch_collapse(const PrepArgs &a, hipStream_t st);
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
-                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0);  // bfk_sort.hip
+                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs = 0, int comp_pb = 0, int gen_n = 0, int gen_recs = 0);  // bfk_sort.hip
 int launch_maxlen(const int *indptr, int n, int *out, hipStream_t st);
 // rows of a build for k_tok_clear (rowbits == NULL: the bits are set by a k_tok_rowbits launch of their own)
 struct TokRows {

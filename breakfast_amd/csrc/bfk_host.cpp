@@ -563,6 +563,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     const bool rows_fused = n_rows > 0 && bit_words <= c->tk_rowbits_clean && a.dbg == 0 && !(getenv("BFK_TOK_ROWBITS") && atoi(getenv("BFK_TOK_ROWBITS")) == 0);
     c->tk_rowbits_clean = 0;  // (until this build is enqueued to its end)
     a.rows_fused = rows_fused ? 1 : 0;
+    a.rows_clear_after = T_pad <= TOK_FUSE_ROWBITS_BYTES && a.dbg == 0 ? 1 : 0;
     // bit arrays zero, table all ones, separator padding behind the text, the row statistics [0..7] and the tokeniser's counters
     // [8..15]: one launch
     {
@@ -584,7 +585,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     c->d_indptr = c->own_indptr;
     c->d_indices = c->own_indices;
     c->n = n_rows;
-    c->tk_rowbits_clean = a.dbg == 0 ? bit_words : 0;  // (k_voc_ids has been enqueued: the row bits are zero for the next build)
+    c->tk_rowbits_clean = a.rows_clear_after ? bit_words : 0;  // (k_voc_ids has been enqueued: the row bits are zero for the next build)
     if (copy_counters) HIP_TRY(hipMemcpyAsync(c->h_small, c->d_small, 64, hipMemcpyDeviceToHost, c->stream));
     return BFK_OK;
 }
@@ -1065,7 +1066,7 @@ static int ctx_size_pg(bfk_ctx *c, int recs, int key_bits, size_t *temp_bytes) {
         cap = 0; rc |= dev_realloc(&c->pg_keys, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_keys_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_keys_pm, &cap, total);
-        cap = 0; rc |= dev_realloc(&c->pg_rows, &cap, total);
+        // (pg_rows — the unsorted values — is gone: the sort's first pass works a record's (row, slot) out from its position)
         cap = 0; rc |= dev_realloc(&c->pg_rows_s, &cap, total);
         cap = 0; rc |= dev_realloc(&c->pg_srec, &cap, total + SIG_PAD_ROWS);
         cap = 0; rc |= dev_realloc(&c->pg_recpos, &cap, total);
@@ -1266,6 +1267,9 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
         // (at every size since the walk of labels-only steps is k_pgwalk16: 10k rows, max-dist 5: 0.35 ms without, 0.23 with)
         pl.pg_pb = pl.pg_tb + 3 <= 31 ? 3 : 0;
         if (const char *e = getenv("BFK_PG_POS")) pl.pg_pb = atoi(e) && pl.pg_tb + 3 <= 31 ? 3 : 0;
+        // SHORT records exist only for rows of <= 2 * max_dist tokens: a CSR without a row of <= 2 * PG_MAX_DIST (the bind counted
+        // them) sorts max_dist + 1 records per row instead of max_dist + 2 (the slot is the tail of the position-major input)
+        pl.pg_has_short = (c->n_short == 0 && pl.pg_pb && !(getenv("BFK_PG_SHORT") && atoi(getenv("BFK_PG_SHORT")) == 1)) ? 0 : 1;
         pl.pg_dense = c->max_tok >= 0 && c->max_tok < (1 << PG_CNT_BITS) ? 1 : 0;
         if (const char *e = getenv("BFK_PG_DENSE")) pl.pg_dense = pl.pg_dense && atoi(e) != 0;
         pl.pg_walk16 = 1;  // (BFK_PG_WALK16=0: a wave per row, k_pgjoin)

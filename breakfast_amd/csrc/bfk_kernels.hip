@@ -2121,7 +2121,7 @@ __global__ __launch_bounds__(256) void k_pgfreq(const int *__restrict__ indptr, 
 __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, const uint32_t *__restrict__ indices, int n, int recs,
                                                 int max_dist, int tb, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ keys,
                                                 uint32_t *__restrict__ keys_pm, int *__restrict__ rows_pm, int pm, int kcap,
-                                                int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr, int dense) {
+                                                int *__restrict__ parent, int4 *__restrict__ rowinfo, Counters *ctr, int dense, int has_short) {
     // A group takes PGK_ROWS consecutive rows and has the token loads of all of them in flight, then the count look-ups of all
     // of them: with one row per group a wave was three dependent loads and gone (190 us at 1M rows for 300 MB of traffic).
     constexpr int R = PGK_ROWS;
@@ -2209,26 +2209,34 @@ __global__ __launch_bounds__(256) void k_pgkeys(const int *__restrict__ indptr, 
         // (keys_pm[slot][row] with their (row, slot) values: the sort's input).  The sort is stable, so the group of a token comes
         // out as its records of slot 0 (rows ascending), then slot 1, ... — the order the positional filter of k_pgplace needs —
         // without a single key bit spent on the position.
+        // (keys == NULL: the walk of a labels-only step — k_pgwalk16<false> — never looks at the row-major records: 28 MB of
+        // 28-byte pieces at 1M rows, max_dist 5.  rows_pm == NULL: the value of a record is its position's (row, slot), which
+        // the sort's first pass works out from the position itself instead of loading it.)
         if (l16 < recs) {
             uint32_t key;
             if (l16 < pre) key = sel[q] != 0xFFFFFFFFu ? tinv - (sel[q] & ((1u << tb) - 1u)) + 1u : PG_NONE;
             // a row of max_dist elements or fewer can be within max_dist of a row it shares nothing with; then both have at most
             // 2 * max_dist elements: all of those meet in the group of the SHORT record (key 0, first in the order)
             else key = len <= 2 * max_dist ? 0u : PG_NONE;
-            keys[(size_t)r * recs + l16] = key;
+            if (keys) keys[(size_t)r * recs + l16] = key;
             // (pm = 0 — the positional filter is off: token ids that leave no room for the composite key — keeps the records in
             // row order, so that a group comes out with its rows ascending as the whole-group walk needs it)
             const size_t o = pm ? (size_t)l16 * n + r : (size_t)r * recs + l16;
-            keys_pm[o] = key;
-            rows_pm[o] = r * recs + l16;  // the sort carries (row, slot)
+            // (has_short = 0: the SHORT slot — the last n records of the position-major input — is not sorted at all)
+            if (has_short || l16 < pre) {
+                keys_pm[o] = key;
+                if (rows_pm) rows_pm[o] = r * recs + l16;  // the sort carries (row, slot)
+            }
         }
     }
 }
 
 // can the record in this slot of a row walk at all?  (slot recs - 1: the SHORT record; slot i < recs - 1: prefix position i, which
 // with the positional filter walks sub-groups i .. d - i: none when d - i < i)
-__device__ __forceinline__ bool pg_slot_walks(int slot, int recs, int pb, int max_dist) {
-    return slot == recs - 1 || !pb || max_dist - slot >= slot;
+// has_short = 0: no row of the CSR is short enough for a SHORT record — those records (all "no such record") are then not part
+// of the sorted order at all (a (d + 2)-th of the sort and of k_pgplace, a quarter at max_dist 2), and nobody walks from them
+__device__ __forceinline__ bool pg_slot_walks(int slot, int recs, int pb, int max_dist, int has_short) {
+    return slot == recs - 1 ? has_short != 0 : (!pb || max_dist - slot >= slot);
 }
 
 // one thread per position of the sorted records: for every record of a row where it went and how many positions behind it
@@ -2247,7 +2255,7 @@ __device__ __forceinline__ bool pg_slot_walks(int slot, int recs, int pb, int ma
 // decides by the records test for every candidate (k_pgjoin).
 __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ keys_s /*composite {key : slot}: the sort's last pass*/,
                                                  const int *__restrict__ vals_s, int total, int recs, const int4 *__restrict__ rowinfo,
-                                                 int4 *__restrict__ srec, int2 *__restrict__ recpos, Counters *ctr, int pb, int max_dist) {
+                                                 int4 *__restrict__ srec, int2 *__restrict__ recpos, Counters *ctr, int pb, int max_dist, int has_short) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     const uint32_t key = keys_s[p];
@@ -2285,7 +2293,7 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
     // (7M scattered 8-byte stores were 88 us of this kernel at 1M rows, max_dist 5: the records of positions i > d - i never
     // walk — pg_slot_walks, the walk does not read their entries — and are not stored)
     const int slot = v - row * recs;
-    if (pg_slot_walks(slot, recs, pb, max_dist)) recpos[v] = make_int2(p, behind);
+    if (pg_slot_walks(slot, recs, pb, max_dist, has_short)) recpos[v] = make_int2(p, behind);
     // every PG_EST_STRIDE-th position reports what k_pgjoin will walk from it, so that the walk can be called off when the
     // groups are too big
     if ((p & (PG_EST_STRIDE - 1)) == 0 && behind > 0) atomicAdd(&ctr->pg_est, (unsigned long long)behind);
@@ -2305,7 +2313,7 @@ __global__ __launch_bounds__(256) void k_pgplace(const uint32_t *__restrict__ ke
 // Work items are blocks of 64 rows (t_begin / t_end and the multi-GPU owner rule count in those).
 __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
                                                 const uint32_t *__restrict__ keys, const int4 *__restrict__ rowinfo, int n, int recs,
-                                                int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb) {
+                                                int total, int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb, int has_short) {
     constexpr int SCAP = 1024, WAVES = 4;
     // A token that many rows carry can still be among a row's first d + 1 (small alphabets, random rows): the groups are then a
     // large part of all rows and walking them is quadratic.  k_pgplace reported the walk from every PG_EST_STRIDE-th position
@@ -2411,7 +2419,7 @@ __global__ __launch_bounds__(256) void k_pgjoin(const int4 *__restrict__ srec, c
         const uint32_t key_j = __shfl(hd.key, slot_j);
         const int pos_j = __shfl(hd.pos.x, slot_j);
         const int beh_all = __shfl(hd.pos.y, slot_j);  // (unconditional: a lane that sits this out cannot be read from)
-        const int beh_j = (lane < recs && key_j != PG_NONE && pg_slot_walks(slot_j, recs, pb, d)) ? beh_all : 0;  // (other slots: no entry)
+        const int beh_j = (lane < recs && key_j != PG_NONE && pg_slot_walks(slot_j, recs, pb, d, has_short)) ? beh_all : 0;  // (other slots: no entry)
         const int incl_j = wave_incl_scan_add(beh_j);
         const int T = __builtin_amdgcn_readlane(incl_j, 63);
         if (T == 0) continue;
@@ -2595,7 +2603,7 @@ __device__ __forceinline__ int row16_incl_scan(int x) {  // inclusive prefix sum
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec, const int2 *__restrict__ recpos,
                                                   const int4 *__restrict__ rowinfo, const uint32_t *__restrict__ keys, int n, int recs,
-                                                  int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb) {
+                                                  int shard0, int nshards, int t_begin, int t_end, PairArgs pa, int pb, int has_short) {
     constexpr int WAVES = 4, GSET = 64, U = 4;
     if (pa.ctr->pg_est * (unsigned long long)PG_EST_STRIDE > (unsigned long long)PG_GIVE_UP * (unsigned long long)n) {
         if (blockIdx.x == 0 && threadIdx.x == 0) pa.ctr->pg_fail = 1;  // (groups too big to pay: the host redoes the step on the band kernels)
@@ -2679,7 +2687,7 @@ __global__ __launch_bounds__(256) void k_pgwalk16(const int4 *__restrict__ srec,
     bool active = at < v_end, fresh_row = active;
     // the head of the group's next row {its records' positions and counts, length, signature, offset} is asked for one row ahead
     const int slot = l16 == 0 ? recs - 1 : l16 - 1;
-    const bool walks = l16 < recs && pg_slot_walks(slot, recs, pb, pa.d);  // (k_pgplace stores only these records' entries)
+    const bool walks = l16 < recs && pg_slot_walks(slot, recs, pb, pa.d, has_short);  // (k_pgplace stores only these records' entries)
     int2 h_rp = make_int2(0, 0);
     int4 h_ri = make_int4(0, 0, 0, 0);
     uint32_t h_key = PG_NONE;
@@ -3095,13 +3103,13 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
             const int wblocks = std::max(1, std::min(pl.pf_blocks / 256 * wper, (int)std::min<long long>((long long)own_items * 4, 1 << 20)));
             if (pa.skip_connected)
                 hipLaunchKernelGGL(k_pgwalk16<false>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
-                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb, pl.pg_has_short);
             else
                 hipLaunchKernelGGL(k_pgwalk16<true>, dim3(wblocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_rowinfo, pl.pg_keys, n,
-                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
+                                   pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb, pl.pg_has_short);
         } else {
             hipLaunchKernelGGL(k_pgjoin, dim3(blocks), dim3(256), 0, st, pl.pg_srec, pl.pg_recpos, pl.pg_keys, pl.pg_rowinfo, n, pl.pg_recs,
-                               n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb);
+                               n * pl.pg_recs, pl.shard, pl.n_shards, t_begin, t_end, pa, pl.pg_pb, pl.pg_has_short);
         }
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
@@ -3177,22 +3185,24 @@ int launch_pipeline(const Plan &pl, hipStream_t st, hipEvent_t *ev /*5 or NULL*/
         return launch_flatten(pl, st, ev);
     }
     if (pl.pg) {  // prefix-group path: sampled token counts, records (+ signatures, forest, counters), sort, group order — none of the band kernels' prep
-        const int total = n * pl.pg_recs;
+        const int total = n * (pl.pg_has_short ? pl.pg_recs : pl.pg_recs - 1);  // records in the sorted order
         if (hipMemsetAsync(pl.pg_cnt, 0, sizeof(uint32_t) << PG_CNT_BITS, st) != hipSuccess) return (int)hipGetLastError();
         const int stride = std::max(1, n / 4096);  // ~4k sampled rows: the counts only have to tell common tokens from rare ones
         const int sampled = (n + stride - 1) / stride;
         hipLaunchKernelGGL(k_pgfreq, dim3((sampled + 63) / 64), dim3(256), 0, st, pl.indptr, pl.indices, n, stride, pl.pg_cnt, pl.ctr, pl.pg_dense);
         LAUNCH_CHECK();
+        const bool walk_reads_keys = !(pl.pg_walk16 && pl.skip_connected && !pl.edges);  // (k_pgjoin and the exact-edges walk do)
         hipLaunchKernelGGL(k_pgkeys, dim3((n + 16 * PGK_ROWS - 1) / (16 * PGK_ROWS)), dim3(256), 0, st, pl.indptr, pl.indices, n, pl.pg_recs, pl.d, pl.pg_tb, pl.pg_cnt,
-                           pl.pg_keys, pl.pg_keys_pm, pl.pg_rows, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr, pl.pg_dense);
+                           walk_reads_keys ? pl.pg_keys : (uint32_t *)nullptr, pl.pg_keys_pm, (int *)nullptr, pl.pg_pb ? 1 : 0, pl.kcap, pl.parent, pl.pg_rowinfo, pl.ctr, pl.pg_dense, pl.pg_has_short);
         LAUNCH_CHECK();
         size_t tb = pl.pg_temp_bytes;
         // (the sort's last pass leaves the composite {key : slot} the positional filter bisects on)
-        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys_pm, pl.pg_keys_s, pl.pg_rows, pl.pg_rows_s, (size_t)total, pl.pg_tb, st,
-                                 pl.pg_pb ? pl.pg_recs : 0, pl.pg_pb))
+        // (values: position p of the position-major input holds (row p % n, slot p / n); of the row-major one, p itself)
+        if (int e = sort_records(pl.pg_temp, &tb, pl.pg_keys_pm, pl.pg_keys_s, nullptr, pl.pg_rows_s, (size_t)total, pl.pg_tb, st,
+                                 pl.pg_pb ? pl.pg_recs : 0, pl.pg_pb, pl.pg_pb ? n : 0, pl.pg_recs))
             return e;
         hipLaunchKernelGGL(k_pgplace, dim3((total + 255) / 256), dim3(256), 0, st, pl.pg_keys_s, pl.pg_rows_s, total, pl.pg_recs, pl.pg_rowinfo,
-                           pl.pg_srec, pl.pg_recpos, pl.ctr, pl.pg_pb, pl.d);
+                           pl.pg_srec, pl.pg_recpos, pl.ctr, pl.pg_pb, pl.d, pl.pg_has_short);
         LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         if (int e = launch_pairs(pl, 0, 0x7FFFFFFF, st, ev)) return e;

@@ -87,7 +87,7 @@ template <int RB>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t n,
                                                            int shift, uint32_t n_blk, const uint32_t *__restrict__ hist,
                                                            const uint32_t *__restrict__ tot, uint32_t *__restrict__ keys_out,
-                                                           int *__restrict__ vals_out, int comp_recs, int comp_pb) {
+                                                           int *__restrict__ vals_out, int comp_recs, int comp_pb, uint32_t gen_n, int gen_recs) {
     constexpr int R = 1 << RB;
     __shared__ uint32_t s_run[R];             // first OUTPUT position of the block's records of every digit
     __shared__ uint32_t s_loc[R];             // first position of the digit inside the block's (digit-ordered) tile
@@ -184,7 +184,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (valid) {
             s_key[pos] = key[j];
-            s_val[pos] = vals[i];
+            // (vals == NULL, first pass: the value of input position i is worked out — (i % gen_n) * gen_recs + i / gen_n for a
+            // position-major input of gen_n rows, i itself otherwise — instead of being stored by the producer and loaded here)
+            s_val[pos] = vals ? vals[i] : (gen_n ? (int)((i % gen_n) * (uint32_t)gen_recs + i / gen_n) : (int)i);
         }
     }
     __syncthreads();
@@ -204,19 +206,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *__res
 
 template <int RB>
 int rs_pass(const uint32_t *kin, const int *vin, uint32_t *kout, int *vout, uint32_t n, int shift, uint32_t n_blk, uint32_t *hist,
-            uint32_t *tot, hipStream_t st, int comp_recs, int comp_pb) {
+            uint32_t *tot, hipStream_t st, int comp_recs, int comp_pb, uint32_t gen_n, int gen_recs) {
     hipLaunchKernelGGL(k_rs_count<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, n, shift, n_blk, hist);
     hipLaunchKernelGGL(k_rs_rowscan, dim3(1 << RB), dim3(64), 0, st, hist, n_blk, tot);
-    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, vin, n, shift, n_blk, hist, tot, kout, vout, comp_recs, comp_pb);
+    hipLaunchKernelGGL(k_rs_scatter<RB>, dim3(n_blk), dim3(RS_THREADS), 0, st, kin, vin, n, shift, n_blk, hist, tot, kout, vout, comp_recs, comp_pb, gen_n, gen_recs);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
 // temp == nullptr: only *temp_bytes is set.  Stable sort by key bits [0, bits); keys_in / rows_in stay intact.
-// comp_recs > 0: keys_out holds (key << comp_pb) | (row value % comp_recs) for every key but 0 and 0xFFFFFFFF.
+// rows_in == NULL: the values are the input positions (gen_n = 0) or, for a position-major input of gen_n rows, (p % gen_n) * gen_recs +
+// p / gen_n.  comp_recs > 0: keys_out holds (key << comp_pb) | (row value % comp_recs) for every key but 0 and 0xFFFFFFFF.
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,
-                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs, int comp_pb) {
+                 int *rows_out, size_t n, int bits, hipStream_t st, int comp_recs, int comp_pb, int gen_n, int gen_recs) {
     bits = bits < 1 ? 1 : (bits > 32 ? 32 : bits);
     const int passes = (bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
     const int rb = (bits + passes - 1) / passes;  // 1 .. 11
@@ -247,10 +250,10 @@ int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32
         int e = 0;
         switch (rb) {
             case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8:
-                e = rs_pass<8>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
-            case 9: e = rs_pass<9>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
-            case 10: e = rs_pass<10>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
-            default: e = rs_pass<11>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb); break;
+                e = rs_pass<8>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb, (uint32_t)gen_n, gen_recs); break;
+            case 9: e = rs_pass<9>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb, (uint32_t)gen_n, gen_recs); break;
+            case 10: e = rs_pass<10>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb, (uint32_t)gen_n, gen_recs); break;
+            default: e = rs_pass<11>(kin, vin, kout, vout, (uint32_t)n, p * rb, n_blk, hist, tot, st, last ? comp_recs : 0, comp_pb, (uint32_t)gen_n, gen_recs); break;
         }
         if (e) return e;
         kin = kout;

@@ -770,8 +770,12 @@ __global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
     }
     // the row-start bits have been used (k_tok_scan): cleared here, so that the NEXT build finds them zero and sets its own in
     // k_tok_clear — no k_tok_rowbits launch between the clearing and the scan (4.9 + 1.3 us of a 212 us step)
-    uint4 *rb4 = reinterpret_cast<uint4 *>(a.rowbits);
-    for (uint32_t i = tid, n16 = (a.T_pad / 32u + 16u) / 4u; i < n16; i += nth) rb4[i] = make_uint4(0u, 0u, 0u, 0u);
+    // (texts up to TOK_FUSE_ROWBITS_BYTES: beyond — 1M rows, 333 MB — the million atomics inside k_tok_clear and 41 MB of zeros
+    // here cost 7 us more than the launch they save)
+    if (a.rows_clear_after) {
+        uint4 *rb4 = reinterpret_cast<uint4 *>(a.rowbits);
+        for (uint32_t i = tid, n16 = (a.T_pad / 32u + 16u) / 4u; i < n16; i += nth) rb4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
