@@ -1022,8 +1022,18 @@ static int ctx_size_join(bfk_ctx *c) {
 //   300k    0.47 / 0.41    1.21 / 0.49    1.97 / 0.52    3.11 / 0.60
 //   1M      1.46 / 1.09    (4.5) / 1.23                  (21) / 1.79
 //   3M      6.30 / <4.5
-static int64_t PG_MIN_ROWS(int max_dist) {
-    return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : (max_dist == 3 ? 10000 : 250000));
+// round 4 (SHORT records left out of the sort where no row is short; tools/d2_crossover.py), max_dist 2, band / prefix groups:
+//   rows    default        aa (45 tokens) long (105 tokens per row)   star
+//   100k    0.18 / 0.23    0.20 / 0.24    0.17 / 0.27                 0.52 / 0.38
+//   200k    0.31 / 0.32    0.36 / 0.33    0.27 / 0.37                 0.88 / 0.61
+//   300k    0.46 / 0.40    0.55 / 0.41    0.37 / 0.44                 1.36 / 1.04
+// the groups' prep reads every token, the band's pair kernel does not care how long the rows are: the crossover moves up
+// with the mean row length (the star family — the band's queue takes ten times the candidates — would want the groups at
+// every size: known only after a step, not used)
+static int64_t PG_MIN_ROWS(int max_dist, int64_t n, int64_t nnz) {
+    if (max_dist >= 3) return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : 10000);
+    const int64_t mean_len = n > 0 ? nnz / n : 0;
+    return 200000 * std::max<int64_t>(50, mean_len) / 50;
 }
 
 static bool pg_wanted(const bfk_ctx *c, int max_dist, int n_shards) {
@@ -1035,7 +1045,7 @@ static bool pg_wanted(const bfk_ctx *c, int max_dist, int n_shards) {
     // a shard of a max-dist 2 step: the band kernels — their pair kernel is the step and shards, the groups' records and sort
     // are replicated on every rank (one-device rehearsal, 1M rows, 8 ranks: 0.50 ms band / 1.05 groups)
     if (n_shards > 1 && max_dist == 2) return false;
-    return c->n >= PG_MIN_ROWS(max_dist);
+    return c->n >= PG_MIN_ROWS(max_dist, c->n, c->nnz);
 }
 
 // the 32-bit record keys hold token + 1 (0: SHORT record, all ones: none): the largest token id of the CSR — one pass over

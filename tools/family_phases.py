@@ -6,6 +6,8 @@ fam, n, d = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 uf = list(dict.fromkeys(synth.generate_family(fam, n) if fam != "default" else synth.generate_profiles(n)))
 ip, ix, _ = _lib.build_csr(uf, " ")
 ctx = _lib.Context(0)
+if len(sys.argv) > 4:
+    ctx.set_candidate_path(sys.argv[4])
 ctx.upload_csr(ip, ix)
 d_out = ctx.alloc(4 * len(uf))
 ctx.cluster(d, d_out); ctx.sync()
