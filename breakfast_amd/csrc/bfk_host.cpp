@@ -107,6 +107,7 @@ struct bfk_ctx {
     int join_parity = 0;     // table set of the next step (the other one is cleared by that step)
     bool join_clear = true;  // both sets must be cleared before the next join step
     bool join_off = false;   // this CSR made the join give up once: all-pairs from now on
+    bool pg_dense_d2 = false;  // a max-dist 2 band step on this CSR queued > 8 candidates per row: prefix groups from now on
     bool pg_off = false;     // this CSR made the prefix groups give up once (groups too big): band kernels from now on
     int path_mode = 0;       // bfk_ctx_set_candidate_path: 0 auto, 1 all-pairs kernels, 2 variant join where it applies, 3 prefix groups
     // prefix-group path (max_dist >= 2, large inputs): sampled token counts, records, sorted records, group-order signatures, tiles
@@ -441,6 +442,7 @@ static int ctx_after_bind(bfk_ctx *c) {
     // k_jhash, the other one is clean — whatever CSR comes next; ctx_size_join asks for a clearing when their size changes)
     c->join_off = false;
     c->pg_off = false;
+    c->pg_dense_d2 = false;
     return ctx_size_workspace(c, 0);
 }
 
@@ -629,6 +631,7 @@ static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, i
     c->need_zero = true;  // bins are laid out by kcap
     c->join_off = false;
     c->pg_off = false;
+    c->pg_dense_d2 = false;
     c->tok_pending = false;
     if (int rc = ctx_size_workspace(c, 0)) return rc;
     if ((int64_t)(tp.flt.on ? tc.nnz_kept : tc.nnz) != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
@@ -700,6 +703,7 @@ static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_
     c->last_tiles = 0;
     c->join_off = false;
     c->pg_off = false;
+    c->pg_dense_d2 = false;
     c->need_zero = true;
     c->spec_enqueueing = true;  // (ctx_enqueue marks the plan device-driven by this)
     const int rc = ctx_enqueue(c, max_dist, 0, 1, d_labels_out, true);
@@ -1045,6 +1049,7 @@ static bool pg_wanted(const bfk_ctx *c, int max_dist, int n_shards) {
     // a shard of a max-dist 2 step: the band kernels — their pair kernel is the step and shards, the groups' records and sort
     // are replicated on every rank (one-device rehearsal, 1M rows, 8 ranks: 0.50 ms band / 1.05 groups)
     if (n_shards > 1 && max_dist == 2) return false;
+    if (max_dist == 2 && c->pg_dense_d2) return true;
     return c->n >= PG_MIN_ROWS(max_dist, c->n, c->nnz);
 }
 
@@ -1474,6 +1479,12 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         }
         if (!h.overflow)
             if (int rc = ctx_pair_stats(c, &h)) return rc;
+        // A max-dist 2 step on the band kernels whose queue took many candidates per row (a star-like phylogeny: hub profiles with
+        // thousands of neighbours; 20 per row against 2 on tree-like inputs): the prefix groups do such a CSR 1.2-1.45x faster at
+        // every size (tools/d2_crossover.py) — a property of the CSR that only a step reveals; later steps on it take them.
+        if (!c->plan.join && !c->plan.pg && c->last_d == 2 && c->last_shards == 1 && c->n >= 20000 && !h.overflow &&
+            (int64_t)h.n_cand_total > 8 * c->n)
+            c->pg_dense_d2 = true;
         if (h.overflow) {
             if (int rc = ctx_recover_overflow(c, &h, &retry_slices)) return rc;
             // the queue was too small for this input: double it so that the next run fits in one pass (not when

@@ -67,6 +67,38 @@ def test_dense_max_dist_2_graphs_are_verified_by_the_pruning_kernel_by_themselve
         ctx.close()
 
 
+def test_a_dense_max_dist_2_step_sends_the_next_ones_on_that_csr_to_the_prefix_groups():
+    """what only a step reveals: a band step at max-dist 2 that queued more than 8 candidates per row (star phylogeny) makes
+    the context take the prefix groups for the following steps on that CSR (1.2-1.45x faster there); a new bind starts over,
+    a forced generator is never overridden, the labels are the same either way"""
+    from breakfast_amd.synth import generate_family
+
+    uf = list(dict.fromkeys(generate_family("star", 60000)))
+    indptr, indices, _ = _lib.build_csr(uf, " ")
+    ctx = _lib.Context(0)
+    ctx.upload_csr(indptr, indices)
+    d_out = ctx.alloc(4 * len(uf))
+    ctx.cluster(2, d_out)
+    st1 = ctx.sync()
+    lab1 = ctx.download_i32(d_out, len(uf)).copy()
+    assert st1["path"] == 0 and st1["n_candidates"] > 8 * len(uf)
+    ctx.cluster(2, d_out)
+    st2 = ctx.sync()
+    assert st2["path"] == 2 and st2["n_retry_slices"] == 0 and np.array_equal(ctx.download_i32(d_out, len(uf)), lab1)
+    ctx.set_candidate_path("allpairs")  # forced: stays
+    ctx.cluster(2, d_out)
+    assert ctx.sync()["path"] == 0
+    ctx.set_candidate_path("auto")
+    sparse = list(dict.fromkeys(generate_profiles(30000)))
+    ip2, ix2, _ = _lib.build_csr(sparse, " ")
+    ctx.upload_csr(ip2, ix2)  # a new CSR: what the old one taught is gone
+    d2 = ctx.alloc(4 * len(sparse))
+    for _ in range(2):
+        ctx.cluster(2, d2)
+        assert ctx.sync()["path"] == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("generator", ["band", "prefix", "prefix_pos"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BFK_FUZZ_SEEDS", "4"))))
 def test_fuzz_vs_oracle_with_pruning(seed, generator, monkeypatch):
