@@ -1482,7 +1482,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
         // A max-dist 2 step on the band kernels whose queue took many candidates per row (a star-like phylogeny: hub profiles with
         // thousands of neighbours; 20 per row against 2 on tree-like inputs): the prefix groups do such a CSR 1.2-1.45x faster at
         // every size (tools/d2_crossover.py) — a property of the CSR that only a step reveals; later steps on it take them.
-        if (!c->plan.join && !c->plan.pg && c->last_d == 2 && c->last_shards == 1 && c->n >= 20000 && !h.overflow &&
+        if (!c->plan.join && !c->plan.pg && c->last_d == 2 && c->last_shards == 1 && c->n >= 10000 && !h.overflow &&
             (int64_t)h.n_cand_total > 8 * c->n)
             c->pg_dense_d2 = true;
         if (h.overflow) {
