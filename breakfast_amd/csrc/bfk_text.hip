@@ -779,16 +779,19 @@ __global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
+    // (grid-stride over the REAL token count: a grid sized by the most tokens the text can hold — T/2 + rows — was three
+    // quarters blocks that read the count and left)
     const uint32_t nnz = a.tc->nnz;
-    const uint32_t g0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (g0 >= nnz) return;
-    const uint4 s = *reinterpret_cast<const uint4 *>(a.tokslot + g0);
-    uint4 o;
-    o.x = (uint32_t)a.tabid[s.x];
-    o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y] : 0u;
-    o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z] : 0u;
-    o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w] : 0u;
-    *reinterpret_cast<uint4 *>(a.indices + g0) = o;
+    const uint32_t nth = gridDim.x * 256u * 4u;
+    for (uint32_t g0 = (blockIdx.x * 256u + threadIdx.x) * 4u; g0 < nnz; g0 += nth) {
+        const uint4 s = *reinterpret_cast<const uint4 *>(a.tokslot + g0);
+        uint4 o;
+        o.x = (uint32_t)a.tabid[s.x];
+        o.y = g0 + 1 < nnz ? (uint32_t)a.tabid[s.y] : 0u;
+        o.z = g0 + 2 < nnz ? (uint32_t)a.tabid[s.z] : 0u;
+        o.w = g0 + 3 < nnz ? (uint32_t)a.tabid[s.w] : 0u;
+        *reinterpret_cast<uint4 *>(a.indices + g0) = o;
+    }
 }
 
 // filter mode: the slots of ALL tokens lie in text order in `tokslot` (TOK_NONE where the filter dropped one); the CSR holds the
@@ -926,7 +929,7 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
     if (a.flt.on) {
         hipLaunchKernelGGL(k_tok_ids_kept, dim3((scan_blocks * UNITS_PER_BLK + 3) / 4), dim3(256), 0, st, a, scan_blocks * UNITS_PER_BLK);
     } else {
-        hipLaunchKernelGGL(k_tok_ids, dim3(std::max(1u, (unsigned)((a.nnz_cap + 1023) / 1024))), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_tok_ids, dim3(std::max(1u, (unsigned)std::min<long long>((a.nnz_cap + 1023) / 1024, 4096))), dim3(256), 0, st, a);
     }
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
