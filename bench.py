@@ -754,8 +754,9 @@ def main():
             },
             "roofline": roof,
             "phases_ms": {"tokeniser": tk, "clustering": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
-                          "note": "HIP events inside libbfk, median of 16 profiled steps; ms_hash includes k_tok_head (ms_head); the "
-                                  "rest of ms_per_step is the bind between the halves (one 64-byte D2H + wait) and launch gaps"},
+                          "note": "HIP events inside libbfk, median of 16 PROFILED steps (profiled steps are completed one at a "
+                                  "time: the host waits for the tokeniser's counters between the halves, which the timed "
+                                  "steps — device-driven at max-dist 1 — do not); ms_hash = the three k_tok_hash launches"},
             "counters": {kk: st[kk] for kk in ("pairs_in_band", "pairs_filtered", "n_candidates", "n_edges", "n_connected",
                                                "n_retry_slices", "n_work_items", "max_row_len")},
             "result": {"components": int(len(np.unique(labels))), "labels_crc": int(np.bitwise_xor.reduce(
