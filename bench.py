@@ -152,10 +152,12 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel: str, workload_key: str):
+def measured_traffic(kernel: str, workload_key: str, launches=None):
     """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this very build and
     workload (profiles/*_pmc_per_launch.json, separate --pmc passes).  bench.py cannot collect PMC counters on
-    itself; a file taken on other sources is not quoted (returns None)."""
+    itself; a file taken on other sources is not quoted (returns None).  `launches` = {instantiation: launches per step}:
+    the kernel runs as several instantiations / launches per step and the bytes of a STEP are wanted (the file holds the mean
+    per launch of every instantiation)."""
     import glob
 
     want = kernel_source_digest()
@@ -167,7 +169,16 @@ def measured_traffic(kernel: str, workload_key: str):
         meta = pm.get("_meta", {})
         if meta.get("source_digest") != want or meta.get("workload") != workload_key:
             continue
-        hit = [v for kk, v in pm.items() if kk.startswith(kernel) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        if launches:
+            per = {inst: [v for kk, v in pm.items() if kernel in kk and inst in kk and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+                   for inst in launches}
+            if not all(per.values()):
+                continue
+            f_kib = sum(launches[i] * per[i][0]["FETCH_SIZE"] for i in launches)
+            w_kib = sum(launches[i] * per[i][0]["WRITE_SIZE"] for i in launches)
+            hit = [{"FETCH_SIZE": f_kib, "WRITE_SIZE": w_kib}]
+        else:
+            hit = [v for kk, v in pm.items() if kk.startswith(kernel) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
         if hit:
             # FETCH_SIZE / WRITE_SIZE are KiB.  The guide's x2 note on FETCH_SIZE holds for 16-B-per-lane streaming
             # reads; both readings are given, `traffic` uses the uncorrected counter (lower bound) and says so.
@@ -175,7 +186,8 @@ def measured_traffic(kernel: str, workload_key: str):
                     "fetch_bytes": hit[0]["FETCH_SIZE"] * 1024.0, "write_bytes": hit[0]["WRITE_SIZE"] * 1024.0,
                     "fetch_bytes_x2": 2 * hit[0]["FETCH_SIZE"] * 1024.0,
                     "source": f"{os.path.basename(f)} (commit {meta.get('commit', '?')}, sources {want}): FETCH_SIZE + "
-                              f"WRITE_SIZE per launch, separate --pmc passes; counts Infinity-Cache hits too"}
+                              f"WRITE_SIZE per launch, separate --pmc passes; counts Infinity-Cache hits too" +
+                              (f"; summed over the launches of a step {launches}" if launches else "")}
     return None
 
 
@@ -686,10 +698,9 @@ def main():
         # the tokeniser's dominant kernel: every text byte once + one 4-byte slot per token written
         t_hash = max(tk["ms_hash"] - tk["ms_head"], 1e-6)
         tok_bytes = T + 4 * nnz
-        tok_tr = measured_traffic("bfk::k_tok_hash", wl_key) if world == 1 else None
-        if tok_tr:  # (the hash runs as THREE launches per step — first units, a sample, the rest: the PMC file holds the mean per launch)
-            tok_tr = {**{kk: (3 * v if isinstance(v, float) else v) for kk, v in tok_tr.items()},
-                      "source": tok_tr["source"] + "; x 3 launches of k_tok_hash per step"}
+        # (the hash runs as THREE launches per step — the head, a wave per 1 KiB window: k_tok_hash<1>; a sample and the rest, a wave
+        # per 4 KiB unit: k_tok_hash<4> twice)
+        tok_tr = measured_traffic("bfk::k_tok_hash", wl_key, {"<1>": 1, "<4>": 2}) if world == 1 else None
         roof_tok = {"bound": "hbm", "kernel": "k_tok_hash (its three launches of a step together)",
                     "achieved": tok_bytes / (t_hash * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": tok_bytes / (t_hash * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -199,6 +199,7 @@ struct TokArgs {
     long long nnz_cap;         // upper bound of the token count the buffers are sized for
     int rows_clear_after;      // k_voc_ids clears the row-start bits for the next build (texts up to TOK_FUSE_ROWBITS_BYTES)
     int rows_fused;            // the row-start bits were set by k_tok_clear (no k_tok_rowbits launch)
+    int fine_head;             // bit 0: the head launch of the hash takes a wave per 1 KiB window instead of per 4 KiB unit; bit 1: the sample launch too
     int head_units;            // > 0: k_tok_hash runs the first so many units in a launch of their own before the rest
     int sample;                // > 1: then every sample-th unit, then the others (three launches in all)
     int dbg;                   // BFK_TOK_DEBUG (timing experiments, results invalid): 1 no atomicMin of a found token's first offset,

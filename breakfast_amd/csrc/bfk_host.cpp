@@ -575,6 +575,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
                                      (uint32_t)(T_pad + TOK_TEXT_SLACK - T), (uint8_t)tp.sep, c->d_small, c->stream, rows))
             return fail(BFK_EHIP, std::string("k_tok_clear launch: ") + hipGetErrorString((hipError_t)e));
     }
+    a.fine_head = getenv("BFK_TOK_FINE") ? atoi(getenv("BFK_TOK_FINE")) : 1;
     a.head_units = getenv("BFK_TOK_HEAD_UNITS") ? atoi(getenv("BFK_TOK_HEAD_UNITS")) : 16;
     a.sample = getenv("BFK_TOK_SAMPLE") ? atoi(getenv("BFK_TOK_SAMPLE")) : 16;
     // (a second attempt — the table grew — finds the text resident: no pieces to wait for)

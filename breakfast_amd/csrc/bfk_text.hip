@@ -461,36 +461,40 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
 // bits with scattered global loads and compared them with the bytes of the entry's first occurrence, somewhere in the text:
 // three dependent round trips per token instead of one; 101 us at 100k rows.)
 // masks: start / bound masks of the unit's four windows per lane (from k_tok_scan's arrays, or computed by the caller).
-__device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, TokUnitLds &s, const uint4 (&v)[TOK_WPW],
-                                              const uint32_t (&st)[TOK_WPW], const uint32_t (&bd)[TOK_WPW], uint32_t g0) {
+// WPW = windows the wave takes: TOK_WPW (a whole unit), or 1 — the first launches of a build run with most of the chip idle and
+// cost one wave's latency each (~19 us for a 4 KiB unit of new tokens: nine rounds of the deferred phase): in the HEAD launch a
+// unit is split over four waves (19.5 -> 15 us).  (The sample launch too: 18.3 -> 13.9 us on the benchmark generator, but its
+// 1 900 waves then storm among themselves on inputs whose common tokens appear late — forest 115 -> 142 us, sorted 101 -> 121:
+// TokArgs::fine_head bit 1, off.)
+template <int WPW>
+__device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t win0, TokUnitLds &s, const uint4 (&v)[WPW],
+                                              const uint32_t (&st)[WPW], const uint32_t (&bd)[WPW], uint32_t g0) {
     const int lane = threadIdx.x & 63;
-    const uint32_t text0 = unit * TOK_WPW * TOK_WIN;
+    const uint32_t text0 = win0 * TOK_WIN;
 #pragma unroll
-    for (int u = 0; u < TOK_WPW; u++) {
+    for (int u = 0; u < WPW; u++) {
         *reinterpret_cast<uint4 *>(&s.text[u * (TOK_WIN / 4) + 4 * lane]) = v[u];
         reinterpret_cast<uint16_t *>(s.bound)[u * (TOK_WIN / 16) + lane] = (uint16_t)bd[u];
     }
-    if (a.flt.on) {
-        s.kept[lane] = 0u;
-        s.kept[64 + lane] = 0u;
-    }
-    if (lane < 4) s.text[TOK_WPW * TOK_WIN / 4 + lane] = ldu32(a.text + text0 + TOK_WPW * TOK_WIN + 4 * lane);
-    if (lane < 2) s.bound[TOK_WPW * TOK_WIN / 32 + lane] = a.boundbits[(text0 + TOK_WPW * TOK_WIN) / 32 + lane];
-    int cnt[TOK_WPW], inc[TOK_WPW];
+    if (a.flt.on)
+        for (int i = lane; i < WPW * TOK_WIN / 32; i += 64) s.kept[i] = 0u;
+    if (lane < 4) s.text[WPW * TOK_WIN / 4 + lane] = ldu32(a.text + text0 + WPW * TOK_WIN + 4 * lane);
+    if (lane < 2) s.bound[WPW * TOK_WIN / 32 + lane] = a.boundbits[(text0 + WPW * TOK_WIN) / 32 + lane];
+    int cnt[WPW], inc[WPW];
     uint32_t total = 0;
 #pragma unroll
-    for (int u = 0; u < TOK_WPW; u++) {
+    for (int u = 0; u < WPW; u++) {
         cnt[u] = __popc(st[u]);
         inc[u] = tok_wave_incl_scan(cnt[u]);
         total += (uint32_t)__builtin_amdgcn_readlane(inc[u], 63);
     }
     // the list holds TOK_LIST_CAP starts: a unit with more (rows of a byte or two) is taken one window at a time
-    const int n_sub = total <= TOK_LIST_CAP ? 1 : TOK_WPW;
+    const int n_sub = total <= TOK_LIST_CAP ? 1 : WPW;
     uint32_t done = 0;
     for (int sub = 0; sub < n_sub; sub++) {
         uint32_t n_tok = 0;
 #pragma unroll
-        for (int u = 0; u < TOK_WPW; u++) {
+        for (int u = 0; u < WPW; u++) {
             if (n_sub > 1 && u != sub) continue;
             uint32_t o = n_tok + (uint32_t)(inc[u] - cnt[u]);
             for (uint32_t b = st[u]; b; b &= b - 1) s.list[o++] = (uint16_t)(u * TOK_WIN + 16 * lane + __builtin_ctz(b));
@@ -507,10 +511,8 @@ __device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t unit, T
         __builtin_amdgcn_wave_barrier();  // (the next sub-unit overwrites the list)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (a.flt.on) {  // the unit's kept-token bits: 128 words, two per lane, coalesced
-        a.keptbits[text0 / 32 + lane] = s.kept[lane];
-        a.keptbits[text0 / 32 + 64 + lane] = s.kept[64 + lane];
-    }
+    if (a.flt.on)  // the kept-token bits of the wave's windows: 32 words per window, coalesced
+        for (int i = lane; i < WPW * TOK_WIN / 32; i += 64) a.keptbits[text0 / 32 + i] = s.kept[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,11 +559,12 @@ __global__ __launch_bounds__(1024) void k_tok_scan(TokArgs a, uint32_t blk0) {
 // of what earlier calls scanned: the text arrives in pieces and every piece is scanned when it is there): data[i] = *total +
 // sum of data[0 .. i), then data[n] = *total = the new running sum.  Thread t owns a contiguous piece (a multiple of 4
 // values: 16-byte loads and stores; `data` 16-byte aligned).
-__global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n, unsigned *total_out) {
-    __shared__ unsigned s_w[16];
+template <int THREADS>
+__device__ __forceinline__ void tok_scan_block(uint32_t *data, uint32_t n, unsigned *total_out) {
+    __shared__ unsigned s_w[THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned carry = *total_out;  // (read by every thread before the barrier below, written by thread 0 after it)
-    const uint32_t per = ((n + 1023u) / 1024u + 3u) & ~3u;
+    const uint32_t per = ((n + THREADS - 1u) / THREADS + 3u) & ~3u;
     const uint32_t b = min(n, threadIdx.x * per), e = min(n, b + per);
     unsigned sum = 0;
     uint32_t i = b;
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n
     __syncthreads();
     unsigned run = carry + inc - sum;
     unsigned total = carry;
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < THREADS / 64; w++) {
         if (w < wave) run += s_w[w];
         total += s_w[w];
     }
@@ -598,33 +601,45 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n
     }
 }
 
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t *data, uint32_t n, unsigned *total_out) { tok_scan_block<1024>(data, n, total_out); }
+
 // ------------------------------------------------------------------------------------------------
 // Units [unit0, n_units).  sample = 0: all of them, in order.  sample = S > 1, part 0: every S-th unit (unit0, unit0 + S, ...);
 // part 1: the others.  (The hash runs in THREE launches — the first units, a sample spread over the text, the rest: when all
 // 8 000 waves start at once, every token that many rows carry is met by thousands of waves while its slot is still free, and
 // each of them claims it by compare-and-swap: same-address atomics serialise at ~11 ns.  The waves of the earlier launches are
 // few, and what they insert the later ones find by a plain load.)
-__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units, uint32_t sample, uint32_t part) {
+// scan_n > 0 (the HEAD launch of a build: units of the first 64 KiB, which need no prefix over the blocks): the launch's LAST block
+// is not a hash block — it turns the blocks' token totals into prefixes (what a k_scan_single launch of its own did between
+// k_tok_scan and the hash: ~5 us of stream time; here it is under the head's 15).
+template <int WPW>
+__global__ __launch_bounds__(256) void k_tok_hash(TokArgs a, uint32_t unit0, uint32_t n_units, uint32_t sample, uint32_t part, uint32_t scan_n) {
     __shared__ TokUnitLds s_unit[4];
+    if (scan_n && blockIdx.x == gridDim.x - 1) {  // (block-uniform)
+        tok_scan_block<256>(a.blkbase, scan_n, &a.tc->nnz);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t idx = (uint32_t)blockIdx.x * 4 + wave;
+    constexpr uint32_t SPLIT = TOK_WPW / WPW;  // waves per unit
+    const uint32_t widx = (uint32_t)blockIdx.x * 4 + wave, idx = widx / SPLIT;
     uint32_t unit;
     if (sample <= 1) unit = unit0 + idx;
     else if (part == 0) unit = unit0 + idx * sample;
     else unit = unit0 + (idx / (sample - 1)) * sample + idx % (sample - 1) + 1;
     if (unit >= n_units) return;
-    const uint32_t win0 = unit * TOK_WPW;
-    uint4 v[TOK_WPW];
-    uint32_t st[TOK_WPW], bd[TOK_WPW];
+    const uint32_t win0 = unit * TOK_WPW + (widx % SPLIT) * WPW;
+    uint4 v[WPW];
+    uint32_t st[WPW], bd[WPW];
 #pragma unroll
-    for (int u = 0; u < TOK_WPW; u++) {
+    for (int u = 0; u < WPW; u++) {
         v[u] = *reinterpret_cast<const uint4 *>(a.text + (win0 + u) * TOK_WIN + 16 * lane);
         st[u] = reinterpret_cast<const uint16_t *>(a.startbits)[(win0 + u) * (TOK_WIN / 16) + lane];
         bd[u] = reinterpret_cast<const uint16_t *>(a.boundbits)[(win0 + u) * (TOK_WIN / 16) + lane];
     }
-    const uint32_t g0 = a.blkbase[win0 / TOK_SCAN_WINS] + a.winbase[win0];  // (a unit lies in one scan block)
-    tok_hash_unit(a, unit, s_unit[wave], v, st, bd, g0);
+    // (a unit lies in one scan block; scan_n: the units of this launch lie in block 0, whose prefix — being computed next door — is 0)
+    const uint32_t g0 = (scan_n ? 0u : a.blkbase[win0 / TOK_SCAN_WINS]) + a.winbase[win0];
+    tok_hash_unit<WPW>(a, win0, s_unit[wave], v, st, bd, g0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,14 +771,38 @@ __global__ __launch_bounds__(512) void k_voc_count(const uint32_t *__restrict__ 
 }
 
 // one thread per slot in use: id = first occurrences in front of its offset
-__global__ __launch_bounds__(256) void k_voc_ids(TokArgs a) {
+// voc_scan_n > 0 (texts up to TOK_FUSE_ROWBITS_BYTES: at most 1024 scan blocks): `vocblk` holds the blocks' TOTALS as k_voc_count
+// left them, and every block of this kernel turns them into prefixes for itself, in LDS (a few KB of L2 hits per block) — no
+// one-block k_scan_single launch between the two (~5 us of stream time); block 0 leaves the grand total in tc->n_vocab.
+__global__ __launch_bounds__(256) void k_voc_ids(TokArgs a, uint32_t voc_scan_n) {
+    __shared__ uint32_t s_blk[1024];
+    __shared__ unsigned s_w4[4];
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+    if (voc_scan_n) {  // (block-uniform) thread t owns totals [4t, 4t + 4)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = 4u * threadIdx.x + j < voc_scan_n ? a.vocblk[4u * threadIdx.x + j] : 0u;
+        const uint32_t sum = x[0] + x[1] + x[2] + x[3];
+        const uint32_t inc = (uint32_t)tok_wave_incl_scan((int)sum);
+        if (lane == 63) s_w4[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w = 0; w < wave; w++) run += s_w4[w];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s_blk[4 * threadIdx.x + j] = run;
+            run += x[j];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 255) a.tc->n_vocab = run;  // (the last thread's run is the sum of everything)
+        __syncthreads();
+    }
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
         const TokSlot e = a.table[s];
         if (e.key == TOK_EMPTY) continue;
         const uint32_t o = tok_entry_offset(e);
         const uint32_t w = o / TOK_WIN;
-        uint32_t cnt = a.vocblk[w / TOK_SCAN_WINS] + a.vocwin[w];
+        uint32_t cnt = (voc_scan_n ? s_blk[w / TOK_SCAN_WINS] : a.vocblk[w / TOK_SCAN_WINS]) + a.vocwin[w];
         for (uint32_t q = w * (TOK_WIN / 32); q < (o >> 5); q++) cnt += (uint32_t)__popc(a.firstbits[q]);
         cnt += (uint32_t)__popc(a.firstbits[o >> 5] & ((1u << (o & 31u)) - 1u));
         a.tabid[s] = (int)cnt;  // (an array of its own: k_tok_ids gathers from 4 bytes per slot, not from the 16-byte slots)
@@ -871,11 +910,17 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
     for (int k = 0; k < n_pieces; k++) {
         const unsigned b0 = n_pieces > 1 ? piece_blk[k] : 0u, b1 = n_pieces > 1 ? piece_blk[k + 1] : scan_blocks;
         if (piece_ev && hipStreamWaitEvent(st, piece_ev[k], 0) != hipSuccess) return (int)hipGetLastError();
+        // the prefix over the blocks' token totals: a block of the head launch where there is one (the whole text in one piece, a
+        // head inside the first scan block), a launch of its own otherwise
+        const bool scan_in_head = n_pieces == 1 && a.head_units > 0 && (unsigned)a.head_units <= UNITS_PER_BLK &&
+                                  scan_blocks * UNITS_PER_BLK > (unsigned)a.head_units && scan_blocks <= 16384 && !(a.dbg & 64);
         if (b1 > b0) {
             hipLaunchKernelGGL(k_tok_scan, dim3(b1 - b0), dim3(1024), 0, st, a, b0);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase + b0, b1 - b0, &a.tc->nnz);
-            LAUNCH_CHECK();
+            if (!scan_in_head) {
+                hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.blkbase + b0, b1 - b0, &a.tc->nnz);
+                LAUNCH_CHECK();
+            }
         }
         if (ev && k == 0) {
             (void)hipEventRecord(ev[1], st);
@@ -889,19 +934,22 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
         unsigned uh = u0;
         if (k == 0 && a.head_units > 0 && u1 > u0 + (unsigned)a.head_units) {  // the first units by themselves
             uh = u0 + (unsigned)a.head_units;
-            hipLaunchKernelGGL(k_tok_hash, dim3((uh - u0 + 3) / 4), dim3(256), 0, st, a, u0, uh, 0u, 0u);
+            const unsigned sn = scan_in_head ? scan_blocks : 0u, extra = scan_in_head ? 1u : 0u;
+            if (a.fine_head & 1) hipLaunchKernelGGL(k_tok_hash<1>, dim3(uh - u0 + extra), dim3(256), 0, st, a, u0, uh, 0u, 0u, sn);  // (a wave per window)
+            else hipLaunchKernelGGL(k_tok_hash<TOK_WPW>, dim3((uh - u0 + 3) / 4 + extra), dim3(256), 0, st, a, u0, uh, 0u, 0u, sn);
             LAUNCH_CHECK();
         }
         if (u1 > uh) {
             const unsigned cnt = u1 - uh, S = (unsigned)a.sample;
             if (S > 1 && cnt >= 4 * S) {  // a sample spread over the text, then the rest
                 const unsigned n0 = (cnt + S - 1) / S, n1 = cnt - n0;
-                hipLaunchKernelGGL(k_tok_hash, dim3((n0 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 0u);
+                if (a.fine_head & 2) hipLaunchKernelGGL(k_tok_hash<1>, dim3(n0), dim3(256), 0, st, a, uh, u1, S, 0u, 0u);
+                else hipLaunchKernelGGL(k_tok_hash<TOK_WPW>, dim3((n0 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 0u, 0u);
                 LAUNCH_CHECK();
-                hipLaunchKernelGGL(k_tok_hash, dim3((n1 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 1u);
+                hipLaunchKernelGGL(k_tok_hash<TOK_WPW>, dim3((n1 + 3) / 4), dim3(256), 0, st, a, uh, u1, S, 1u, 0u);
                 LAUNCH_CHECK();
             } else {
-                hipLaunchKernelGGL(k_tok_hash, dim3((cnt + 3) / 4), dim3(256), 0, st, a, uh, u1, 0u, 0u);
+                hipLaunchKernelGGL(k_tok_hash<TOK_WPW>, dim3((cnt + 3) / 4), dim3(256), 0, st, a, uh, u1, 0u, 0u, 0u);
                 LAUNCH_CHECK();
             }
         }
@@ -922,9 +970,12 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a.firstbits, a.vocwin, a.vocblk);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.vocblk, scan_blocks, &a.tc->n_vocab);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_voc_ids, dim3(table_blocks), dim3(256), 0, st, a);
+    const bool voc_scan_in_ids = scan_blocks <= 1024 && !(a.dbg & 64);
+    if (!voc_scan_in_ids) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.vocblk, scan_blocks, &a.tc->n_vocab);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_voc_ids, dim3(table_blocks), dim3(256), 0, st, a, voc_scan_in_ids ? scan_blocks : 0u);
     LAUNCH_CHECK();
     if (a.flt.on) {
         hipLaunchKernelGGL(k_tok_ids_kept, dim3((scan_blocks * UNITS_PER_BLK + 3) / 4), dim3(256), 0, st, a, scan_blocks * UNITS_PER_BLK);
