@@ -1,6 +1,7 @@
 """One-off extended fuzz sweep (more seeds than the test suite runs): device tokeniser, fused text -> labels, the clustering
 kernels with every candidate generator, and the device prepare, each against the oracle / the host stage.
-Run on a GPU box:  python tools/fuzz_sweep.py [first_seed] [n_seeds]"""
+Run on a GPU box:  python tests/fuzz_sweep.py [first_seed] [n_seeds]   (not collected by pytest; lives here because only tests/
+may use the oracle)"""
 import os
 import sys
 from pathlib import Path
@@ -9,7 +10,7 @@ import numpy as np
 
 root = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(root))
-sys.path.insert(0, str(root / "tests"))
+sys.path.insert(0, str(root / "tests"))  # (conftest helpers and the fuzz generators of the suite)
 from oracle import ref_port as orc  # noqa: E402
 from test_frontend import OPTS, _fuzz_tokens  # noqa: E402
 from test_gpu_parity import fuzz_case  # noqa: E402
