@@ -522,6 +522,9 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     // resident text
     int64_t slots = 1 << 16;
     while (slots < nnz_cap / 32) slots <<= 1;
+    // (a big table is walked three times and gathered from once per token: from 8M slots on half of that rule — 1M rows: 4M slots
+    // for 1.4M entries, hash + 5 us, the walks and the gather - 29 us; 100k rows, 512k slots: halving loses 1.4 us)
+    if (slots >= ((int64_t)8 << 20) && c->tk_grow == 0) slots >>= 1;
     slots <<= 3 * c->tk_grow;
     if (const char *e = getenv("BFK_TOK_SLOTS_SHIFT")) slots = atoi(e) >= 0 ? slots << atoi(e) : std::max<int64_t>(1 << 12, slots >> -atoi(e));  // (experiments)
     if (slots > ((int64_t)1 << 31)) slots = (int64_t)1 << 31;
@@ -577,7 +580,12 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     }
     a.fine_head = getenv("BFK_TOK_FINE") ? atoi(getenv("BFK_TOK_FINE")) : 1;
     a.head_units = getenv("BFK_TOK_HEAD_UNITS") ? atoi(getenv("BFK_TOK_HEAD_UNITS")) : 16;
-    a.sample = getenv("BFK_TOK_SAMPLE") ? atoi(getenv("BFK_TOK_SAMPLE")) : 16;
+    // the sample launch should stay a few hundred to a thousand waves whatever the text size (its waves must not storm among
+    // themselves): every 16th unit up to ~130 MB, then a stride that grows with the text — 1M rows (81k units): 64, measured
+    // against 16 on three input shapes: tree 336 -> 322 us, forest 608 -> 496, sorted 406 -> 340 (tools/tok_split_ab.sh)
+    int sample = 16;
+    while (sample < 256 && (T_pad / (TOK_WPW * TOK_WIN)) / 1000 >= 2 * sample) sample *= 2;
+    a.sample = getenv("BFK_TOK_SAMPLE") ? atoi(getenv("BFK_TOK_SAMPLE")) : sample;
     // (a second attempt — the table grew — finds the text resident: no pieces to wait for)
     const bool pieces = tp.n_pieces > 1 && attempt == 0;
     if (int e = launch_tokenize(a, c->stream, ev, pieces ? tp.n_pieces : 1, tp.piece_blk, pieces ? c->tk_piece_ev : nullptr))
