@@ -987,7 +987,9 @@ static bool join_wanted(const bfk_ctx *c, int max_dist) {
     // 0.51 / 1.47 (the hubs' neighbours fill a few cells of the band kernels' sort key: tiles of thousands of rows).  Hence the
     // join beyond 800k rows too while rows are short — it never loses much there and is the one the hubs do not hurt.
     if (c->n <= 800000) return true;
-    return c->n <= 1200000 && c->nnz <= 64 * c->n;
+    // (with the filter bitmap capped at 2 MB the join stays ahead of the band kernels up to 2M short rows — 1.5M: 0.702 / 0.726 ms,
+    // 2M: 0.957 / 0.997; beyond, 8 bits per row no longer fit the cap)
+    return c->n <= 2000000 && c->nnz <= 64 * c->n;
 }
 
 static int ctx_size_join(bfk_ctx *c) {

@@ -107,7 +107,7 @@ def test_config3_one_million_rows_max_dist_1(million):
     uf, indptr, indices = _csr(million)
     assert len(uf) > 990_000
     l1, st1 = _lib.cluster_csr(indptr, indices, 1)
-    assert st1["path"] == 1                 # short rows: the variant join up to 1.2M rows (round 4; the band kernels beyond)
+    assert st1["path"] == 1                 # short rows: the variant join up to 2M rows (round 4; the band kernels beyond)
     assert st1["n_retry_slices"] == 0
     assert st1["pairs_resolved"] == len(uf) * (len(uf) - 1) // 2
     _check_fix_point(l1)
