@@ -332,6 +332,73 @@ __device__ __forceinline__ bool tok_key_at(const TokUnitLds &s, uint32_t pos, un
     return (win & 0x7Fu) != 0u;  // the token ends within 7 bytes
 }
 
+// unaligned 32 bits of the staged text at byte `pos`
+__device__ __forceinline__ uint32_t tok_lds_u32(const TokUnitLds &s, uint32_t pos) {
+    return __builtin_amdgcn_alignbyte(s.text[(pos >> 2) + 1], s.text[pos >> 2], pos & 3u);
+}
+
+// A MEDIUM token — 8 .. TOK_MED_LEN bytes, all of them inside the staged text (unit + 16 bytes): insertions, del:11288:9,
+// amino-acid mutations.  tok_long for such a token without its first three dependent global round trips: the end from the
+// staged bound bits, the filter's verdict and the hash (the same hash) from the staged bytes; what is left is the probe chain —
+// slot, slot again past the caches, the entry's bytes — as long as a deferred short token's.  (Every token of 8+ bytes through
+// tok_long made a text with 6 % such tokens 44 % slower to hash: 1M rows with indels 384 us against 266.)
+// -> false: not a medium token (tok_long takes it).
+constexpr uint32_t TOK_MED_LEN = 24;
+__device__ __forceinline__ bool tok_medium(const TokArgs &a, const TokUnitLds &s, uint32_t pos, uint32_t staged, uint32_t j, uint32_t *slot_out,
+                                           bool *invalid) {
+    const uint32_t bi = pos + 1;
+    const uint32_t win = __builtin_amdgcn_alignbit(s.bound[(bi >> 5) + 1], s.bound[bi >> 5], bi & 31u);  // bound bits of bytes pos+1 ..
+    if (win == 0u) return false;  // longer than 32 bytes
+    const uint32_t len = (uint32_t)__builtin_ctz(win) + 1u;
+    if (len < 8u || len > TOK_MED_LEN || pos + len > staged) return false;
+    if (a.flt.on) {
+        const int v = tok_classify(a.flt, len, [&](uint32_t i) { return (tok_lds_u32(s, pos + (i & ~3u)) >> (8 * (i & 3u))) & 0xFFu; });
+        if (v != TOKV_KEEP) {
+            *invalid = v == TOKV_INVALID;
+            *slot_out = TOK_NONE;
+            return true;
+        }
+    }
+    uint32_t h = 0x9747B28Cu ^ len, k = 0;
+    for (; k + 4 <= len; k += 4) h = mur_step(h, tok_lds_u32(s, pos + k));
+    if (len & 3u) h = mur_step(h, tok_lds_u32(s, pos + k) & ((1u << (8 * (len & 3u))) - 1u));
+    h = mur_final(h);
+    const uint32_t hi = 0x80000000u | (h & 0x7FFF0000u) | (len & 0xFFFFu);  // 1 : tag15 : len16 (tok_long's word)
+    const unsigned long long me = ((unsigned long long)hi << 32) | j;
+    uint32_t slot = h & a.tmask;
+    for (int probes = 0;; probes++) {
+        unsigned long long cur = a.table[slot].key;
+        if (cur == TOK_EMPTY || (uint32_t)(cur >> 32) == hi)  // free, or maybe this token: the state past the caches (the offset moves)
+            cur = __hip_atomic_load(&a.table[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cur == TOK_EMPTY) {
+            cur = atomicCAS(&a.table[slot].key, TOK_EMPTY, me);
+            if (cur == TOK_EMPTY) break;
+        }
+        if ((uint32_t)(cur >> 32) == hi) {
+            bool same = (uint32_t)cur == j;
+            if (!same) {  // the entry's occurrence (global) against this one (staged)
+                const uint8_t *e = a.text + (uint32_t)cur;
+                uint32_t diff = 0;
+                for (k = 0; k + 4 <= len; k += 4) diff |= ldu32(e + k) ^ tok_lds_u32(s, pos + k);
+                if (len & 3u) diff |= (ldu32(e + k) ^ tok_lds_u32(s, pos + k)) & ((1u << (8 * (len & 3u))) - 1u);
+                same = diff == 0u;
+            }
+            if (same) {
+                if ((uint32_t)cur > j) atomicMin(&a.table[slot].key, me);
+                break;
+            }
+        }
+        if (probes >= TOK_MAX_PROBE) {
+            atomicOr(&a.tc->fail, TOK_FAIL_TABLE);
+            slot = 0;
+            break;
+        }
+        slot = (slot + 1) & a.tmask;
+    }
+    *slot_out = slot;
+    return true;
+}
+
 // Tokens [0, n_tok) of the list -> table; the slot of token t is stored at out[t].
 // Phase 1, U tokens per lane and round: all their LDS reads, then all their table slots — ONE 16-byte plain load each — in
 // flight together; a token whose slot shows its key is settled there (its first offset lowered when this occurrence is
@@ -341,7 +408,7 @@ __device__ __forceinline__ bool tok_key_at(const TokUnitLds &s, uint32_t pos, un
 // Phase 2: the deferred tokens, 64 at a time, through the probe chain that reads past the caches.  (Settling them inside
 // the rounds made every round as long as its slowest lane's chain — plain load, load past the caches, compare-and-swap,
 // offset: 100 us at 100k rows against 30 for the rounds alone.)
-__device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s, uint32_t text0, uint32_t n_tok, uint32_t *out) {
+__device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s, uint32_t text0, uint32_t n_tok, uint32_t *out, uint32_t staged) {
     constexpr int U = TOK_LOOKUP_U;
     const int lane = threadIdx.x & 63;
     uint32_t n_pend = 0;
@@ -412,7 +479,7 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
         uint32_t sl;
         if (!inl) {
             bool inval = false;
-            sl = tok_long(a, j, &inval);
+            if ((a.dbg & 8) || !tok_medium(a, s, pos, staged, j, &sl, &inval)) sl = tok_long(a, j, &inval);
             n_inval += inval ? 1u : 0u;
         } else {
             uint32_t slot = tok_hash_inline(key) & a.tmask;
@@ -503,7 +570,7 @@ __device__ __forceinline__ void tok_hash_unit(const TokArgs &a, uint32_t win0, T
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!(a.dbg & 4)) tok_unit_lookup(a, s, text0, n_tok, a.tokslot + g0 + done);
+        if (!(a.dbg & 4)) tok_unit_lookup(a, s, text0, n_tok, a.tokslot + g0 + done, (uint32_t)(WPW * TOK_WIN + 16));
         else  // (timing experiment: a defined slot for every token all the same — k_tok_ids follows them)
             for (uint32_t t = threadIdx.x & 63; t < n_tok; t += 64) a.tokslot[g0 + done + t] = 0u;
         done += n_tok;
