@@ -702,7 +702,7 @@ def main():
             roof_cluster["groups"] = {"members_visited": st["pairs_filtered"], "candidates": st["n_candidates"], "edges_checked": st["n_edges"],
                                       "dropped_as_connected": st.get("n_connected", 0)}
         # the tokeniser's dominant kernel: every text byte once + one 4-byte slot per token written
-        t_hash = max(tk["ms_hash"] - tk["ms_head"], 1e-6)
+        t_hash = max(tk["ms_hash"], 1e-6)  # (the three launches of k_tok_hash: the event bracket around them)
         tok_bytes = T + 4 * nnz
         # (the hash runs as THREE launches per step — the head, a wave per 1 KiB window: k_tok_hash<1>; a sample and the rest, a wave
         # per 4 KiB unit: k_tok_hash<4> twice)

@@ -12,6 +12,8 @@ _HERE = Path(__file__).resolve().parent
 FRONT_PATH = _HERE / "libbfk_front.so"
 LIB_PATH = Path(os.environ["BFK_LIB"]) if os.environ.get("BFK_LIB") else _HERE / "libbfk.so"
 EUNSUPPORTED = -7
+ENOMEM = -2
+EHIP = -4
 ABI_VERSION = 3  # BFK_ABI_VERSION of include/bfk.h (same number as _lib.ABI_VERSION)
 VAR_TYPES = {"covsonar_dna": 0, "covsonar_aa": 1, "nextclade_dna": 2, "nextclade_aa": 3, "raw": 4}
 _lib = None
@@ -57,6 +59,8 @@ def load():
         lib.bfk_table_close.restype = None
         lib.bfk_table_prepare.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.POINTER(PrepInfo)]
         lib.bfk_table_invalid.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.bfk_table_invalid_count.argtypes = [C.c_void_p]
+        lib.bfk_table_invalid_count.restype = C.c_int64
         lib.bfk_table_cluster_write.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]
         lib.bfk_table_pipeline_device.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
                                                   C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
@@ -154,6 +158,9 @@ class Table:
             raise FrontError(rc, _err(self.lib))
         self.info = info
         return info, int(n.value)
+
+    def invalid_count(self) -> int:
+        return int(self.lib.bfk_table_invalid_count(self.h))
 
     def invalid(self, i):
         p, n = C.c_void_p(), C.c_int64()

@@ -114,6 +114,7 @@ EXPORTS = {
     "bfk_table_indptr": (c_i32p, [C.c_void_p]),
     "bfk_table_indices": (c_i32p, [C.c_void_p]),
     "bfk_table_invalid": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
+    "bfk_table_invalid_count": (C.c_int64, [C.c_void_p]),
     "bfk_table_feature": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_id": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), c_i64p]),
     "bfk_table_write": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i64p]),
@@ -486,6 +487,9 @@ class Table:
         if owned:
             self.lib.bfk_free(p)
         return s
+
+    def invalid_count(self) -> int:
+        return int(self.lib.bfk_table_invalid_count(self.h))
 
     def invalid(self, i):
         return self._str(self.lib.bfk_table_invalid, i, False)

@@ -187,6 +187,9 @@ struct TokArgs {
     const int *span_len;       // filter mode with rows that do not abut (bfk_table): length of row r's span (what lies behind it up to the
                                // next row's start has been blanked with separator bytes); NULL: a row ends where the next one starts
     TokFilter flt;
+    uint2 *inv_queue;          // filter mode: {byte offset, length} of the first inv_cap token occurrences that match no pattern (any order)
+    uint32_t inv_cap;
+    uint32_t *row_empties;     // filter mode: empty tokens of every row (k_tok_empties); NULL: not wanted
     uint32_t *winbase, *vocwin; // [T_pad / TOK_WIN]: tokens / vocabulary entries in front of every window inside its scan block
     uint32_t *blkbase, *vocblk; // [T_pad / TOK_PAD_BYTES + 1]: ... in front of every scan block (k_scan_single)
     TokSlot *table;            // tmask + 1 slots of 16 bytes

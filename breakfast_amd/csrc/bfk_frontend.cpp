@@ -440,12 +440,22 @@ inline bool is_na(const char *p, int64_t n) {
 // UTF-8 (read_table's default) and raises UnicodeDecodeError otherwise, compares ids and features as code-point strings —
 // which for valid UTF-8 is byte equality — and to_csv encodes them back unchanged.  The validator is Python's: no overlong
 // forms, no surrogates (U+D800..DFFF), nothing beyond U+10FFFF.  Checks the sequences that START in [i, e); a sequence may
-// end behind e (the buffer has a sentinel byte); stray continuation bytes at i are left to the slice in front (which
-// reads them as the tail of its last sequence, or flags them).
+// end behind e (the buffer has a sentinel byte); continuation bytes at i that the last sequence of the slice in front covers
+// are that slice's to check.
 bool utf8_valid_from(const char *b, int64_t i, int64_t e, int64_t n_total, bool first_slice) {
     const unsigned char *u = (const unsigned char *)b;
-    if (!first_slice)  // a slice that starts inside a sequence: its head belongs to the slice in front
-        for (int k = 0; k < 3 && i < e && (u[i] & 0xC0) == 0x80; k++) i++;
+    if (!first_slice && i < e && (u[i] & 0xC0) == 0x80) {
+        // a slice that starts inside a sequence: exactly the continuation bytes that the sequence's lead byte (within the three
+        // bytes in front of i) covers belong to the slice in front, which validates them; a continuation byte that no lead
+        // covers is invalid whichever slice it falls into (the result must not depend on where the slices are cut)
+        int64_t j = i - 1;
+        while (j >= 0 && i - j <= 3 && (u[j] & 0xC0) == 0x80) j--;
+        if (j < 0 || i - j > 3) return false;
+        const unsigned char c = u[j];
+        const int need = c >= 0xC2 && c <= 0xDF ? 1 : c >= 0xE0 && c <= 0xEF ? 2 : c >= 0xF0 && c <= 0xF4 ? 3 : 0;
+        if (j + 1 + need <= i) return false;  // (no lead there, or its sequence ended in front of i)
+        i = std::min<int64_t>(j + 1 + need, e);
+    }
     while (i < e) {
         const unsigned char c = u[i];
         if (c < 0x80) {
@@ -996,10 +1006,25 @@ extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const 
     return BFK_OK;
 }
 
+// the invalid token occurrences of a device prepare, in the reference's print order: spans into the table's bytes (length 0: an
+// empty token).  n == 0 with info.n_invalid > 0: every one of them is an empty token.
+extern "C" int bfk_table_set_invalid(bfk_table *t, const int64_t *off, const int32_t *len, int64_t n) {
+    if (!t || !t->prepared || n < 0 || (n > 0 && (!off || !len))) return bfk_fail(BFK_EARG, "bfk_table_set_invalid: bad argument");
+    t->invalid.clear();
+    t->invalid.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (off[i] < 0 || len[i] < 0 || off[i] + len[i] > (int64_t)t->bytes.size()) return bfk_fail(BFK_EARG, "bfk_table_set_invalid: span outside the table");
+        t->invalid.push_back(Span{off[i], len[i]});
+    }
+    return BFK_OK;
+}
+
 extern "C" const int32_t *bfk_table_group(const bfk_table *t) { return t && t->prepared ? t->group.data() : nullptr; }
 extern "C" const int32_t *bfk_table_weight(const bfk_table *t) { return t && t->prepared ? t->weight.data() : nullptr; }
 extern "C" const int32_t *bfk_table_indptr(const bfk_table *t) { return t && t->prepared ? t->indptr.data() : nullptr; }
 extern "C" const int32_t *bfk_table_indices(const bfk_table *t) { return t && t->prepared ? t->indices.data() : nullptr; }
+
+extern "C" int64_t bfk_table_invalid_count(const bfk_table *t) { return t && t->prepared ? (int64_t)t->invalid.size() : -1; }
 
 extern "C" int bfk_table_invalid(const bfk_table *t, int64_t i, const char **tok_out, int64_t *len_out) {
     if (!t || !t->prepared || !tok_out || !len_out || i < 0 || i >= (int64_t)t->invalid.size()) return bfk_fail(BFK_EARG, "bfk_table_invalid: bad argument");

@@ -133,6 +133,9 @@ struct bfk_ctx {
     // device prepare of a table (filter + collapse, bfk_prep.hip): span lengths, row hashes, the hash table, representatives,
     // prefix sums, group index / first row of the unique rows, their CSR, {totals, failure flags}
     int *pr_spanlen = nullptr, *pr_rep = nullptr, *pr_group = nullptr, *pr_first = nullptr, *pr_uindptr = nullptr, *pr_small = nullptr;
+    uint2 *pr_inv = nullptr;        // device prepare: {byte offset, length} of the token occurrences that match no pattern (PREP_INV_CAP)
+    uint32_t *pr_empties = nullptr; // device prepare: empty tokens per row
+    int64_t pr_empties_cap = 0;
     unsigned long long *pr_rowhash = nullptr;
     PrepSlot *pr_table = nullptr;
     int2 *pr_val = nullptr, *pr_blk = nullptr;
@@ -169,6 +172,9 @@ struct bfk_ctx {
         unsigned piece_blk[9] = {0};
         TokFilter flt{};                // filter_features on the device (flt.on), judged token by token where it is hashed
         const int *d_span_len = nullptr;  // rows that do not abut (a table's feature column): the rows' lengths
+        uint2 *d_inv = nullptr;           // filter mode: where the invalid token occurrences are noted (inv_cap of them)
+        uint32_t inv_cap = 0;
+        uint32_t *d_row_empties = nullptr;  // filter mode: empty tokens per row
     };
     struct SpecStep {
         TokPlan tp;
@@ -257,7 +263,7 @@ extern "C" int bfk_ctx_destroy(bfk_ctx *c) {
                     c->d_blk_stats, c->d_start3c, c->d_join, c->own_labels, c->own_gather, c->pg_keys, c->pg_keys_s, c->pg_rows,
                     c->pg_rows_s, c->pg_recpos, c->pg_temp, c->pg_srec, c->pg_cnt, c->pg_rowinfo, c->pg_keys_pm, c->tk_text, c->tk_rowoff,
                     c->tk_zero, c->tk_bits, c->tk_winbase, c->tk_table, c->tk_tabid, c->tk_slots, c->d_edge_sel, c->pr_spanlen, c->pr_rep, c->pr_group, c->pr_first,
-                    c->pr_uindptr, c->pr_small, c->pr_rowhash, c->pr_table, c->pr_val, c->pr_blk, c->pr_uindices};
+                    c->pr_uindptr, c->pr_small, c->pr_rowhash, c->pr_table, c->pr_val, c->pr_blk, c->pr_uindices, c->pr_inv, c->pr_empties};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &slot : c->ev)
@@ -552,6 +558,9 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     a.keptwin = c->tk_winbase + 2 * n_win + 2 * n_blk;
     a.keptblk = c->tk_winbase + 3 * n_win + 2 * n_blk;
     a.flt = tp.flt;
+    a.inv_queue = tp.d_inv;
+    a.inv_cap = tp.d_inv ? tp.inv_cap : 0u;
+    a.row_empties = tp.d_row_empties;
     a.span_len = tp.d_span_len;
     a.table = c->tk_table;
     a.tabid = c->tk_tabid;
@@ -653,7 +662,7 @@ static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, i
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
         if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->tk_stats.ms_hash = ms;
-        if (hipEventElapsedTime(&ms, ev[1], ev[6]) == hipSuccess) c->tk_stats.ms_head = ms;
+        c->tk_stats.ms_head = 0.f;  // (round 3's k_tok_head is gone: the hash is three launches of k_tok_hash, all inside ms_hash)
         if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->tk_stats.ms_ids = ms;
         if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) c->tk_stats.ms_total = ms;
     }
@@ -690,6 +699,26 @@ static bool spec_wanted(const bfk_ctx *c, int64_t n_rows, int64_t T, int32_t max
 }
 
 static int ctx_spec_finish_one(bfk_ctx *c);
+
+// waits for the step that was enqueued last and, when its variant join gave up (a probe chain beyond JOIN_MAX_PROBE, a dup list
+// or a candidate queue that overflowed), redoes it on the all-pairs path.  -> *redone (may be NULL)
+static int ctx_join_repair(bfk_ctx *c, bool *redone = nullptr) {
+    if (redone) *redone = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->ran || c->n <= 0 || !c->plan.join) return BFK_OK;
+    struct { int join_fail; int overflow; } f{};
+    const Counters *dc = reinterpret_cast<const Counters *>(c->d_head);
+    HIP_TRY(hipMemcpy(&f.join_fail, &dc->join_fail, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&f.overflow, &dc->overflow, sizeof(int), hipMemcpyDeviceToHost));
+    if (!f.join_fail && !f.overflow) return BFK_OK;
+    if (f.join_fail) c->join_off = true;
+    c->need_zero = c->ctr_dirty = true;
+    c->join_clear = true;
+    if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (redone) *redone = true;
+    return BFK_OK;
+}
 
 // tokeniser launched -> the join's kernels behind it on device-resident counts; nothing waits
 static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_dist, void *d_labels_out) {
@@ -739,7 +768,12 @@ static int ctx_spec_finish_one(bfk_ctx *c) {
     bool retry = false;
     int rc = ctx_tok_finish(c, st.tp, &retry, 1 + idx, st.ev);
     const bool outside = !rc && !retry && (c->kcap > JOIN_INLINE_ROW || c->nnz <= 0);
-    if (!rc && !retry && !outside) {
+    // the step's own outcome of the variant join (k_flatten left it in the step's slot: [5] give-up, [6] queue overflow, [7] a
+    // queue that should have stayed empty): the labels in the caller's buffer miss edges — this step is redone on the all-pairs
+    // path, the ones behind it as they were
+    const int *slot = c->h_small + 16 * (1 + idx);
+    const bool join_gave_up = !rc && !retry && !outside && (slot[5] | slot[6] | slot[7]) != 0;
+    if (!rc && !retry && !outside && !join_gave_up) {
         c->ran = true;  // (ctx_tok_finish cleared it: the step it belongs to has been enqueued)
         return BFK_OK;
     }
@@ -754,9 +788,14 @@ static int ctx_spec_finish_one(bfk_ctx *c) {
     c->need_zero = c->ctr_dirty = true;
     c->join_clear = true;
     if (rc) return rc;  // (malformed offsets, a token of 64 KiB: the caller's error; the later steps are dropped with it)
+    bool first = true;
     for (const bfk_ctx::SpecStep &r : redo) {
         if (int r2 = ctx_tokenize(c, r.tp, nullptr, nullptr)) return r2;
-        if (int r2 = ctx_enqueue(c, r.d, 0, 1, r.labels, true)) return r2;
+        if (int r2 = ctx_enqueue(c, r.d, 0, 1, r.labels, !(first && join_gave_up))) return r2;
+        // every redone step is completed before the next one goes out: its own give-up (bfk_ctx_sync would only see the last
+        // step's) is repaired here
+        if (int r2 = ctx_join_repair(c)) return r2;
+        first = false;
     }
     return BFK_OK;
 }
@@ -1875,6 +1914,7 @@ extern "C" int bfk_table_raw(const bfk_table *t, const char **bytes_out, int64_t
 extern "C" int bfk_table_any_high(const bfk_table *t);
 extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
                                       const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len);
+extern "C" int bfk_table_set_invalid(bfk_table *t, const int64_t *off, const int32_t *len, int64_t n);
 
 // BFK_FRONT_TIMING=1: stage times of the device pipeline on stderr (like the host stages' StageTimer)
 struct DevTimer {
@@ -1890,15 +1930,21 @@ struct DevTimer {
     }
 };
 
+constexpr uint32_t PREP_INV_CAP = 65536;  // invalid token occurrences the device prepare hands to the host (more: the host stage takes the input)
+
 struct PrepResult {
     int64_t n_rows = 0, n_unique = 0, nnz = 0, n_invalid = 0;
     int32_t n_vocab = 0;
     bool filtering = false;
+    // the "Skipping invalid feature" lines in the reference's order (rows in input order, tokens in row order): spans into the
+    // table's bytes, length 0 for an empty token.  Empty when every invalid token is an empty one (n_invalid lines of '').
+    std::vector<int64_t> inv_off;
+    std::vector<int32_t> inv_len;
 };
 
 // -> BFK_EUNSUPPORTED (nothing printed, nothing written: the host stages take the input) for what the device stages do not
-// restate: multi-byte token separators, 4 GiB of text, non-empty tokens that match no pattern (the reference prints each of
-// them, in order), a feature with non-ASCII bytes under a grammar, two different rows with one 64-bit hash
+// restate: multi-byte token separators, 4 GiB of text, more than PREP_INV_CAP non-empty tokens that match no pattern, a feature
+// with non-ASCII bytes under a grammar, two different rows with one 64-bit hash
 static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, PrepResult *res) {
     if (!t || !sep2 || !opts || !res) return fail(BFK_EARG, "device prepare: null argument");
     if (sep2_len <= 0) return fail(BFK_EARG, "empty separator");
@@ -1989,13 +2035,69 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     tp.flt.skip_del = opts->skip_del;
     tp.flt.trim_start = opts->trim_start;
     tp.flt.upper = opts->reference_length - opts->trim_end;
+    if (filtering) {
+        if (!c->pr_inv && hipMalloc((void **)&c->pr_inv, (size_t)PREP_INV_CAP * sizeof(uint2)) != hipSuccess) return fail(BFK_ENOMEM, "hipMalloc failed");
+        if (int rc = dev_realloc(&c->pr_empties, &c->pr_empties_cap, n, 1.05)) return rc;
+        tp.d_inv = c->pr_inv;
+        tp.inv_cap = PREP_INV_CAP;
+        tp.d_row_empties = c->pr_empties;
+    }
     if (int rc = ctx_text_events(c)) return rc;
     if (int rc = ctx_tokenize(c, tp, nullptr, nullptr)) return rc;  // (the CSR of ALL rows is bound now)
     tm.lap("prepare: tokenise + filter");
-    if (c->tk_stats.n_invalid > 0)
-        return fail(BFK_EUNSUPPORTED, "device prepare: tokens that match no pattern of the feature type (the host stage lists them in the reference's order)");
     // empty tokens are "invalid" for every grammar whose patterns do not match the empty string (:182-184)
-    const int64_t n_invalid = (filtering && opts->var_type != BFK_VAR_RAW && opts->var_type != BFK_VAR_NEXTCLADE_AA) ? c->tk_stats.n_empty : 0;
+    const int64_t n_empty_inv = (filtering && opts->var_type != BFK_VAR_RAW && opts->var_type != BFK_VAR_NEXTCLADE_AA) ? c->tk_stats.n_empty : 0;
+    const int64_t n_other_inv = c->tk_stats.n_invalid;
+    if (n_other_inv > (int64_t)PREP_INV_CAP)
+        return fail(BFK_EUNSUPPORTED, "device prepare: more than 65536 tokens that match no pattern of the feature type (the host stage lists them)");
+    const int64_t n_invalid = n_empty_inv + n_other_inv;
+    res->inv_off.clear();
+    res->inv_len.clear();
+    if (n_other_inv > 0) {
+        // The reference prints every invalid token where it meets it: rows in input order, tokens in row order, empty ones as ''.
+        // The device noted the non-empty ones in whatever order its waves met them: sorted by byte offset they are in the text's
+        // order, and the empty ones (all alike) go between them by count — the empty tokens of the rows in front (k_tok_empties
+        // left them per row) plus those of the token's own row in front of it (counted here, on the table's bytes).
+        std::vector<uint2> q((size_t)n_other_inv);
+        HIP_TRY(hipMemcpy(q.data(), c->pr_inv, q.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+        std::sort(q.begin(), q.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
+        std::vector<uint32_t> emp;
+        if (n_empty_inv > 0) {
+            emp.resize((size_t)n);
+            HIP_TRY(hipMemcpy(emp.data(), c->pr_empties, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+        res->inv_off.reserve((size_t)n_invalid);
+        res->inv_len.reserve((size_t)n_invalid);
+        int64_t emitted = 0, rows_done = 0, before_rows = 0;  // empties listed so far; rows whose empties are inside before_rows
+        for (const uint2 &tk : q) {
+            const int64_t off = base + (int64_t)tk.x;
+            // the row that holds the token: the last one that starts at or before it
+            const int64_t r = (std::upper_bound(row_off.begin(), row_off.begin() + n, off) - row_off.begin()) - 1;
+            if (r < 0 || off + (int64_t)tk.y > row_off[(size_t)r] + row_len[(size_t)r]) return fail(BFK_EHIP, "device prepare: an invalid token outside its row");
+            int64_t want = 0;
+            if (n_empty_inv > 0) {
+                for (; rows_done < r; rows_done++) before_rows += emp[(size_t)rows_done];
+                // empty tokens of row r in front of the token: the row splits at every separator; an empty piece ends at a
+                // separator that follows the row's start or another separator
+                int64_t in_row = 0;
+                const char *rb = bytes + row_off[(size_t)r];
+                for (int64_t k = 0, lim = off - row_off[(size_t)r]; k < lim; k++)
+                    if ((unsigned char)rb[k] == sp && (k == 0 || (unsigned char)rb[k - 1] == sp)) in_row++;
+                want = before_rows + in_row;
+            }
+            for (; emitted < want; emitted++) {
+                res->inv_off.push_back(off);
+                res->inv_len.push_back(0);
+            }
+            res->inv_off.push_back(off);
+            res->inv_len.push_back((int32_t)tk.y);
+        }
+        for (; emitted < n_empty_inv; emitted++) {
+            res->inv_off.push_back(base);
+            res->inv_len.push_back(0);
+        }
+        tm.lap("prepare: invalid tokens in order");
+    }
     const int64_t nnz_all = c->nnz;
     if (int rc = dev_realloc(&c->pr_uindices, &c->pr_uidx_cap, nnz_all + 16, 1.05)) return rc;
     HIP_TRY(hipMemsetAsync(c->pr_table, 0xFF, (size_t)slots * sizeof(PrepSlot), c->stream));
@@ -2046,9 +2148,9 @@ static void prep_info(const PrepResult &r, bfk_prep_info *info) {
     info->filtered = r.filtering ? 1 : 0;
 }
 
-// bfk_table_prepare's contract computed on the device, results installed in the table (group, weight, CSR of the unique rows):
-// what the parity tests compare with the host stage field by field.  (bfk_table_invalid has nothing to hand out: inputs with
-// non-empty invalid tokens are declined, the empty ones are counted in info_out->n_invalid.)
+// bfk_table_prepare's contract computed on the device, results installed in the table (group, weight, CSR of the unique rows, the
+// invalid tokens in the reference's order): what the parity tests compare with the host stage field by field.  (When every
+// invalid token is an empty one the table holds no list: info_out->n_invalid lines of ''.)
 extern "C" int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, bfk_prep_info *info_out) {
     if (!info_out) return fail(BFK_EARG, "bfk_table_prepare_device: null argument");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -2065,7 +2167,8 @@ extern "C" int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t 
     if (r.nnz) HIP_TRY(hipMemcpyAsync(ix.data(), c->pr_uindices, (size_t)r.nnz * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     prep_info(r, info_out);
-    return bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, ip.data(), ix.data(), sep2, sep2_len);
+    if (int rc = bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, ip.data(), ix.data(), sep2, sep2_len)) return rc;
+    return bfk_table_set_invalid(t, r.inv_off.data(), r.inv_len.data(), (int64_t)r.inv_off.size());
 }
 
 // The CLI's whole middle in one call: filter + collapse + CSR on the device, the unique rows clustered where they lie (no CSR
@@ -2099,6 +2202,7 @@ extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, in
     HIP_TRY(hipStreamSynchronize(c->stream));
     tm.lap("pipeline: cluster + D2H");
     if (int rc = bfk_table_set_prepared(t, group.data(), first.data(), r.n_unique, info_out, nullptr, nullptr, sep2, sep2_len)) return rc;
+    if (int rc = bfk_table_set_invalid(t, r.inv_off.data(), r.inv_len.data(), (int64_t)r.inv_off.size())) return rc;
     if (r.nnz <= 0) return BFK_OK;
     // a component counts the ORIGINAL sequences of its rows (:329-339); labels are the component's smallest row
     const int32_t *weight = bfk_table_weight(t);

@@ -2838,14 +2838,27 @@ __global__ void k_compress(int *parent, int n) {
 }
 
 // (no hooks run concurrently with this kernel, so plain cached loads and no compression stores)
+// dyn_host (a device-driven text step): the step's OWN outcome of the variant join goes to its pinned slot — [5] a give-up of
+// k_jhash / k_join (a probe chain over JOIN_MAX_PROBE, a dup list that overflowed), [6] the candidate queue overflowed, [7] the
+// queue was expected empty and is not — and the device word is cleared: several such steps may be open at once, and the host
+// looks at each step's slot when it completes that step (the device words alone would only ever describe the LAST step, and
+// the next k_jhash resets `overflow`).
 __global__ void k_flatten(const int *__restrict__ parent, int n, int *__restrict__ labels, Counters *ctr, int expect_empty_queue,
-                          const int *dyn) {
+                          const int *dyn, int *dyn_host) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (dyn && (join_dyn_unusable(dyn) || join_dyn_outside(dyn))) return;  // (no forest was built: the host redoes the step)
     if (i == 0 && ctr) ctr->n_dup = 0;  // the dup list of the variant join: consumed, empty for the next step
+    if (i == 0 && dyn_host) {  // (what the kernels in front of this one left: complete, this is a later launch)
+        dyn_host[5] = ctr->join_fail;
+        dyn_host[6] = ctr->overflow;
+        ctr->join_fail = 0;
+    }
     // k_verify was not launched because k_join decides every match of this CSR itself: a queue that is not empty all the
     // same means the step is redone on the all-pairs path
-    if (expect_empty_queue && i < CAND_SHARDS && ctr->ncand[i] != 0u) ctr->join_fail = 1;
+    if (expect_empty_queue && i < CAND_SHARDS && ctr->ncand[i] != 0u) {
+        if (dyn_host) dyn_host[7] = 1;
+        else ctr->join_fail = 1;
+    }
     if (i >= n) return;
     int cur = parent[i], next;
     while (cur > (next = parent[cur])) cur = next;
@@ -3155,7 +3168,7 @@ int launch_pairs(const Plan &pl, int t_begin, int t_end, hipStream_t st, hipEven
 
 int launch_flatten(const Plan &pl, hipStream_t st, hipEvent_t *ev) {
     hipLaunchKernelGGL(k_flatten, dim3((std::max(pl.n, CAND_SHARDS) + 255) / 256), dim3(256), 0, st, pl.parent, pl.n, pl.labels, pl.ctr,
-                       pl.join && pl.join_skip_verify ? 1 : 0, pl.join ? pl.ja.dyn : nullptr);
+                       pl.join && pl.join_skip_verify ? 1 : 0, pl.join ? pl.ja.dyn : nullptr, pl.join && pl.ja.dyn ? pl.ja.dyn_host : nullptr);
     LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[4], st);
     return 0;
@@ -3274,7 +3287,7 @@ int launch_lists(int *parent, int n, const long long *off, const int *flat, long
                            n_lists, n, ctr);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr);
+    hipLaunchKernelGGL(k_flatten, dim3((n + 255) / 256), dim3(256), 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr, (int *)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -3285,7 +3298,7 @@ int launch_merge(int *parent, int n, const int *gathered, int n_parts, int *labe
     dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_merge, g, b, 0, st, parent, n, gathered, n_parts, ctr, skip, splice);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr);
+    hipLaunchKernelGGL(k_flatten, g, b, 0, st, (const int *)parent, n, labels, (Counters *)nullptr, 0, (const int *)nullptr, (int *)nullptr);
     LAUNCH_CHECK();
     if (changed) {
         hipLaunchKernelGGL(k_changed, g, b, 0, st, (const int *)labels, gathered, n, changed);

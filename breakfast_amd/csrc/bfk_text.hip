@@ -259,6 +259,13 @@ __device__ __forceinline__ uint32_t tok_hash_inline(unsigned long long key) {
     return h ^ (h >> 16);
 }
 
+// A token occurrence that matches no pattern of the feature type (the reference prints every one of them, breakfast.py:182-184):
+// counted, and — up to inv_cap of them — noted as {byte offset, length} for the host, which puts them into the text's order.
+__device__ __forceinline__ void tok_note_invalid(const TokArgs &a, uint32_t j, uint32_t len) {
+    const uint32_t q = atomicAdd(&a.tc->n_invalid, 1u);
+    if (q < a.inv_cap) a.inv_queue[q] = make_uint2(j, len);
+}
+
 // a token of 8 bytes or more at byte offset j: length from the bound bits in global memory, the filter's verdict, hash over
 // its bytes, HASHED entry.  -> its slot, or TOK_NONE when the filter drops it (*invalid: it matched no pattern)
 __device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j, bool *invalid) {
@@ -277,6 +284,7 @@ __device__ __forceinline__ uint32_t tok_long(const TokArgs &a, uint32_t j, bool 
         const int v = tok_classify(a.flt, len, [&](uint32_t i) { return (uint32_t)p[i]; });
         if (v != TOKV_KEEP) {
             *invalid = v == TOKV_INVALID;
+            if (v == TOKV_INVALID) tok_note_invalid(a, j, len);
             return TOK_NONE;
         }
     }
@@ -355,6 +363,7 @@ __device__ __forceinline__ bool tok_medium(const TokArgs &a, const TokUnitLds &s
         const int v = tok_classify(a.flt, len, [&](uint32_t i) { return (tok_lds_u32(s, pos + (i & ~3u)) >> (8 * (i & 3u))) & 0xFFu; });
         if (v != TOKV_KEEP) {
             *invalid = v == TOKV_INVALID;
+            if (v == TOKV_INVALID) tok_note_invalid(a, j, len);
             *slot_out = TOK_NONE;
             return true;
         }
@@ -412,7 +421,6 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
     constexpr int U = TOK_LOOKUP_U;
     const int lane = threadIdx.x & 63;
     uint32_t n_pend = 0;
-    uint32_t n_inval = 0;  // (per lane) token occurrences that match no pattern of the feature type
     for (uint32_t r0 = 0; r0 < n_tok; r0 += 64 * U) {
         bool act[U], inl[U];
         uint32_t pos[U], slot[U];
@@ -430,7 +438,7 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
                 if (v != TOKV_KEEP) {  // dropped: no table entry, no CSR entry
                     act[u] = false;
                     out[t] = TOK_NONE;
-                    n_inval += v == TOKV_INVALID ? 1u : 0u;
+                    if (v == TOKV_INVALID) tok_note_invalid(a, text0 + pos[u], (uint32_t)(kb >> 56));
                 }
             }
             slot[u] = tok_hash_inline(key[u]) & a.tmask;
@@ -480,7 +488,6 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
         if (!inl) {
             bool inval = false;
             if ((a.dbg & 8) || !tok_medium(a, s, pos, staged, j, &sl, &inval)) sl = tok_long(a, j, &inval);
-            n_inval += inval ? 1u : 0u;
         } else {
             uint32_t slot = tok_hash_inline(key) & a.tmask;
             // the slot's state past the caches, key and first offset requested together
@@ -512,11 +519,6 @@ __device__ __forceinline__ void tok_unit_lookup(const TokArgs &a, TokUnitLds &s,
         }
         if (a.flt.on && sl != TOK_NONE) atomicOr(&s.kept[pos >> 5], 1u << (pos & 31u));
         out[t] = sl;
-    }
-    if (a.flt.on) {  // invalid occurrences of the wave: one add (they are rare; what they are is the host path's to print)
-        uint32_t tot = n_inval;
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-        if (lane == 0 && tot) atomicAdd(&a.tc->n_invalid, tot);
     }
 }
 
@@ -813,6 +815,7 @@ __global__ __launch_bounds__(256) void k_tok_empties(TokArgs a) {
         }
         const uint32_t first_is_start = e > s ? (a.startbits[s >> 5] >> (s & 31u)) & 1u : 0u;
         cnt = (nb - first_is_start) + 1u - ns;
+        if (a.row_empties) a.row_empties[r] = cnt;  // (the host interleaves the "invalid" lines of empty and other tokens by these)
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.tc->n_empty, cnt);
@@ -890,8 +893,8 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     // quarters blocks that read the count and left)
     // The gather id = tabid[slot] is what the kernel costs (a scattered 4-byte load per token: 43.5M of them at 1M rows, from a
     // 16 MB array), and most tokens of a profile are the few hundred mutations nearly every row carries: a direct-mapped cache
-    // {slot, id} in the block's LDS answers those (an entry is one 8-byte word: read and written whole, a stale or lost entry is
-    // only a miss).  2048 entries (16 KB: 4096 are no better, 8192 cost occupancy — 213 us): 1M rows 182 -> 139 us, 100k rows
+    // {slot, id} in the block's LDS answers those (an entry is one 8-byte word, read and written whole by relaxed atomics: a stale
+    // or lost entry is only a miss).  2048 entries (16 KB: 4096 are no better, 8192 cost occupancy — 213 us): 1M rows 182 -> 139 us, 100k rows
     // 13.3 -> 12.4.  CACHE = 0 gathers directly (BFK_TOK_IDCACHE=0).
     __shared__ unsigned long long s_cache[CACHE ? CACHE : 1];
     if (CACHE) {
@@ -903,10 +906,12 @@ __global__ __launch_bounds__(256) void k_tok_ids(TokArgs a) {
     auto id_of = [&](uint32_t slot) -> uint32_t {
         if (!CACHE) return (uint32_t)a.tabid[slot];
         const uint32_t c = (slot ^ (slot >> 12)) & (uint32_t)(CACHE - 1);
-        const unsigned long long e = s_cache[c];
+        // (all waves of the block read and write the entries: relaxed 64-bit atomics — one ds_read_b64 / ds_write_b64 each — so that
+        // an entry is never torn into the tag of one token and the id of another)
+        const unsigned long long e = __hip_atomic_load(&s_cache[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((uint32_t)(e >> 32) == slot) return (uint32_t)e;
         const uint32_t id = (uint32_t)a.tabid[slot];
-        s_cache[c] = ((unsigned long long)slot << 32) | id;
+        __hip_atomic_store(&s_cache[c], ((unsigned long long)slot << 32) | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return id;
     };
     for (uint32_t g0 = (blockIdx.x * 256u + threadIdx.x) * 4u; g0 < nnz; g0 += nth) {
@@ -1009,10 +1014,7 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
                 LAUNCH_CHECK();
             }
         }
-        if (ev && k == 0) {
-            (void)hipEventRecord(ev[1], st);
-            (void)hipEventRecord(ev[6], st);
-        }
+        if (ev && k == 0) (void)hipEventRecord(ev[1], st);
         // A token that starts near the end of the piece may reach into the next one (up to TOK_MAX_LEN bytes), whose text and
         // bound bits are not there yet: the last TOK_HOLD_UNITS units of a piece wait for the next piece's scan.
         const unsigned u0 = hashed;

@@ -53,24 +53,38 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
         # (multi-byte token separators, tokens that match no pattern and have to be listed, ...): the stages below take over.
         made = not outdir.exists()
         outdir.mkdir(parents=True, exist_ok=True)
+
+        def drop_outdir():
+            if made:
+                try:
+                    outdir.rmdir()
+                except OSError:
+                    pass
+
         try:
             info, n_clusters = table.pipeline_device(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length,
                                                      max_dist, min_cluster_size, outdir / "clusters.tsv")
         except _front.Unsupported:
             info = None
+        except _front.FrontError as e:
+            # out of device memory for the prepare's extra buffers, a row table that overflowed: nothing has been printed or
+            # written — the host stages below handled such inputs before there was a device prepare, and still do
+            if e.code not in (_front.ENOMEM, _front.EHIP):
+                drop_outdir()
+                table.close()
+                raise
+            info = None
         if info is not None:
             n, nu = int(info.n_rows), int(info.n_unique)
             print(f"Number of sequences: {n}")
-            for _ in range(int(info.n_invalid)):  # (only empty tokens get here: the device declines inputs with any other invalid one)
-                print("Skipping invalid feature: ''")
+            listed = table.invalid_count()  # (0: every invalid token is an empty one)
+            for i in range(int(info.n_invalid)):
+                print(f"Skipping invalid feature: '{table.invalid(i) if listed else ''}'")
             print(f"Number of duplicates: {n - nu}")
             print(f"Number of unique sequences: {nu}")
             if info.nnz == 0:
-                if made:
-                    try:
-                        outdir.rmdir()
-                    except OSError:
-                        pass
+                drop_outdir()
+                table.close()
                 # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
                 raise ValueError("unable to infer matrix dimensions")
             print("Imported cached results are not available. "
@@ -81,31 +95,33 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
             table.close()
             return True
     try:
-        info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
-    except _front.Unsupported:
-        return False
-    n, nu = int(info.n_rows), int(info.n_unique)
-    print(f"Number of sequences: {n}")
-    for i in range(int(info.n_invalid)):
-        print(f"Skipping invalid feature: '{table.invalid(i)}'")
-    print(f"Number of duplicates: {n - nu}")
-    print(f"Number of unique sequences: {nu}")
-    outdir.mkdir(parents=True, exist_ok=True)
-    if max_dist == 0:
-        print("Skip sparse matrix calculation since max-dist = 0")
-        n_clusters = table.cluster_write(0, min_cluster_size, outdir / "clusters.tsv")
-    else:
-        if info.nnz == 0:
-            # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
-            raise ValueError("unable to infer matrix dimensions")
-        print("Imported cached results are not available. "
-              "Distance matrix of complete dataset will be calculated.")
-        n_clusters = table.cluster_write(max_dist, min_cluster_size, outdir / "clusters.tsv", n_gpus)
-        print("Create graph and recover connected components")
-        print("Save clusters")
-    print(f"Number of clusters found: {n_clusters}")
-    table.close()
-    return True
+        try:
+            info = table.prepare(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length)
+        except _front.Unsupported:
+            return False
+        n, nu = int(info.n_rows), int(info.n_unique)
+        print(f"Number of sequences: {n}")
+        for i in range(int(info.n_invalid)):
+            print(f"Skipping invalid feature: '{table.invalid(i)}'")
+        print(f"Number of duplicates: {n - nu}")
+        print(f"Number of unique sequences: {nu}")
+        outdir.mkdir(parents=True, exist_ok=True)
+        if max_dist == 0:
+            print("Skip sparse matrix calculation since max-dist = 0")
+            n_clusters = table.cluster_write(0, min_cluster_size, outdir / "clusters.tsv")
+        else:
+            if info.nnz == 0:
+                # the reference dies here: csr_matrix cannot infer the shape of an all-empty matrix (:214)
+                raise ValueError("unable to infer matrix dimensions")
+            print("Imported cached results are not available. "
+                  "Distance matrix of complete dataset will be calculated.")
+            n_clusters = table.cluster_write(max_dist, min_cluster_size, outdir / "clusters.tsv", n_gpus)
+            print("Create graph and recover connected components")
+            print("Save clusters")
+        print(f"Number of clusters found: {n_clusters}")
+        return True
+    finally:
+        table.close()
 
 
 def _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,

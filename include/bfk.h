@@ -300,8 +300,11 @@ const int32_t *bfk_table_group(const bfk_table *t);    /* [n_rows]  unique-row i
 const int32_t *bfk_table_weight(const bfk_table *t);   /* [n_unique] input rows per unique row (len of the id tuple) */
 const int32_t *bfk_table_indptr(const bfk_table *t);   /* [n_unique + 1] */
 const int32_t *bfk_table_indices(const bfk_table *t);  /* [nnz] */
-/* i-th invalid token occurrence, in the order the reference prints them */
+/* i-th invalid token occurrence, in the order the reference prints them (src/breakfast/breakfast.py:182-184) */
 int bfk_table_invalid(const bfk_table *t, int64_t i, const char **tok_out, int64_t *len_out);
+/* how many of them the table lists: info.n_invalid after the host prepare; after a device prepare info.n_invalid too, or 0 when
+ * every invalid token is an empty one (info.n_invalid lines of ''); -1: not prepared */
+int64_t bfk_table_invalid_count(const bfk_table *t);
 /* filtered feature string of unique row u (sep2-joined kept tokens): library-allocated, bfk_free */
 int bfk_table_feature(const bfk_table *t, int64_t u, char **str_out, int64_t *len_out);
 /* id of input row r (view) */

@@ -220,6 +220,40 @@ def test_reader_byte_check_finds_a_bad_byte_anywhere(bad, at, tmp_path, monkeypa
         _lib.Table.open(p, "\t", "id", "f")
 
 
+@pytest.mark.parametrize("threads", [1, 3, 5, 8])
+def test_reader_finds_a_stray_continuation_byte_at_a_slice_start(threads, tmp_path, monkeypatch):
+    """the UTF-8 check runs in parallel slices cut at n * q / threads: a continuation byte right at a cut that no lead byte in
+    front of it covers (the slice in front ends in ASCII, or in a complete sequence) is invalid for every thread count — pandas
+    raises UnicodeDecodeError on it — and a sequence that does straddle the cut is accepted"""
+    monkeypatch.setenv("BFK_THREADS", str(threads))
+    line = "s{:07d}\tA1T C22G del:333:4\n"
+    text = bytearray(("id\tf\n" + "".join(line.format(i) for i in range(60_000))).encode())
+    n = len(text)
+    p = tmp_path / "in.tsv"
+    for q in range(1, 8):
+        for parts in (3, 5, 8):
+            cut = n * q // parts
+            if cut + 4 >= n or any(text[j] in b"\t\n" for j in range(cut - 2, cut + 3)):
+                continue
+            for bad in (b"\xa9", b"\xc3\xa9\xa9"[1:], b"\xa9\xa9"):   # stray continuation bytes at the cut, ASCII in front
+                t2 = bytearray(text)
+                t2[cut:cut + len(bad)] = bad
+                p.write_bytes(bytes(t2))
+                with pytest.raises(_lib.Unsupported):
+                    _lib.Table.open(p, "\t", "id", "f")
+            t2 = bytearray(text)   # a complete two-byte sequence in front of the cut, then a stray continuation byte AT the cut
+            t2[cut - 2:cut + 1] = b"\xc3\xa9\xa9"
+            p.write_bytes(bytes(t2))
+            with pytest.raises(_lib.Unsupported):
+                _lib.Table.open(p, "\t", "id", "f")
+            t2 = bytearray(text)   # a three-byte sequence across the cut: valid
+            t2[cut - 1:cut + 2] = "\u6771".encode()
+            p.write_bytes(bytes(t2))
+            t = _lib.Table.open(p, "\t", "id", "f")
+            assert len(t) == 60_000
+            t.close()
+
+
 def test_reader_takes_utf8_at_any_offset_and_across_slice_cuts(tmp_path, monkeypatch):
     """valid multi-byte sequences wherever the parallel slices are cut (a slice that starts inside a sequence leaves its head
     to the slice in front): accepted, ids and clusters.tsv bytes equal to the pandas mirror's"""

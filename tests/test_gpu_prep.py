@@ -31,10 +31,18 @@ def both(ids, feats, sep2, var_type, opts):
     return th, ih, td, idv
 
 
+def invalid_lines(t, info):
+    """what the CLI prints for the table's invalid tokens, in order (a device prepare lists nothing when all of them are empty)"""
+    listed = t.invalid_count()
+    assert listed in (0, info.n_invalid)
+    return [t.invalid(i) if listed else "" for i in range(info.n_invalid)]
+
+
 def assert_same(th, ih, td, idv):
-    assert td is not None, "the device stage declined an input without invalid tokens"
+    assert td is not None, "the device stage declined the input"
     for k in ("n_rows", "n_unique", "nnz", "n_invalid", "n_vocab", "filtered"):
         assert getattr(ih, k) == getattr(idv, k), k
+    assert invalid_lines(td, idv) == invalid_lines(th, ih)  # the reference's print order (breakfast.py:182-184)
     np.testing.assert_array_equal(td.group, th.group)
     np.testing.assert_array_equal(td.weight, th.weight)
     np.testing.assert_array_equal(td.indptr, th.indptr)
@@ -69,7 +77,8 @@ def host_invalid_tokens(tokens, var_type, opts):
 def test_device_filter_and_collapse_vs_host_on_the_token_grammar_fuzz(var_type, opts):
     """the five grammars as device byte matchers: rows built from the fuzz tokens of tests/test_frontend.py that the host calls
     valid (kept or dropped: trims, indel switches, 19+ digit positions, leading zeros ...) plus empty tokens in every place —
-    identical group / weight / CSR / counts; with ONE token the host calls invalid the device stage declines the input"""
+    identical group / weight / CSR / counts; with tokens the host calls invalid in the rows (and empty ones around them) the
+    device stage lists the same tokens in the same order"""
     rng = np.random.default_rng(zlib.crc32(repr((var_type, opts, 1)).encode()))
     toks = sorted({t for t in _fuzz_tokens(rng, 1500) + _structured_tokens(rng, 1500) if t and " " not in t})
     filtering = opts[0] or opts[1] or opts[2] > 0 or opts[3] > 0
@@ -83,25 +92,30 @@ def test_device_filter_and_collapse_vs_host_on_the_token_grammar_fuzz(var_type, 
     feats += ["", " ", "  ", g(0) + "  " + g(1), " " + g(2), g(3) + " ", feats[5], feats[7], feats[5]]
     ids = [f"s{i}" for i in range(len(feats))]
     assert_same(*both(ids, feats, " ", var_type, opts))
-    for tok in list(sorted(bad))[:: max(1, len(bad) // 12)]:
+    some = list(sorted(bad))[:: max(1, len(bad) // 12)]
+    for tok in some:
         th, ih, td, idv = both(ids + ["x"], feats + [g(0) + " " + tok], " ", var_type, opts)
-        assert td is None and ih.n_invalid >= 1, tok
+        assert ih.n_invalid >= 1, tok
+        assert_same(th, ih, td, idv)
+    if some:  # invalid tokens, empty tokens and kept ones interleaved in many rows: the order of the lines is the text's
+        feats2 = list(feats)
+        for k in range(0, len(feats2), 3):
+            b1, b2 = some[k % len(some)], some[(k // 3 + 1) % len(some)]
+            feats2[k] = [b1 + " " + feats2[k], feats2[k] + "  " + b1 + " ", " " + b1 + "  " + g(k) + " " + b2, b1 + " " + b1, "  " + b2 + "  "][k % 5]
+        assert_same(*both(ids, feats2, " ", var_type, opts))
 
 
 def test_device_filter_kats(kats):
     """the reference's own filter cases (tests/golden/kats.json, captured by importing it): the device stage either gives
-    the host stage's result or — where the reference prints a non-empty invalid token — declines"""
+    the host stage's result, the printed tokens included"""
     for c in kats["filter"]:
         if len(c["sep"]) != 1:
             continue
         opts = (c["skip_ins"], c["skip_del"], c["trim_start"], c["trim_end"], c["reference_length"])
         th, ih, td, idv = both(["a", "b"], [c["input"], c["input"]], c["sep"], c["var_type"], opts)
         names = [ln.split("'", 1)[1].rsplit("'", 1)[0] for ln in c["stdout"].splitlines() if ln.startswith("Skipping invalid")]
-        if any(n != "" for n in names):
-            assert td is None, c
-        else:
-            assert_same(th, ih, td, idv)
-            assert idv.n_invalid == 2 * len(names)
+        assert_same(th, ih, td, idv)
+        assert invalid_lines(td, idv) == names + names  # (two rows with the case's input)
 
 
 @pytest.mark.parametrize("opts", OPTS[:4])
@@ -140,6 +154,25 @@ def test_device_prepare_a_hub_of_identical_rows_and_long_tokens():
         th, ih, td, idv = both(ids, feats, " ", "covsonar_dna", opts)
         assert_same(th, ih, td, idv)
         assert int(td.weight.max()) >= 60000
+
+
+def test_device_prepare_lists_invalid_tokens_and_declines_only_beyond_its_queue():
+    """up to 65536 invalid token occurrences are noted on the device ({offset, length}) and ordered on the host; more than that
+    (a file in another dialect altogether) is the host stage's"""
+    rng = np.random.default_rng(5)
+    feats = synth.generate_profiles(30000, seed=3)
+    ids = [f"s{i}" for i in range(len(feats))]
+    for k in rng.choice(len(feats), 100, replace=False):   # 100 stray tokens in 30k rows
+        toks = feats[k].split(" ")
+        toks.insert(int(rng.integers(0, len(toks) + 1)), ["S:N501Y", "stray", "n/a", "A12", "del:5"][int(rng.integers(5))])
+        feats[k] = " ".join(toks)
+    opts = (True, True, 264, 228, 29903)
+    th, ih, td, idv = both(ids, feats, " ", "covsonar_dna", opts)
+    assert ih.n_invalid == 100
+    assert_same(th, ih, td, idv)
+    many = ["x%d y%d" % (i, i) for i in range(40000)]    # 80 000 invalid tokens: beyond the queue
+    th, ih, td, idv = both([f"m{i}" for i in range(len(many))], many, " ", "covsonar_dna", opts)
+    assert td is None and ih.n_invalid == 80000
 
 
 def test_device_prepare_declines_what_it_does_not_restate():
@@ -186,7 +219,7 @@ def test_pipeline_on_the_device_writes_the_host_path_s_clusters_tsv(max_dist, in
 def test_cli_runs_the_device_stages_and_prints_what_the_host_stages_print(tmp_path, monkeypatch):
     """python -m breakfast_amd through fastpath.run: with the device prepare (the default) and with BFK_DEVICE_PREP=0 (host
     tokeniser / filter / collapse) — the same stdout, the same clusters.tsv; an input with a token that has to be listed
-    takes the host stages by itself"""
+    is listed by the device stages too, in the reference's order"""
     inp = tmp_path / "in.tsv"
     synth.generate_tsv(inp, 20000)
     lines = inp.read_text().splitlines()
@@ -208,8 +241,12 @@ def test_cli_runs_the_device_stages_and_prints_what_the_host_stages_print(tmp_pa
     out_h, sha_h = run(tmp_path / "host", False)
     assert out_d == out_h and sha_d == sha_h
     assert out_d.count("Skipping invalid feature: ''") == 2
-    lines.append("bad\tA300T notatoken C400G")
+    lines.insert(7000, "bad1\tA300T notatoken C400G")
+    lines.insert(300, "bad2\t  S:N501Y A301T  xyz ")
+    lines.append("bad3\tfoo")
     inp.write_text("\n".join(lines) + "\n")
-    out_d, sha_d = run(tmp_path / "dev2", True)  # declined by the device stage: the host stages list the token
+    out_d, sha_d = run(tmp_path / "dev2", True)  # listed by the device stage: offsets noted by the kernels, ordered by the host
     out_h, sha_h = run(tmp_path / "host2", False)
     assert out_d == out_h and sha_d == sha_h and "Skipping invalid feature: 'notatoken'" in out_d
+    inv = [ln for ln in out_d.splitlines() if ln.startswith("Skipping invalid")]
+    assert [ln.split("'")[1] for ln in inv] == ["", "", "S:N501Y", "", "xyz", "", "notatoken", "", "", "foo"]

@@ -378,6 +378,28 @@ def test_open_text_steps_complete_in_order_and_a_step_outside_the_assumptions_re
     ctx.close()
 
 
+def test_a_join_give_up_in_an_open_text_step_that_is_not_the_last_is_repaired():
+    """the variant join's outcome is per step: a step whose join gives up (300 identical rows: a probe chain beyond
+    JOIN_MAX_PROBE) while later device-driven steps are open is redone on the all-pairs path when it is completed — the device
+    words alone describe only the last step (k_flatten leaves every step's outcome in the step's own pinned slot)"""
+    import torch
+
+    ok_a = list(dict.fromkeys(generate_profiles(3000)))
+    ok_b = list(dict.fromkeys(generate_profiles(2000, seed=5)))
+    same = ["A1T A2T A3T"] * 300 + ["A1T A2T", "A1T A2T A3T A4T", "C5G"] + ok_b[:50]
+    for batches in ([ok_a, same, ok_b], [same, ok_a, ok_b, ok_a], [ok_a, same, same, ok_b, same]):
+        dev = [_device_text(r) for r in batches]
+        labs = [torch.full((len(r),), -3, dtype=torch.int32, device="cuda") for r in batches]
+        ctx = _lib.Context(0)
+        for (buf, off, d_text, d_off), rows, lab in zip(dev, batches, labs):
+            ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, lab.data_ptr())
+        ctx.sync()
+        for rows, lab in zip(batches, labs):
+            ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
+            assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+        ctx.close()
+
+
 def test_pinned_host_buffer_for_the_text():
     """bfk_host_alloc / bfk_host_free: a caller builds its text in page-locked memory and hands that to bfk_cluster_text"""
     rows = list(dict.fromkeys(generate_profiles(20000)))
