@@ -9,7 +9,8 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-FRONT_PATH = _HERE / "libbfk_front.so"
+# (BFK_FRONT_LIB: another build of the library, e.g. the sanitizer build of `make -C breakfast_amd/csrc asan`)
+FRONT_PATH = Path(os.environ["BFK_FRONT_LIB"]) if os.environ.get("BFK_FRONT_LIB") else _HERE / "libbfk_front.so"
 LIB_PATH = Path(os.environ["BFK_LIB"]) if os.environ.get("BFK_LIB") else _HERE / "libbfk.so"
 EUNSUPPORTED = -7
 ENOMEM = -2

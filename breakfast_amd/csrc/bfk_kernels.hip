@@ -17,7 +17,8 @@
 //                lock-free union-find hooks of the verified edges (one edge per lane);
 //                k_verify_long for pairs > 192 tokens
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
-//   max_dist == 1 (up to 800k rows) replaces k_sig .. k_verify by the VARIANT JOIN: k_jhash (additive multiset hash
+//   max_dist == 1 (up to 800k rows; up to 2M while rows average at most 64 tokens: join_wanted in bfk_host.cpp) replaces
+//                k_sig .. k_verify by the VARIANT JOIN: k_jhash (additive multiset hash
 //                of every row -> hash table + bitmap), k_join (one lookup per token occurrence: H(B) - h(t); matches
 //                certified by a 64-lane compare and hooked at once; what the compare cannot decide: counted exactly by
 //                the wave while no row has more than 128 tokens — no k_verify launch then —, to k_verify's queue
@@ -2040,7 +2041,7 @@ __global__ __launch_bounds__(1024, 8) void k_join(const int *__restrict__ indptr
 //   grouping by hash classes of the tokens 3.7e8), 144 per row, 178 at 300k.  The order affects only the work, never
 //   the result.
 //   k_pgfreq counts the tokens of a sample of the rows; k_pgkeys leaves max_dist + 2 records per row (prefix elements,
-//   SHORT or unique sentinels : row, slot); a device radix sort (rocPRIM) orders them; k_pgplace lays {row, length,
+//   SHORT or unique sentinels : row, slot); the LSD radix sort of bfk_sort.hip (hand-written) orders them; k_pgplace lays {row, length,
 //   64-bit signature} out in that order and notes where every record went; k_pgjoin walks, row by row, the groups of
 //   the row's records and queues every member that passes the second level, once (see there).  Exact: sharing a prefix
 //   element is a necessary condition, so is the signature level, the verify is exact, and every pair is queued once.

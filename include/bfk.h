@@ -177,7 +177,8 @@ int bfk_ctx_build_csr(bfk_ctx *ctx, const char *buf, const int64_t *row_off, int
  *   bfk_ctx_cluster_text_device  + the body of cluster_features (:287-326) -> canonical labels in d_labels_out (device
  *                                int32[n_rows]).  This is the step bench.py times: profile strings in HBM -> labels in HBM.
  *                                ASYNCHRONOUS: it returns with tokeniser and clustering kernels enqueued.  At max_dist 1 up to
- *                                800k rows (the variant join) NOTHING waits in between — the clustering kernels read the token
+ *                                800k rows (the device-driven form of the variant join; the join itself serves up to 2M short
+ *                                rows, the host then sizes its launch after a wait) NOTHING waits in between — the clustering kernels read the token
  *                                count and the longest row from device memory — and up to four such steps may be open at once:
  *                                a caller that streams batches enqueues the next while the last one runs.  Every other entry
  *                                point — bfk_ctx_sync first of all — completes the open steps in order: a step whose input was
@@ -202,11 +203,11 @@ typedef struct bfk_text_stats {
     int32_t host_fallback;   /* 1: the device tokeniser declined the input (BFK_EUNSUPPORTED), the host tokeniser built the CSR */
     int32_t reserved_;
     float ms_h2d;            /* text + row offsets, host -> device */
-    float ms_scan;           /* k_tok_rowbits + k_tok_scan */
-    float ms_hash;           /* k_tok_head + k_tok_hash */
-    float ms_ids;            /* k_tok_rows + k_tok_first + k_tok_ids */
+    float ms_scan;           /* (k_tok_rowbits +) k_tok_scan */
+    float ms_hash;           /* the three launches of k_tok_hash (first units, a sample spread over the text, the rest) */
+    float ms_ids;            /* k_tok_rows + k_voc_count + k_voc_ids + k_tok_ids */
     float ms_total;          /* first copy to last kernel */
-    float ms_head;           /* (round 3: k_tok_head alone; the hash now runs as three launches, this stays 0) */
+    float ms_head;           /* always 0 (round 3 had a k_tok_head kernel; kept for the layout of ABI 3) */
     float reserved2_;
     int64_t n_invalid;       /* filter mode: non-empty token occurrences that matched no pattern of the feature type */
     int64_t n_empty;         /* filter mode: empty tokens inside the rows' spans */
