@@ -95,7 +95,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(indptr, indices, d, n_u, target_s=10.0):
+def cpu_baseline(indptr, indices, d, n_u, target_s=10.0, full_limit_s=50.0):
     """CPU legs on the host cores, each on a bounded sample of S query rows (the reference's select_ind shape,
     breakfast.py:241-245), scaled to pairs/s as S*(N_u-1)/2 / t — the share of the job's unordered pairs those S
     query rows account for.  Top level: the scikit-learn kernel the reference itself calls
@@ -116,7 +116,7 @@ def cpu_baseline(indptr, indices, d, n_u, target_s=10.0):
     res = orc.cluster_csr(indptr, indices, d, select_ind=sel, n_threads=cores)
     t = time.perf_counter() - t0
     port = {
-        "value": s * (n_u - 1) / 2 / t, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "value": s * (n_u - 1) / 2 / t, "unit": "pairs/s", "cores": cores, "kind": "port", "sampled": s < n_u,
         "kernel": "oracle/bfk_oracle.c (C restatement of the reference path)",
         "sample": f"{s} of {n_u} query rows x all columns (select_ind shape), {res['n_merges']} row merges "
                   f"in {t:.1f} s, OpenMP over query rows like sklearn's prange; extrapolated to the full job",
@@ -128,19 +128,105 @@ def cpu_baseline(indptr, indices, d, n_u, target_s=10.0):
         if sk_port.available():
             sel0 = np.sort(rng.choice(n_u, size=min(n_u, 200), replace=False)).astype(np.int64)
             _, t0s = sk_port.neighbours(indptr, indices, d, select_ind=sel0)
+            # 10k / 100k are timed IN FULL where that fits a minute on this host (every row a query row) — decided
+            # by a bounded sample first; otherwise that sample is the figure, and the line says `sampled`
             s2 = int(min(n_u, max(200, 200 * target_s / max(t0s, 1e-3))))
             sel2 = np.sort(rng.choice(n_u, size=s2, replace=False)).astype(np.int64)
             _, ts = sk_port.neighbours(indptr, indices, d, select_ind=sel2)
-            return {"value": s2 * (n_u - 1) / 2 / ts, "unit": "pairs/s", "cores": cores, "kind": "port",
+            if s2 < n_u and ts * n_u / s2 <= full_limit_s:  # (the bounded sample says the whole job fits: time the whole job)
+                s2 = n_u
+                sel2 = np.arange(n_u, dtype=np.int64)
+                _, ts = sk_port.neighbours(indptr, indices, d, select_ind=sel2)
+            return {"value": s2 * (n_u - 1) / 2 / ts, "unit": "pairs/s", "cores": cores, "kind": "port", "sampled": s2 < n_u,
                     "kernel": "scikit-learn pairwise_distances_chunked(metric='manhattan') -> _sparse_manhattan: the "
                               "third-party kernel the reference calls (breakfast.py:259-267), driven band by band by "
                               "oracle/sk_port.py; " + sk_port.versions(),
-                    "sample": f"{s2} of {n_u} query rows x their length bands, {sk_port.merges(indptr, d, sel2)} row "
-                              f"merges, {ts:.1f} s inside the sklearn calls; extrapolated to the full job",
+                    "sample": (f"all {n_u} rows x their length bands" if s2 == n_u else f"{s2} of {n_u} query rows x their length bands, "
+                               "extrapolated to the full job") + f": {sk_port.merges(indptr, d, sel2)} row merges, {ts:.1f} s inside the sklearn calls",
                     "seconds": round(ts, 2), "c_oracle": port}
     except Exception as e:  # the baseline is a report, never a reason to lose the bench line
         port["sklearn_error"] = repr(e)
     return port
+
+
+def predicted_speedup(one_gpu, exchange, world):
+    """Amdahl reading of the N-rank step from the ONE-GPU phases measured in this run: every rank repeats the
+    tokeniser, the table build of the candidate generator (`prep`) and the flatten; the pair work is dealt out; the label
+    exchange + merge (measured on the N ranks: the slowest rank's median) comes on top.  What the driver's scaling record is to
+    be read against — a prediction, never a measurement."""
+    if not one_gpu or "phases_ms" not in one_gpu:
+        return None
+    ph = one_gpu["phases_ms"]
+    repl = ph["tokeniser"] + ph["prep"] + ph["flatten"]
+    shard = ph["pairs"]
+    exch = max((x["all_gather"] + x["merge_flatten"] for x in exchange["per_rank_ms"]), default=0.0) if exchange else 0.0
+    t1 = repl + shard
+    return {"replicated_ms": repl, "sharded_ms": shard, "exchange_merge_ms": exch, "n": world,
+            "amdahl_ceiling": t1 / (repl + shard / world), "with_exchange": t1 / (repl + shard / world + exch)}
+
+
+def compact_line(out: dict) -> dict:
+    """THE line: the contract's keys and every headline scalar first, nested detail (numbers only) after; what a number means is
+    said once, in DESIGN.md 6 — the explanatory strings of the full record (--detail FILE) are not repeated in every run."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+    def r(x, n=6):
+        return float(f"{x:.{n}g}") if isinstance(x, float) else x
+
+    host, cli, roof = out.get("t_cluster_host_ms") or {}, out.get("clusters_tsv") or {}, out["roofline"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    line["metric"] = "genome-pair dists/sec"
+    line.update(pick(out, ("value_host_inclusive_pinned", "value_host_inclusive")))
+    if host:
+        line["t_cluster_host_pinned_ms"] = host.get("pinned_buffer")
+        line["t_cluster_host_fresh_pageable_ms"] = host.get("fresh_pageable_buffer")
+        line["h2d_ms"] = host.get("h2d_ms")
+    if out.get("sustained"):
+        line["sustained_ms_per_step"] = out["sustained"]["ms_per_step"]
+    line.update(pick(out, ("clusters_tsv_wall_s", "clusters_tsv_wall_median_s", "clusters_tsv_wall_ordinary_exit_s")))
+    if cli:
+        line["clusters_tsv_sha256_matches_reference"] = cli.get("sha256_matches_reference")
+    line["value_resident_csr"] = out.get("value_resident_csr")
+    line["resident_csr_ms_per_step"] = (out.get("resident_csr") or {}).get("ms_per_step")
+    if out.get("all_pairs"):
+        ap_ = out["all_pairs"]
+        line["all_pairs"] = {"ms_per_step": ap_["ms_per_step"], "labels_equal_default_path": ap_["labels_equal_default_path"],
+                             "prefilter_ms": ap_["phases_ms"]["ms_prefilter"], "prep_ms": ap_["phases_ms"]["ms_prep"],
+                             "frac_of_issue_ceiling": ap_["roofline"]["frac"]}
+    cfg = out["config"]
+    line["config"] = pick(cfg, ("workload", "workload_key", "kernel_source_digest", "n_unique", "nnz", "n_vocab", "max_dist", "text_bytes",
+                                "untimed_steps_before_warmup", "candidate_path", "collective_backend", "world_size", "n_edges_per_rank",
+                                "predicted_speedup"))
+    line["config"]["step"] = "profile text resident in HBM -> tokeniser, vocabulary, CSR -> clustering kernels -> labels in HBM (DESIGN 6)"
+    if cfg.get("step_phases"):
+        line["config"]["step_phases"] = pick(cfg["step_phases"], ("per_rank_ms", "tokeniser_ms_every_rank", "payload_bytes_per_rank"))
+    if cfg.get("one_gpu_same_workload"):
+        line["config"]["one_gpu_same_workload"] = pick(cfg["one_gpu_same_workload"], ("ms_per_step", "steps", "value", "labels_equal_n_gpu_run"))
+    sk = roof.get("second_kernel") or {}
+    line["roofline"] = {**pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch")),
+                        "second_kernel": pick(sk, ("kernel", "achieved", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch")),
+                        "whole_step": pick(roof.get("whole_step") or {}, ("bytes", "GBps", "frac")),
+                        "reference_equivalent": pick(roof.get("reference_equivalent") or {}, ("bytes", "equivalent_GBps"))}
+    if "traffic" not in line["roofline"]:
+        line["roofline"]["traffic"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {**pick(cb, ("value", "unit", "cores", "kind", "sampled", "sample", "seconds")),
+                                **({"c_oracle_value": cb["c_oracle"]["value"]} if "c_oracle" in cb else {})}
+    line["phases_ms"] = {"tokeniser": out["phases_ms"]["tokeniser"], "clustering": out["phases_ms"]["clustering"]}
+    line["counters"] = out["counters"]
+    line["result"] = out["result"]
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return r(o)
+
+    return rnd(line)
 
 
 def kernel_source_digest():
@@ -260,6 +346,8 @@ def main():
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="only the timed steps + roofline (no host / CLI / CPU legs)")
+    ap.add_argument("--detail", default="", help="also write the FULL record (every leg, with its explanatory strings) to this file; "
+                                                 "stdout is always the ONE compact line (<= 4 KB, scalars first)")
     ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join", "prefix"], help="candidate generator of the main leg")
     a = ap.parse_args()
 
@@ -556,7 +644,19 @@ def main():
             e1 = time.perf_counter() - t0
             st1 = eng.sync()
             lab1 = sc1.labels[0][:n_u].cpu().numpy()
-            one_gpu = {"ms_per_step": e1 / k1 * 1e3, "steps": k1, "value": n_u * (n_u - 1) / 2 * k1 / e1,
+            # where the one-GPU step's time goes (HIP events inside libbfk, 8 profiled steps): what every rank of an N-rank step
+            # repeats (tokeniser, the join's table build, flatten) and what the ranks share (the pair work)
+            eng.ctx.set_profiling(True)
+            p_st, p_tk = [], []
+            for _ in range(8):
+                text_step1()
+                p_st.append(eng.sync())
+                p_tk.append(eng.ctx.text_stats())
+            eng.ctx.set_profiling(False)
+            med1 = lambda xs: sorted(xs)[len(xs) // 2]
+            ph1 = {"tokeniser": med1([x["ms_total"] - x["ms_h2d"] for x in p_tk]), "prep": med1([x["ms_prep"] for x in p_st]),
+                   "pairs": med1([x["ms_prefilter"] + x["ms_verify"] for x in p_st]), "flatten": med1([x["ms_flatten"] for x in p_st])}
+            one_gpu = {"ms_per_step": e1 / k1 * 1e3, "steps": k1, "value": n_u * (n_u - 1) / 2 * k1 / e1, "phases_ms": ph1,
                        "labels_equal_n_gpu_run": bool(np.array_equal(lab1, labels)), "path": st1["path"],
                        "what": "the same steps (text in HBM -> labels) by rank 0's GPU alone (world 1), timed after the N-rank "
                                "steps while the other ranks wait: ms_per_step of this line / this = the speed-up the N GPUs gave"}
@@ -771,7 +871,8 @@ def main():
                              f"(k,f,g) cells of the sorted order round-robin over {world} rank(s)") +
                             (f", label merge {a.merge} ({sc.rounds} round(s))" if world > 1 else ""),
                 **({"collective_backend": backend, "world_size": world, "n_edges_per_rank": edges_per_rank,
-                    "step_phases": exchange, "one_gpu_same_workload": one_gpu} if world > 1 else {}),
+                    "step_phases": exchange, "one_gpu_same_workload": one_gpu,
+                    "predicted_speedup": predicted_speedup(one_gpu, exchange, world)} if world > 1 else {}),
             },
             "roofline": roof,
             "phases_ms": {"tokeniser": tk, "clustering": {kk: st[kk] for kk in ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten", "ms_total")},
@@ -803,7 +904,9 @@ def main():
             out["all_pairs"] = allpairs
         if full and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(indptr, indices, d, n_u)
-        print(json.dumps(out), flush=True)
+        if a.detail:
+            Path(a.detail).write_text(json.dumps(out, indent=1) + "\n")
+        print(json.dumps(compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
