@@ -19,6 +19,7 @@ from breakfast_amd.synth import generate_profiles
 from oracle import ref_port as orc
 
 pytestmark = pytest.mark.gpu
+ORACLE_THREADS = min(16, os.cpu_count() or 8)  # (the oracle's OpenMP threads: a GPU box gives a test run 16 cores)
 FIX = GOLD / "ref_fixtures"
 
 
@@ -157,7 +158,7 @@ def test_random_multisets_vs_oracle(n, alphabet, kmax, d, seed):
     indptr, indices = _random_multisets(n, seed, alphabet, kmax)
     if indptr[-1] == 0:
         indices = np.zeros(0, np.int32)
-    want = orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"]
+    want = orc.cluster_csr(indptr, indices, d, n_threads=ORACLE_THREADS)["labels"]
     got, st = _lib.cluster_csr(indptr, indices, d)
     assert np.array_equal(got, want)
     assert st["sig_words"] == (1 if d <= 2 else 2 if d <= 5 else 4)
@@ -523,7 +524,7 @@ def test_order_consistent_rows_with_repeats_vs_oracle(seed, d):
     indptr[1:] = np.cumsum([len(r) for r in rows])
     indices = np.concatenate(rows) if indptr[-1] else np.zeros(0, np.int32)
     labels, st = _lib.cluster_csr(indptr, indices, d)
-    assert np.array_equal(labels, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
+    assert np.array_equal(labels, orc.cluster_csr(indptr, indices, d, n_threads=ORACLE_THREADS)["labels"])
     # the exact edge set, by brute force on the dense count matrix
     from scipy.spatial.distance import cdist
 
@@ -647,7 +648,7 @@ def test_variant_join_equals_the_all_pairs_path(name, inline, monkeypatch):
     monkeypatch.setenv("BFK_JOIN", "1")
     got, st = _lib.cluster_csr(indptr, indices, 1)
     assert np.array_equal(got, want)
-    assert np.array_equal(got, orc.cluster_csr(indptr, indices, 1, n_threads=8)["labels"])
+    assert np.array_equal(got, orc.cluster_csr(indptr, indices, 1, n_threads=ORACLE_THREADS)["labels"])
     assert st["n_edges"] == st0["n_edges"]
     if name != "small_alphabet":  # (hundreds of empty and one-token rows there: may or may not exceed the limit)
         assert (st["n_retry_slices"] > 0) == (name == "perms400")
@@ -871,7 +872,7 @@ def test_variant_join_on_a_resident_context_alternates_its_tables():
     for name in ("medium", "long_rows", "profiles30k", "tiny_rows", "medium", "perms100"):
         indptr, indices = cases[name]
         n = len(indptr) - 1
-        want = orc.cluster_csr(indptr, indices, 1, n_threads=8)["labels"]
+        want = orc.cluster_csr(indptr, indices, 1, n_threads=ORACLE_THREADS)["labels"]
         ctx.upload_csr(indptr, indices)
         d_out = ctx.alloc(4 * n)
         for _ in range(3):
@@ -1050,7 +1051,7 @@ def test_prefix_groups_equal_the_band_path(n, d, indels, pos, monkeypatch):
     assert st["n_work_items"] == (nu + 63) // 64  # work items of the prefix-group path: blocks of 64 rows
     ctx.close()
     if n <= 3000:
-        assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=8)["labels"])
+        assert np.array_equal(want, orc.cluster_csr(indptr, indices, d, n_threads=ORACLE_THREADS)["labels"])
     elif n <= 20000 and indels:  # the oracle for every size it can afford
         assert np.array_equal(want, oracle_labels_indel(n, d))
 
@@ -1079,7 +1080,7 @@ def test_prefix_groups_on_random_multisets(seed, monkeypatch):
     monkeypatch.setenv("BFK_PG", "1")
     for d in (2, 3, 6):
         indptr, indices = _random_multisets(900, 100 * seed + d, alphabet=60, kmax=3 * d)
-        want = orc.cluster_csr(indptr, indices, d, n_threads=8)
+        want = orc.cluster_csr(indptr, indices, d, n_threads=ORACLE_THREADS)
         got, st = _lib.cluster_csr(indptr, indices, d)
         assert np.array_equal(got, want["labels"]), (seed, d)
 
@@ -1099,7 +1100,7 @@ def test_prefix_groups_hub_row_overflows_the_lds_set(monkeypatch):
     indptr[1:] = np.cumsum([len(r) for r in rows])
     indices = np.concatenate(rows).astype(np.int32)
     for d in (2, 4):
-        want = orc.cluster_csr(indptr, indices, d, n_threads=8)
+        want = orc.cluster_csr(indptr, indices, d, n_threads=ORACLE_THREADS)
         got, st = _lib.cluster_csr(indptr, indices, d)
         assert np.array_equal(got, want["labels"])
         monkeypatch.setenv("BFK_PG", "0")

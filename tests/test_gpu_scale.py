@@ -36,6 +36,26 @@ def _csr(rows):
     return uf, indptr, indices
 
 
+@pytest.fixture(scope="module")
+def million_csr(million):
+    """unique rows + CSR of the whole million, built ONCE: the unique rows of a prefix of the input are a prefix of these (first
+    occurrences keep their order) and so is their CSR (vocabulary ids are handed out by first appearance) — every size below is a
+    slice.  n_unique_of(n) = unique rows among the first n input rows."""
+    seen, first = set(), np.zeros(len(million), dtype=np.int64)
+    for i, r in enumerate(million):
+        if r not in seen:
+            seen.add(r)
+            first[i] = 1
+    uf, indptr, indices = _csr(million)
+    return uf, indptr, indices, np.cumsum(first)
+
+
+def _csr_prefix(million_csr, n_rows):
+    uf, indptr, indices, cum = million_csr
+    m = int(cum[n_rows - 1])
+    return uf[:m], indptr[: m + 1].copy(), indices[: int(indptr[m])].copy()
+
+
 def _check_fix_point(labels):
     n = len(labels)
     assert np.all(labels <= np.arange(n)) and np.array_equal(labels[labels], labels)
@@ -103,8 +123,8 @@ def _sharded_labels(indptr, indices, d, n_shards):
 
 
 @pytest.mark.exact_edges
-def test_config3_one_million_rows_max_dist_1(million):
-    uf, indptr, indices = _csr(million)
+def test_config3_one_million_rows_max_dist_1(million_csr):
+    uf, indptr, indices = _csr_prefix(million_csr, 1_000_000)
     assert len(uf) > 990_000
     l1, st1 = _lib.cluster_csr(indptr, indices, 1)
     assert st1["path"] == 1                 # short rows: the variant join up to 2M rows (round 4; the band kernels beyond)
@@ -176,11 +196,11 @@ def test_config4_one_million_rows_max_dist_5_indels(million_indels, monkeypatch)
 @pytest.mark.exact_edges
 @pytest.mark.parametrize("n_rows,join,third_key", [(590_000, True, False), (610_000, True, True), (790_000, True, True),
                                                    (815_000, True, True)])
-def test_size_switches_without_knobs(million, n_rows, join, third_key):
+def test_size_switches_without_knobs(million_csr, n_rows, join, third_key):
     """either side of the 600k third-key switch (the all-pairs kernels, max-dist 2) and of 800k rows, where the device-driven
     text step ends and — for rows of more than 64 tokens on average — the variant join (max-dist 1); the paths must agree
     with each other and with sampled oracle rows"""
-    uf, indptr, indices = _csr(million[:n_rows])
+    uf, indptr, indices = _csr_prefix(million_csr, n_rows)
     n = len(uf)
     assert (n >= 600_000) == third_key
     l1, st = _lib.cluster_csr(indptr, indices, 1)
@@ -200,10 +220,12 @@ def test_size_switches_without_knobs(million, n_rows, join, third_key):
     _check_sampled_rows(indptr, indices, 1, l1, 12, seed=n_rows + 1)
 
 
-@pytest.mark.parametrize("d,indels", [(1, False), (2, True), (5, True)])
-def test_50k_rows_against_the_full_oracle(d, indels):
+@pytest.mark.parametrize("d,indels,n_rows", [(1, False, 50000), (2, True, 50000), (5, True, 32000)])
+def test_50k_rows_against_the_full_oracle(d, indels, n_rows):
+    """(max-dist 5: 32k rows — the oracle's all-pairs work grows with the square of the rows and took 97 of the suite's 515 s at
+    50k; 20k rows at max-dist 5 are compared in test_gpu_parity.py as well)"""
     kw = dict(p_del=0.05, p_ins=0.01) if indels else {}
-    uf, indptr, indices = _csr(generate_profiles(50000, **kw))
+    uf, indptr, indices = _csr(generate_profiles(n_rows, **kw))
     got, st = _lib.cluster_csr(indptr, indices, d)
     want = orc.cluster_csr(indptr, indices, d, n_threads=CORES)["labels"]
     assert d > 3 or st["n_retry_slices"] == 0  # (a dense d = 5 graph may outgrow the first queue: recovered in slices, same labels)

@@ -3,6 +3,8 @@ text -> first-appearance vocabulary -> CSR must equal the reference's sparse_fea
 for entry — golden stage vectors and KATs produced by the imported reference, the oracle's restatement on seeded inputs,
 and the host tokeniser (bfk_build_csr) at BASELINE's sizes.  Integer / byte work: bit-exact."""
 
+import os
+
 import numpy as np
 import pytest
 from conftest import load_stage, stage_names
@@ -12,6 +14,7 @@ from breakfast_amd.synth import generate_profiles
 from oracle import ref_port as orc
 
 pytestmark = pytest.mark.gpu
+ORACLE_THREADS = min(16, os.cpu_count() or 8)  # (the oracle's OpenMP threads: a GPU box gives a test run 16 cores)
 
 
 def _same(got, want):
@@ -194,11 +197,12 @@ def test_text_resident_in_hbm_gives_the_same_csr_and_labels(case):
     if len(ix):
         d_lab = torch.empty(max(len(rows), 1), dtype=torch.int32, device="cuda")
         for d in (1, 3):
+            want_labels = orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"]
             for _ in range(2):  # twice: a second step on the same buffers finds nothing left over from the first
                 ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", d, d_lab.data_ptr())
                 st = ctx.sync()
                 assert st["n_retry_slices"] == 0
-                assert np.array_equal(d_lab.cpu().numpy()[: len(rows)], orc.cluster_csr(want[0], want[1], d, n_threads=8)["labels"])
+                assert np.array_equal(d_lab.cpu().numpy()[: len(rows)], want_labels)
     ctx.close()
 
 
@@ -313,7 +317,7 @@ def test_device_driven_text_step_redoes_what_its_assumptions_do_not_cover(case, 
         return
     want = orc.sparse_feature_matrix(rows, " ")
     if len(want[1]):
-        lab = orc.cluster_csr(want[0], want[1], 1, n_threads=8)["labels"]
+        lab = orc.cluster_csr(want[0], want[1], 1, n_threads=ORACLE_THREADS)["labels"]
     else:  # (the reference's csr_matrix cannot even be built from an all-empty input: every row is the same empty multiset)
         lab = np.zeros(len(rows), dtype=np.int32)
     for got, _ in results:
@@ -336,12 +340,12 @@ def test_device_driven_step_then_other_entries_without_a_sync():
     ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
     ctx.cluster(2, d_lab.data_ptr())                 # another step on the CSR the open bind leaves
     ctx.sync()
-    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 2, n_threads=8)["labels"])
+    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 2, n_threads=ORACLE_THREADS)["labels"])
     ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
     ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())  # back to back
     assert ctx.text_stats()["nnz"] == len(want[1])
     ctx.sync()
-    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 1, n_threads=8)["labels"])
+    assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], 1, n_threads=ORACLE_THREADS)["labels"])
     ctx.close()                                       # and a context destroyed with a bind still open
     ctx = _lib.Context(0)
     ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
@@ -366,7 +370,7 @@ def test_open_text_steps_complete_in_order_and_a_step_outside_the_assumptions_re
     ctx.sync()
     for rows, lab in zip(batches, labs):
         ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
-        assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+        assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=ORACLE_THREADS)["labels"])
     # the same buffer for every step (what bench.py does): the last step's labels are in it
     lab = torch.empty(len(ok_a), dtype=torch.int32, device="cuda")
     buf, off, d_text, d_off = dev[0]
@@ -374,7 +378,7 @@ def test_open_text_steps_complete_in_order_and_a_step_outside_the_assumptions_re
         ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(ok_a), " ", 1, lab.data_ptr())
     st = ctx.sync()
     ip, ix, _ = orc.sparse_feature_matrix(ok_a, " ")
-    assert st["n_retry_slices"] == 0 and np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+    assert st["n_retry_slices"] == 0 and np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=ORACLE_THREADS)["labels"])
     ctx.close()
 
 
@@ -396,7 +400,7 @@ def test_a_join_give_up_in_an_open_text_step_that_is_not_the_last_is_repaired():
         ctx.sync()
         for rows, lab in zip(batches, labs):
             ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
-            assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=8)["labels"])
+            assert np.array_equal(lab.cpu().numpy(), orc.cluster_csr(ip, ix, 1, n_threads=ORACLE_THREADS)["labels"])
         ctx.close()
 
 
@@ -430,7 +434,7 @@ def test_cluster_text_matches_oracle_labels():
     ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
     for d in (1, 3):
         lab, st, _, _ = _lib.cluster_text(buf, off, " ", d)
-        assert np.array_equal(lab, orc.cluster_csr(ip, ix, d, n_threads=8)["labels"])
+        assert np.array_equal(lab, orc.cluster_csr(ip, ix, d, n_threads=ORACLE_THREADS)["labels"])
 
 
 def test_device_csr_with_the_text_sent_in_pieces(monkeypatch):
