@@ -178,7 +178,8 @@ def compact_line(out: dict) -> dict:
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
     line["metric"] = "genome-pair dists/sec"
-    line.update(pick(out, ("value_host_inclusive_pinned", "value_host_inclusive")))
+    line.update(pick(out, ("contexts", "contexts_trial_ms_per_step", "ms_per_step_one_context", "value_one_context", "value_host_inclusive_pinned",
+                           "value_host_inclusive")))
     if host:
         line["t_cluster_host_pinned_ms"] = host.get("pinned_buffer")
         line["t_cluster_host_fresh_pageable_ms"] = host.get("fresh_pageable_buffer")
@@ -199,7 +200,9 @@ def compact_line(out: dict) -> dict:
     line["config"] = pick(cfg, ("workload", "workload_key", "kernel_source_digest", "n_unique", "nnz", "n_vocab", "max_dist", "text_bytes",
                                 "untimed_steps_before_warmup", "candidate_path", "collective_backend", "world_size", "n_edges_per_rank",
                                 "predicted_speedup"))
-    line["config"]["step"] = "profile text resident in HBM -> tokeniser, vocabulary, CSR -> clustering kernels -> labels in HBM (DESIGN 6)"
+    line["config"]["step"] = ("profile text resident in HBM -> tokeniser, vocabulary, CSR -> clustering kernels -> labels in HBM (DESIGN 6)" +
+                              (f"; {out['contexts']} resident contexts take the steps in turn: steps of different batches overlap"
+                               if out.get("contexts", 1) > 1 else ""))
     if cfg.get("step_phases"):
         line["config"]["step_phases"] = pick(cfg["step_phases"], ("per_rank_ms", "tokeniser_ms_every_rank", "payload_bytes_per_rank"))
     if cfg.get("one_gpu_same_workload"):
@@ -207,7 +210,7 @@ def compact_line(out: dict) -> dict:
     sk = roof.get("second_kernel") or {}
     line["roofline"] = {**pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch")),
                         "second_kernel": pick(sk, ("kernel", "achieved", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch")),
-                        "whole_step": pick(roof.get("whole_step") or {}, ("bytes", "GBps", "frac")),
+                        "whole_step": pick(roof.get("whole_step") or {}, ("bytes", "GBps", "frac", "frac_one_context")),
                         "reference_equivalent": pick(roof.get("reference_equivalent") or {}, ("bytes", "equivalent_GBps"))}
     if "traffic" not in line["roofline"]:
         line["roofline"]["traffic"] = None
@@ -346,6 +349,9 @@ def main():
     ap.add_argument("--merge", default="allgather", choices=["allgather", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="only the timed steps + roofline (no host / CLI / CPU legs)")
+    ap.add_argument("--contexts", type=int, default=0, help="one GPU: resident contexts (a stream and buffers each) that take the text steps in "
+                                                            "turn, distributed.TextPipeline; 1 = every step behind the one before; 0 = "
+                                                            "2, 3 and 4 are tried on 150 untimed steps each and the fastest is taken")
     ap.add_argument("--detail", default="", help="also write the FULL record (every leg, with its explanatory strings) to this file; "
                                                  "stdout is always the ONE compact line (<= 4 KB, scalars first)")
     ap.add_argument("--path", default="auto", choices=["auto", "allpairs", "join", "prefix"], help="candidate generator of the main leg")
@@ -497,13 +503,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def warm(step, count):
+    def warm(step, count, sync=None):
         # a candidate-queue overflow (dense inputs) is repaired inside sync() and grows the queue, so repeat until a
         # step runs clean: the timed steps must be complete single-pass steps
         for _ in range(6):
             for _ in range(max(count, 1)):
                 step()
-            again = int(eng.sync()["n_retry_slices"] != 0)
+            again = int((sync or eng.sync)()["n_retry_slices"] != 0)
             if world > 1:  # every rank must run the same number of steps (each step holds a collective)
                 tt = torch.tensor([again], dtype=torch.int32, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -511,7 +517,7 @@ def main():
             if not again:
                 return
 
-    def timed(step, count):
+    def timed(step, count, sync=None):
         barrier()
         t0 = time.perf_counter()
         for _ in range(count):
@@ -522,7 +528,7 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        st_ = eng.sync()  # checks the device-side overflow / error flags of the last timed step(s)
+        st_ = (sync or eng.sync)()  # checks the device-side overflow / error flags of the last timed step(s)
         if st_["n_retry_slices"] != 0:
             raise SystemExit("bench invalid: a timed step overflowed the candidate queue")
         return elapsed, st_
@@ -563,12 +569,67 @@ def main():
     elapsed, st_timed = timed(text_step, a.steps)
     labels = sc.labels[0][:n_u].cpu().numpy()
     ms_step = elapsed / a.steps * 1e3
+    # ---- one GPU: the same steps dealt to `--contexts` resident contexts in turn (distributed.TextPipeline: a stream and buffers
+    # each), so that steps of different batches run beside each other — a step's twelve dependent launches leave the chip partly
+    # idle (the vocabulary hash's first two launches: 34 us with a few hundred waves).  Every step is still the complete hot path on
+    # its batch; `value` is this whole-job throughput, the one-context figure (every step behind the one before) stands beside it.
+    one_ctx = {"ms_per_step": ms_step, "value": n_u * (n_u - 1) / 2 * a.steps / elapsed}
+    n_ctx = a.contexts if world == 1 else 1
+    run_step, run_sync = text_step, None
+    calib = None
+    if n_ctx != 1:
+        from breakfast_amd.distributed import TextPipeline
+
+        def make_pipe(depth):
+            pp = TextPipeline(local_rank, depth, a.path)
+            ll = [torch.empty(max(n_u, 1), dtype=torch.int32, device="cuda") for _ in range(depth)]
+
+            def st_():
+                i = step_no[0]
+                step_no[0] += 1
+                pp.step_text(d_texts[i % n_copies].data_ptr(), T, d_off.data_ptr(), n_u, " ", d, ll[i % depth], inputs_ready=True, want_event=False)
+
+            return pp, ll, st_
+
+        if n_ctx <= 0:
+            # How the streams of a pipeline share the chip depends on the hardware queues the HIP runtime happened to deal them
+            # (two of a pipeline's streams on one queue run behind each other: three contexts gave 0.128 or 0.157 - 0.18 ms per step at
+            # 100k rows depending on what else had created streams before): a few INSTANCES are tried on 150 untimed steps each, the
+            # fastest one — that very instance, streams and all — serves the timed steps, the others are closed.
+            calib, best = {}, None
+            for tag, depth in (("2", 2), ("3", 3), ("4", 4), ("3b", 3)):
+                pp, ll, st_ = make_pipe(depth)
+                warm(st_, 100, pp.sync)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(150):
+                    st_()
+                torch.cuda.synchronize()
+                calib[tag] = (time.perf_counter() - t0) / 150 * 1e3
+                pp.sync()
+                if best is None or calib[tag] < best[0]:
+                    if best is not None:
+                        best[2].close()
+                    best = (calib[tag], depth, pp, ll, st_)
+                else:
+                    pp.close()
+            _, n_ctx, pipe, p_labels, pipe_step = best
+        else:
+            pipe, p_labels, pipe_step = make_pipe(n_ctx)
+        run_step, run_sync = pipe_step, pipe.sync
+        warm(pipe_step, PRE_ROLL, pipe.sync)
+        warm(pipe_step, a.warmup, pipe.sync)
+        elapsed, st_timed = timed(pipe_step, a.steps, pipe.sync)
+        ms_step = elapsed / a.steps * 1e3
+        for pl_ in p_labels:
+            if not np.array_equal(pl_[:n_u].cpu().numpy(), labels):
+                raise SystemExit("bench invalid: a pipelined step's labels differ from the one-context step's")
 
     # ---- the same steps for >= 1 s (long enough for an outside sampler of GPU utilisation to see the device busy)
     sustained = None
     if world == 1 and not a.quick:
         n_sus = int(min(100000, max(a.steps, math.ceil(1.0 / max(ms_step * 1e-3, 1e-6)))))
-        e2, _ = timed(text_step, n_sus)
+        e2, _ = timed(run_step, n_sus, run_sync)
         sustained = {"steps": n_sus, "seconds": round(e2, 4), "ms_per_step": e2 / n_sus * 1e3}
     st, tk = profiled_text()
     edges_per_rank = None
@@ -824,6 +885,7 @@ def main():
         roof["second_kernel"] = other
         roof["whole_step"] = {"bytes": step_bytes, "GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                               "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_one_context": step_bytes / (one_ctx["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "note": "compulsory bytes of every kernel of the step (tokeniser: text twice + 12 B per token + "
                                       "indptr; clustering kernels as listed in DESIGN 8) / ms_per_step"}
         roof["reference_equivalent"] = {
@@ -883,6 +945,8 @@ def main():
                                                "n_retry_slices", "n_work_items", "max_row_len")},
             "result": {"components": int(len(np.unique(labels))), "labels_crc": int(np.bitwise_xor.reduce(
                 (labels.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(13)))},
+            "contexts": n_ctx, "ms_per_step_one_context": one_ctx["ms_per_step"], "value_one_context": one_ctx["value"],
+            **({"contexts_trial_ms_per_step": calib} if calib else {}),
             "value_resident_csr": resident["value"],
             "resident_csr": resident,
         }

@@ -38,10 +38,10 @@ class GpuEngine:
     libbfk the handle of torch's DEFAULT stream — 0 — means "the context's own stream" to bfk_ctx_set_stream: the kernels
     then ran on a stream the collectives did not wait for.  Found by the round-3 rehearsal's per-phase events.)"""
 
-    def __init__(self, device_index: int):
+    def __init__(self, device_index: int, stream=None):
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
         self.ctx = _lib.Context(device_index)
         self.ctx.set_stream(self.stream.cuda_stream)
         self.n = 0
@@ -187,3 +187,73 @@ class ShardedClusterer:
             if int(self.flag.item()) == 0 or self.rounds >= 64:
                 return self.labels[0]
             cur = self.labels
+
+
+class TextPipeline:
+    """Text steps (profile strings resident in HBM -> labels in HBM, bfk_ctx_cluster_text_device) on `depth` resident contexts of
+    ONE GPU that take the steps in turn, each context with its own stream and its own buffers (0.15 GB at 100k rows, 2.5 GB at
+    1M, of 288).  A step is a chain of twelve dependent launches of which the first ones of the vocabulary hash (34 us of ~190
+    at 100k rows) and every launch's tail leave most of the chip idle; with the next batch's step running beside it on another
+    stream the chip is shared by the two (measured, 100k rows, max-dist 1: 0.198 ms per step with one context, 0.146 with two,
+    0.135 with three, 0.175 with four — the host then cannot enqueue fast enough).  Every step is the complete hot path on its
+    batch; what changes is that steps of DIFFERENT batches overlap.
+
+    step_text(..., labels_out) enqueues and returns an event that fires when the step's labels are in `labels_out` (a CUDA int32
+    tensor of n_rows; the caller's, one per step in flight — like d_labels_out of the C-ABI).  The step's stream waits for the
+    caller's current stream first (the text is there); the caller's stream is NOT made to wait for the step — that would order
+    every later step behind it: wait for the event, or call sync().  sync() completes every context (a step whose input was
+    outside what its device-driven launch assumed, or whose join gave up, is redone there) and returns the last step's stats,
+    with `n_retry_slices` = the sum over the contexts."""
+
+    def __init__(self, device_index: int, depth: int = 3, candidate_path: str | None = None):
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        # The streams the steps run on are created ONE AFTER THE OTHER, before anything else creates a stream: the HIP runtime deals
+        # streams round-robin onto its hardware queues (four by default, GPU_MAX_HW_QUEUES), and two of the pipeline's streams on one
+        # queue run behind each other — with a stream per context created in between (every context owns one) the 1st and the 3rd
+        # stream shared a queue: 0.157 ms per step instead of 0.128 at 100k rows.
+        torch.cuda.set_device(torch.device("cuda", device_index))
+        streams = [torch.cuda.Stream(torch.device("cuda", device_index)) for _ in range(depth)]
+        self.engines = [GpuEngine(device_index, st) for st in streams]
+        if candidate_path is not None:
+            for e in self.engines:
+                e.ctx.set_candidate_path(candidate_path)
+        self.k = 0
+
+    @property
+    def depth(self) -> int:
+        return len(self.engines)
+
+    def step_text(self, d_text: int, text_bytes: int, d_row_off: int, n_rows: int, sep: str, max_dist: int, labels_out,
+                  inputs_ready: bool = False, want_event: bool = True):
+        """inputs_ready: the text and the offsets are complete in HBM already (nothing of the caller's stream to wait for);
+        want_event = False: no event is recorded (the caller will sync()).  Both save host time per step — at 0.14 ms per step the
+        host's twelve launches are half of it."""
+        e = self.engines[self.k % len(self.engines)]
+        self.k += 1
+        if not inputs_ready:
+            e.stream.wait_stream(torch.cuda.current_stream(e.device))
+        e.n = int(n_rows)
+        e._keep = None
+        # (the context launches on the stream it was given at construction: no stream guard needed around the call)
+        e.ctx.cluster_text_device(d_text, text_bytes, d_row_off, n_rows, sep, max_dist, labels_out.data_ptr())
+        if not want_event:
+            return None
+        done = torch.cuda.Event()
+        done.record(e.stream)
+        return done
+
+    def sync(self):
+        last = (self.k - 1) % len(self.engines) if self.k else 0
+        stats, retries = None, 0
+        for i, e in enumerate(self.engines):
+            st = e.sync()
+            retries += int(st.get("n_retry_slices", 0))
+            if i == last:
+                stats = dict(st)
+        stats["n_retry_slices"] = retries
+        return stats
+
+    def close(self):
+        for e in self.engines:
+            e.ctx.close()

@@ -404,6 +404,39 @@ def test_a_join_give_up_in_an_open_text_step_that_is_not_the_last_is_repaired():
         ctx.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_text_pipeline_overlaps_the_steps_of_different_batches_and_keeps_every_batch_s_labels(depth):
+    """distributed.TextPipeline: `depth` contexts of one GPU (a stream and buffers each) take the text steps in turn, so steps of
+    different batches run beside each other; every batch's labels are its own (oracle), whatever the depth — also for batches
+    outside the device-driven launch's assumptions (a row of 200 tokens; 300 identical rows: the join gives up) in the middle"""
+    import torch
+
+    from breakfast_amd.distributed import TextPipeline
+
+    ok_a = list(dict.fromkeys(generate_profiles(3000)))
+    ok_b = list(dict.fromkeys(generate_profiles(2000, seed=5)))
+    base = [f"A{i}T" for i in range(260)]
+    long_rows = [" ".join(base[:200]), " ".join(base[:199]), "A1T A2T", "A1T"] + ok_b[:50]
+    same = ["A1T A2T A3T"] * 300 + ["A1T A2T", "C5G"] + ok_a[:40]
+    batches = [ok_a, ok_b, long_rows, ok_b, same, ok_a, ok_b, ok_a, same, ok_b, ok_a]
+    dev = [_device_text(r) for r in batches]
+    labs = [torch.full((len(r),), -3, dtype=torch.int32, device="cuda") for r in batches]
+    pipe = TextPipeline(0, depth)
+    evs = []
+    for (buf, off, d_text, d_off), rows, lab in zip(dev, batches, labs):
+        evs.append(pipe.step_text(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, lab))
+    pipe.sync()
+    assert all(e.query() for e in evs)
+    want = {}
+    for rows, lab in zip(batches, labs):
+        key = id(rows)
+        if key not in want:
+            ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
+            want[key] = orc.cluster_csr(ip, ix, 1, n_threads=ORACLE_THREADS)["labels"]
+        assert np.array_equal(lab.cpu().numpy(), want[key])
+    pipe.close()
+
+
 def test_pinned_host_buffer_for_the_text():
     """bfk_host_alloc / bfk_host_free: a caller builds its text in page-locked memory and hands that to bfk_cluster_text"""
     rows = list(dict.fromkeys(generate_profiles(20000)))
