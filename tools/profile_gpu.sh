@@ -2,7 +2,8 @@
 # Collects the rocprofv3 evidence bench.py's roofline block is checked against (run through gpurun on a GPU box):
 # Everything lands in gpurun_out/profiles/ (gpurun merges only gpurun_out/ back); copy the files into profiles/.
 #   1. the bench line itself (no profiler attached)  -> profiles/<tag>_bench.json
-#   2. kernel trace + stats of `python3 bench.py --quick`  -> profiles/<tag>_kernel_stats.csv
+#   2. kernel trace + stats of `python3 bench.py --quick --contexts 1` (one context: every step behind the one before, so a kernel's
+#      duration is its own and not that of two steps sharing the chip)  -> profiles/<tag>_kernel_stats.csv
 #   3. PMC passes (separate runs, never combined with traces): FETCH_SIZE / WRITE_SIZE, then the SQ counters
 #      -> profiles/<tag>_pmc_per_launch.json (per-kernel means per launch; FETCH_SIZE/WRITE_SIZE in KiB as
 #      rocprofv3 reports them), stamped with the digest of the kernel sources and the workload key: bench.py
@@ -21,12 +22,12 @@ cd /tmp
 export TMPDIR=/tmp
 
 if [ $skip_bench = 0 ]; then
-    python3 "$root/bench.py" "$@" > "$dst/${tag}_bench.json"
-    echo "[profile] bench line written"
+    python3 "$root/bench.py" --detail "$dst/${tag}_bench_detail.json" "$@" > "$dst/${tag}_bench.json"
+    echo "[profile] bench line written (+ the full record: ${tag}_bench_detail.json)"
 fi
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- \
-    python3 "$root/bench.py" --steps 200 --warmup 20 --quick "$@" > "$dst/${tag}_bench_under_rocprof.json"
+    python3 "$root/bench.py" --steps 200 --warmup 20 --quick --contexts 1 "$@" > "$dst/${tag}_bench_under_rocprof.json"
 echo "[profile] kernel trace done"
 
 i=0
@@ -34,7 +35,7 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES S
            "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
     timeout -k 10 180 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -o p -- \
-        python3 "$root/bench.py" --steps 20 --warmup 5 --quick "$@" > /dev/null
+        python3 "$root/bench.py" --steps 20 --warmup 5 --quick --contexts 1 "$@" > /dev/null
     echo "[profile] pmc pass $i done"
 done
 
