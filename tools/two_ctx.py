@@ -1,5 +1,5 @@
 """Throughput of text steps with 1 .. 4 contexts (distributed.TextPipeline) and the host's share: time to ENQUEUE the steps
-against time until they are done.  usage (GPU box): python tools/two_ctx.py [rows]"""
+against time until they are done.  usage (GPU box): [GPU_MAX_HW_QUEUES=n] python tools/two_ctx.py [rows [text copies [idle context 0|1 [depths, e.g. 3,2,4]]]]"""
 import sys
 import time
 from pathlib import Path
@@ -15,6 +15,7 @@ from breakfast_amd.synth import generate_profiles  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 N_COPIES = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 IDLE_CTX = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+DEPTHS = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [3, 2]
 rows = list(dict.fromkeys(generate_profiles(n)))
 buf, off = _lib.pack_rows(rows)
 T, n_u = len(buf), len(rows)
@@ -35,7 +36,7 @@ if IDLE_CTX:
     for _ in range(50):
         idle.step_text(texts[0].data_ptr(), T, d_off.data_ptr(), n_u, " ", 1)
     idle.e.sync()
-for n_ctx in (3, 2):
+for n_ctx in DEPTHS:
     pipe = TextPipeline(0, n_ctx)
     labs = [torch.empty(n_u, dtype=torch.int32, device="cuda") for _ in range(n_ctx)]
     k = [0]
