@@ -65,6 +65,8 @@ def load():
         lib.bfk_table_cluster_write.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]
         lib.bfk_table_pipeline_device.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
                                                   C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
+        lib.bfk_table_pipeline_device_gpus.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32, C.c_int32,
+                                                       C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -144,15 +146,20 @@ class Table:
         return info
 
     def pipeline_device(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length, max_dist: int,
-                        min_cluster_size: int, path):
-        """filter + collapse + CSR + clustering on the device and the writer, one native call (bfk_table_pipeline_device);
+                        min_cluster_size: int, path, n_gpus: int = 1):
+        """filter + collapse + CSR + clustering on the device and the writer, one native call (bfk_table_pipeline_device[_gpus]:
+        with n_gpus > 1 the unique rows are clustered on several devices where that pays);
         -> (PrepInfo, clusters written); Unsupported: the device stages decline the input, nothing was done"""
         opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
                           int(reference_length))
         info, n = PrepInfo(), C.c_int64()
         sepb = sep2.encode()
-        rc = self.lib.bfk_table_pipeline_device(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
-                                                str(path).encode(), C.byref(info), C.byref(n))
+        if n_gpus > 1:
+            rc = self.lib.bfk_table_pipeline_device_gpus(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
+                                                         int(n_gpus), str(path).encode(), C.byref(info), C.byref(n))
+        else:
+            rc = self.lib.bfk_table_pipeline_device(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
+                                                    str(path).encode(), C.byref(info), C.byref(n))
         if rc == EUNSUPPORTED:
             raise Unsupported(_err(self.lib))
         if rc:

@@ -120,3 +120,14 @@ extern "C" int bfk_table_pipeline_device(bfk_table *t, const char *sep2, int64_t
     if (!f) return bfk_fail(BFK_ENODEV, g_path + " does not export bfk_table_cluster_write_device");
     return f(t, sep2, sep2_len, opts, max_dist, min_cluster_size, path, info_out, n_clusters_out);  // (errors: same thread, same bfk_last_error)
 }
+
+// ... with the clustering on n_gpus devices where that pays (bfk_table_cluster_write_device_gpus)
+typedef int (*pipeline_gpus_fn)(bfk_table *, const char *, int64_t, const bfk_filter_opts *, int32_t, int32_t, int32_t, const char *, bfk_prep_info *, int64_t *);
+extern "C" int bfk_table_pipeline_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                              int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
+                                              int64_t *n_clusters_out) {
+    if (int rc = bfk_preload_wait()) return rc;
+    pipeline_gpus_fn f = (pipeline_gpus_fn)dlsym(g_handle, "bfk_table_cluster_write_device_gpus");
+    if (!f) return bfk_fail(BFK_ENODEV, g_path + " does not export bfk_table_cluster_write_device_gpus");
+    return f(t, sep2, sep2_len, opts, max_dist, min_cluster_size, n_gpus, path, info_out, n_clusters_out);
+}

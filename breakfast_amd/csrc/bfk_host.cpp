@@ -2175,8 +2175,27 @@ extern "C" int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t 
 // ever visits the host), component sizes against min_cluster_size (:329-339), clusters.tsv by the native writer.
 // max_dist must be > 0 (max-dist 0 needs no device).  info_out->nnz == 0: nothing was clustered or written — the reference
 // cannot build a matrix from an all-empty input (:214), the caller raises its error.
+// n_gpus > 1 (round 5; `--gpus N` of the CLI): filter + collapse + CSR on device 0 as above, then — where several devices pay for
+// this input (multi_worth: the rule of bfk_cluster_csr) — the unique rows' CSR comes back to the host ONCE and goes through the
+// multi-device driver (cluster_multi: every device holds the CSR, takes its share of the pair work, labels merged on device 0);
+// elsewhere the one-device path below, whatever n_gpus says.
+static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out);
+
 extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                                               int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
+    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, 1, path, info_out, n_clusters_out);
+}
+
+extern "C" int bfk_table_cluster_write_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                                   int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
+                                                   int64_t *n_clusters_out) {
+    if (n_gpus < 1 || n_gpus > 64) return fail(BFK_EARG, "n_gpus must be 1..64");
+    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, n_gpus, path, info_out, n_clusters_out);
+}
+
+static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
@@ -2191,7 +2210,13 @@ extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, in
     std::vector<int32_t> group((size_t)r.n_rows), first((size_t)std::max<int64_t>(r.n_unique, 1)), labels((size_t)std::max<int64_t>(r.n_unique, 1));
     HIP_TRY(hipMemcpyAsync(group.data(), c->pr_group, (size_t)r.n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     if (r.n_unique) HIP_TRY(hipMemcpyAsync(first.data(), c->pr_first, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
-    if (r.nnz > 0) {
+    if (r.nnz > 0 && n_gpus > 1 && multi_worth(r.n_unique, max_dist, n_gpus)) {
+        std::vector<int32_t> ip((size_t)r.n_unique + 1), ix((size_t)r.nnz);
+        HIP_TRY(hipMemcpyAsync(ip.data(), c->pr_uindptr, ip.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(ix.data(), c->pr_uindices, ix.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = cluster_multi(ip.data(), ix.data(), r.n_unique, max_dist, n_gpus, labels.data(), nullptr)) return rc;
+    } else if (r.nnz > 0) {
         // the unique rows' CSR is clustered where the collapse left it
         if (int rc = bfk_ctx_bind_csr_device(c, c->pr_uindptr, c->pr_uindices, r.n_unique)) return rc;
         if (int rc = ctx_own_labels(c, r.n_unique)) return rc;

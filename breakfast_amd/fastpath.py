@@ -47,7 +47,7 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
         table = _front.Table.open(input_file, sep, id_col, clust_col)
     except _front.Unsupported:
         return False
-    if max_dist != 0 and n_gpus == 1 and os.environ.get("BFK_DEVICE_PREP", "1") != "0":
+    if max_dist != 0 and os.environ.get("BFK_DEVICE_PREP", "1") != "0":
         # filter + collapse + CSR on the device, the unique rows clustered where they lie, the writer: ONE native call
         # (bfk_table_cluster_write_device).  It declines — nothing printed, nothing written — what only the host stage restates
         # (multi-byte token separators, tokens that match no pattern and have to be listed, ...): the stages below take over.
@@ -63,7 +63,7 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
 
         try:
             info, n_clusters = table.pipeline_device(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length,
-                                                     max_dist, min_cluster_size, outdir / "clusters.tsv")
+                                                     max_dist, min_cluster_size, outdir / "clusters.tsv", n_gpus)
         except _front.Unsupported:
             info = None
         except _front.FrontError as e:

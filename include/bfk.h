@@ -209,7 +209,7 @@ typedef struct bfk_text_stats {
     float ms_total;          /* first copy to last kernel */
     float ms_head;           /* always 0 (round 3 had a k_tok_head kernel; kept for the layout of ABI 3) */
     float reserved2_;
-    int64_t n_invalid;       /* filter mode: non-empty token occurrences that matched no pattern of the feature type */
+    int64_t n_invalid;       /* filter mode: non-empty token occurrences that matched no pattern of the feature type (noted for the host) */
     int64_t n_empty;         /* filter mode: empty tokens inside the rows' spans */
 } bfk_text_stats;
 int bfk_ctx_text_stats(bfk_ctx *ctx, bfk_text_stats *out);
@@ -344,9 +344,11 @@ int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cl
  * between the feature column's fields is blanked, every token occurrence is judged by the five feature grammars where it is
  * hashed (a dropped token never enters the vocabulary or the CSR), rows are collapsed by a hash of their identity (the kept-id
  * sequence, or the raw bytes when nothing is filtered: :128-129) with an exact comparison against the representative, unique
- * rows in first-appearance order (:72-79).  BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token
- * separators of several bytes, 4 GiB of text, NON-EMPTY tokens that match no pattern (the reference prints each, in order; the
- * empty ones are only counted: info_out->n_invalid lines "Skipping invalid feature: ''"), non-ASCII bytes under a grammar.
+ * rows in first-appearance order (:72-79).  Tokens that match no pattern (the reference prints each: rows in input order, tokens
+ * in row order, :182-184) are noted on the device as {offset, length}, put into that order on the host and handed out by
+ * bfk_table_invalid (when every one of them is an EMPTY token the table lists nothing: info_out->n_invalid lines of '').
+ * BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token separators of several bytes, 4 GiB of text,
+ * more than 65 536 non-empty tokens that match no pattern, non-ASCII bytes under a grammar.
  *   bfk_table_prepare_device        results installed in the table like bfk_table_prepare's (group, weight, CSR of the unique
  *                                   rows; the filtered feature STRINGS stay with the host stage: BFK_ESTATE from their accessors)
  *   bfk_table_cluster_write_device  the CLI's whole middle: the unique rows are clustered where the collapse left them (no CSR
@@ -359,6 +361,15 @@ int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_
 /* the same through the library bfk_preload_start loaded (libbfk_front.so: no HIP dependency of its own) */
 int bfk_table_pipeline_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                               int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out);
+/* the same with the clustering on n_gpus devices where several devices pay for the input (the rule of bfk_cluster_csr: max_dist 2
+ * from 300k unique rows, max_dist >= 3 from 500k on >= 4 devices, max_dist 1 from 2M): filter + collapse + CSR on device 0, the
+ * unique rows' CSR to every device, labels merged on device 0.  Replaces console.py:153-170 under `--gpus N` (round 5). */
+int bfk_table_cluster_write_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                        int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
+                                        int64_t *n_clusters_out);
+int bfk_table_pipeline_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                   int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
+                                   int64_t *n_clusters_out);
 
 /* write `path` = "id\tcluster_id" per input row in input order; cluster_of_unique[u] = any positive cluster
  * number or 0 for none; numbers are re-assigned 1.. by first appearance in input order (:51-60).       */

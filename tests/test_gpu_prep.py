@@ -156,6 +156,24 @@ def test_device_prepare_a_hub_of_identical_rows_and_long_tokens():
         assert int(td.weight.max()) >= 60000
 
 
+@pytest.mark.parametrize("max_dist", [2, 3])
+def test_pipeline_on_several_devices_rehearsed_on_one(max_dist, tmp_path, monkeypatch):
+    """bfk_table_cluster_write_device_gpus (`--gpus N`): filter + collapse + CSR on the device, then the unique rows' CSR through the
+    multi-device driver — every rank's contexts on device 0 here (BFK_MULTI_ONE_DEVICE=1 also forces the split, which the rule would
+    not take at this size): the same clusters.tsv as the one-device call"""
+    inp = tmp_path / "in.tsv"
+    synth.generate_tsv(inp, 30000, p_del=0.05, p_ins=0.01)
+    opts = (False, False, 264, 228, 29903)
+    t1 = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    i1, n1 = t1.cluster_write_device(" ", "covsonar_dna", *opts, max_dist, 2, tmp_path / "one.tsv")
+    monkeypatch.setenv("BFK_MULTI_ONE_DEVICE", "1")
+    t4 = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    i4, n4 = t4.cluster_write_device(" ", "covsonar_dna", *opts, max_dist, 2, tmp_path / "four.tsv", n_gpus=4)
+    assert n1 == n4 and (tmp_path / "one.tsv").read_bytes() == (tmp_path / "four.tsv").read_bytes()
+    for k in ("n_rows", "n_unique", "nnz", "n_invalid", "n_vocab", "filtered"):
+        assert getattr(i1, k) == getattr(i4, k), k
+
+
 def test_device_prepare_lists_invalid_tokens_and_declines_only_beyond_its_queue():
     """up to 65536 invalid token occurrences are noted on the device ({offset, length}) and ordered on the host; more than that
     (a file in another dialect altogether) is the host stage's"""
