@@ -511,6 +511,76 @@ struct StageTimer {
 
 int unsupported(const std::string &why) { return bfk_fail(BFK_EUNSUPPORTED, "bfk_table: input needs the general reader: " + why); }
 
+// pandas' default CSV dialect (read_table: quotechar '"', doublequote, QUOTE_MINIMAL, no escapechar — breakfast.py:16-21 passes none
+// of these) as its C tokeniser applies it: a quote OPENS a quoted field only as the field's first byte; inside, "" is one quote
+// and any other byte — separators and line breaks too — is content; after the closing quote the field runs on, verbatim, up to
+// the next separator or line end; a quote anywhere else is content.  One field of a record:
+struct Fld {
+    int64_t s0 = 0;        // first raw byte
+    int64_t cs = 0, ce = 0;  // content, when it lies in the image as it is (!rewrite)
+    int64_t e = 0;         // raw end: the separator or the line end behind it
+    bool rewrite = false;  // "" inside, or bytes behind the closing quote: the content has to be put together (unquote_field)
+};
+// A record that starts at p, separator sp; the image has a '\n' at b[n] (sentinel) and every '\r' in it is followed by '\n'.
+// -> the start of the next record (behind the record's LF — which need not be the first LF after p), or -1: the file ends inside
+// a quoted field (pandas: "EOF inside string").  Fields id_i / ft_i are handed out, all of them when `all` is given.
+int64_t quoted_record(const char *b, int64_t p, int64_t n, char sp, int id_i, int ft_i, int *ncol, Fld *id, Fld *ft, std::vector<Fld> *all) {
+    int col = 0;
+    int64_t i = p;
+    for (;;) {
+        Fld f;
+        f.s0 = i;
+        if (b[i] == '"') {
+            int64_t j = i + 1;
+            for (;;) {
+                const char *q = (const char *)memchr(b + j, '"', (size_t)(n - j));
+                if (!q) return -1;
+                j = q - b;
+                if (b[j + 1] != '"') break;
+                f.rewrite = true;
+                j += 2;
+            }
+            f.cs = i + 1;
+            f.ce = j;
+            i = j + 1;
+            if (b[i] != sp && b[i] != '\n' && b[i] != '\r') {
+                f.rewrite = true;
+                while (b[i] != sp && b[i] != '\n' && b[i] != '\r') i++;
+            }
+        } else {
+            while (b[i] != sp && b[i] != '\n' && b[i] != '\r') i++;
+            f.cs = f.s0;
+            f.ce = i;
+        }
+        f.e = i;
+        if (col == id_i && id) *id = f;
+        if (col == ft_i && ft) *ft = f;
+        if (all) all->push_back(f);
+        col++;
+        if (b[i] == sp) {
+            i++;
+            continue;
+        }
+        *ncol = col;
+        return (b[i] == '\r' ? i + 1 : i) + 1;
+    }
+}
+// the content of a field with f.rewrite, written over its own raw bytes from f.s0 on (it is never longer) -> its length
+int64_t unquote_field(char *b, const Fld &f) {
+    int64_t w = f.s0, i = f.s0 + 1;
+    for (;;) {
+        const char c = b[i];
+        if (c == '"') {
+            if (b[i + 1] != '"') break;
+            i++;
+        }
+        b[w++] = c;
+        i++;
+    }
+    for (i++; i < f.e; i++) b[w++] = b[i];
+    return w - f.s0;
+}
+
 // every id distinct?  (read_input raises on duplicates, :24-27: left to the pandas path)
 // Row-parallel: an insert-only open-addressing table of row indices, slots taken by compare-and-swap; a row that meets
 // an equal id on its probe path — whoever put it there — has found a duplicate (two rows with one id start probing at the
@@ -593,19 +663,20 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     tm.lap("open: read");
     const char *b = t->bytes.data();
     const int64_t n = sz;
-    bool any_high = false;
+    bool any_high = false, any_quote = false;
     {   // byte checks, in parallel slices
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / chunk_bytes(1 << 20) + 1));
-        std::atomic<int> bad{0}, high{0};
+        std::atomic<int> bad{0}, high{0}, quotes{0};
         parallel_chunks(parts, [&](int q) {
             int64_t i = n * q / parts;
             const int64_t e = n * (q + 1) / parts;
-            bool seen_high = false;
+            bool seen_high = false, seen_quote = false;
             auto bad_byte = [&](int64_t j) {
                 const unsigned char c = (unsigned char)b[j];
                 seen_high = seen_high || c >= 0x80;
-                // CR is accepted only as part of a CRLF line end (the reference's own fixtures are CRLF files)
-                return c == '"' || c == 0 || (c == '\r' && b[j + 1] != '\n');
+                seen_quote = seen_quote || c == '"';
+                // CR is accepted only in front of an LF (the reference's own fixtures are CRLF files)
+                return c == 0 || (c == '\r' && b[j + 1] != '\n');
             };
             // eight bytes at a time: a word without a high bit, a zero byte, a quote or a CR needs no second look
             constexpr uint64_t L = 0x0101010101010101ull, H = 0x8080808080808080ull;
@@ -627,12 +698,14 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
                     return;
                 }
             if (seen_high) high.store(1);
+            if (seen_quote) quotes.store(1);
         });
         if (bad.load()) {
             delete t;
-            return unsupported("quote, lone CR or NUL byte");
+            return unsupported("lone CR or NUL byte");
         }
         any_high = high.load() != 0;
+        any_quote = quotes.load() != 0;
         if (any_high) {
             // bytes >= 0x80 (accession names with accents, say) are opaque to an unquoted table with an ASCII separator — if
             // the file is valid UTF-8 (pandas raises UnicodeDecodeError otherwise) and does not start with a byte-order mark
@@ -671,15 +744,38 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
         return unsupported("empty file");
     }
     const int64_t header_lf = line_end(pos, &he);
+    int64_t data_start = header_lf + 1;
     int ncols = 0, id_i = -1, ft_i = -1;
     std::vector<std::string> names;
-    for (int64_t s = pos;;) {
-        const char *c = (const char *)memchr(b + s, sp, (size_t)(he - s));
-        const int64_t e = c ? c - b : he;
-        names.emplace_back(b + s, (size_t)(e - s));
-        ncols++;
-        if (!c) break;
-        s = e + 1;
+    if (any_quote && memchr(b + pos, '"', (size_t)(he - pos))) {  // quoted column names (the record may run over several lines)
+        std::vector<Fld> hf;
+        data_start = quoted_record(b, pos, n, sp, -1, -1, &ncols, nullptr, nullptr, &hf);
+        if (data_start < 0) {
+            delete t;
+            return unsupported("the file ends inside a quoted field");
+        }
+        for (const Fld &f : hf) {
+            if (!f.rewrite) {
+                names.emplace_back(b + f.cs, (size_t)(f.ce - f.cs));
+                continue;
+            }
+            std::string raw(b + f.s0, (size_t)(f.e - f.s0));
+            raw += '\n';
+            Fld g = f;
+            g.s0 = 0;
+            g.e = f.e - f.s0;
+            raw.resize((size_t)unquote_field(&raw[0], g));
+            names.push_back(raw);
+        }
+    } else {
+        for (int64_t s = pos;;) {
+            const char *c = (const char *)memchr(b + s, sp, (size_t)(he - s));
+            const int64_t e = c ? c - b : he;
+            names.emplace_back(b + s, (size_t)(e - s));
+            ncols++;
+            if (!c) break;
+            s = e + 1;
+        }
     }
     for (int i = 0; i < ncols; i++) {
         if (names[(size_t)i].empty()) {
@@ -698,9 +794,20 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
         delete t;
         return unsupported("column not found");
     }
-    pos = header_lf + 1;
-    {   // data lines, in parallel slices that start at line starts; the slices' rows are concatenated in order
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n - pos) / chunk_bytes(1 << 20) + 1));
+    pos = std::min(data_start, n);
+    // Data lines, in parallel slices that start at line starts; the slices' rows are concatenated in order.  With quotes in the
+    // file a slice boundary (the first LF behind an even split) may lie INSIDE a quoted field: then the slice in front — whose
+    // records are followed through their quoted line breaks — ends behind its boundary instead of on it.  Every slice ending
+    // on its boundary proves all of them true record starts (the first slice starts at one; induction); otherwise the lines
+    // are read again as one slice.  Nothing is written to the image before that is settled (fields that need unquoting are
+    // listed and rewritten afterwards).
+    struct Rewrite {
+        uint32_t row;  // within the slice
+        bool is_ft;
+        Fld f;
+    };
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int parts = attempt ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n - pos) / chunk_bytes(1 << 20) + 1));
         std::vector<int64_t> cut((size_t)parts + 1, n);
         cut[0] = pos;
         for (int q = 1; q < parts; q++) {
@@ -709,7 +816,9 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
             cut[(size_t)q] = at >= n ? n : std::min<int64_t>(n, line_end(at, &ce) + 1);  // the line straddling the cut stays with the slice before
         }
         std::vector<std::vector<Span>> pid((size_t)parts), pft((size_t)parts);
+        std::vector<std::vector<Rewrite>> prw((size_t)parts);
         std::vector<const char *> why((size_t)parts, nullptr);
+        std::atomic<int> off_boundary{0};
         parallel_chunks(parts, [&](int q) {
             int64_t p = cut[(size_t)q];
             const int64_t pe = cut[(size_t)q + 1];
@@ -722,6 +831,35 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
                 const int64_t lf = line_end(p, &le);
                 if (le == p) {  // blank line: skipped
                     p = lf + 1;
+                    continue;
+                }
+                if (any_quote && memchr(b + p, '"', (size_t)(le - p))) {
+                    Fld fi, ff;
+                    int col = 0;
+                    const int64_t next = quoted_record(b, p, n, sp, id_i, ft_i, &col, &fi, &ff, nullptr);
+                    if (next < 0) {
+                        why[(size_t)q] = "the file ends inside a quoted field";
+                        return;
+                    }
+                    if (col != ncols) {
+                        why[(size_t)q] = "ragged row";
+                        return;
+                    }
+                    if (fi.e - fi.s0 > INT32_MAX || ff.e - ff.s0 > INT32_MAX) {
+                        why[(size_t)q] = "field longer than 2 GiB";
+                        return;
+                    }
+                    Span id{fi.cs, (int32_t)(fi.ce - fi.cs)}, ft{ff.cs, (int32_t)(ff.ce - ff.cs)};
+                    if (fi.rewrite) prw[(size_t)q].push_back(Rewrite{(uint32_t)vi.size(), false, fi});
+                    else if (is_na(b + id.off, id.len)) {
+                        why[(size_t)q] = "NA-valued id";
+                        return;
+                    }
+                    if (ff.rewrite) prw[(size_t)q].push_back(Rewrite{(uint32_t)vi.size(), true, ff});
+                    else if (is_na(b + ft.off, ft.len)) ft.len = 0;
+                    vi.push_back(id);
+                    vf.push_back(ft);
+                    p = next;
                     continue;
                 }
                 int col = 0;
@@ -752,8 +890,10 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
                 vf.push_back(ft);
                 p = lf + 1;
             }
+            if (pe < n && p != pe) off_boundary.store(1);  // (the last slice ends on the sentinel, or one behind it)
         });
         tm.lap("open: lines and columns");
+        if (off_boundary.load() && attempt == 0) continue;  // (a line break inside a quoted field at a slice boundary: one slice)
         size_t total = 0;
         for (int q = 0; q < parts; q++) {
             if (why[(size_t)q]) {
@@ -763,12 +903,31 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
             }
             total += pid[(size_t)q].size();
         }
+        // fields with doubled quotes, or with bytes behind their closing quote: the content, written over the raw field
+        char *mb = t->bytes.data();
+        parallel_chunks(parts, [&](int q) {
+            for (const Rewrite &w : prw[(size_t)q]) {
+                Span &sp_ = (w.is_ft ? pft : pid)[(size_t)q][w.row];
+                sp_ = Span{w.f.s0, (int32_t)unquote_field(mb, w.f)};
+                if (is_na(mb + sp_.off, sp_.len)) {
+                    if (w.is_ft) sp_.len = 0;
+                    else why[(size_t)q] = "NA-valued id";
+                }
+            }
+        });
+        for (int q = 0; q < parts; q++)
+            if (why[(size_t)q]) {
+                const std::string w = why[(size_t)q];
+                delete t;
+                return unsupported(w);
+            }
         t->ids.reserve(total);
         t->feats.reserve(total);
         for (int q = 0; q < parts; q++) {
             t->ids.insert(t->ids.end(), pid[(size_t)q].begin(), pid[(size_t)q].end());
             t->feats.insert(t->feats.end(), pft[(size_t)q].begin(), pft[(size_t)q].end());
         }
+        break;
     }
     tm.lap("open: concatenate");
     if (t->ids.empty()) {
@@ -1090,11 +1249,21 @@ extern "C" int bfk_table_write(const bfk_table *t, const char *path, const int32
         char num[16];
         for (size_t r = r0; r < r1; r++) {
             const Span id = t->ids[r];
-            // csv.QUOTE_MINIMAL: only a field holding the output delimiter needs quotes here (quote, CR and LF
-            // never reach a table)
-            const bool q2 = memchr(b + id.off, '\t', (size_t)id.len) != nullptr;
+            // csv.QUOTE_MINIMAL (to_csv, :67-69): a field holding the output delimiter, a quote or a line break (an id that
+            // was quoted in the input can) is quoted, its quotes doubled
+            bool q2 = false, dq = false;
+            for (int32_t k = 0; k < id.len; k++) {
+                const char ch = b[id.off + k];
+                q2 = q2 || ch == '\t' || ch == '"' || ch == '\n' || ch == '\r';
+                dq = dq || ch == '"';
+            }
             if (q2) out += '"';
-            out.append(b + id.off, (size_t)id.len);
+            if (!dq) out.append(b + id.off, (size_t)id.len);
+            else
+                for (int32_t k = 0; k < id.len; k++) {
+                    out += b[id.off + k];
+                    if (b[id.off + k] == '"') out += '"';
+                }
             if (q2) out += '"';
             out += '\t';
             const int32_t c = cluster_of_unique[(size_t)t->group[r]];

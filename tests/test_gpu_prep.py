@@ -268,3 +268,52 @@ def test_cli_runs_the_device_stages_and_prints_what_the_host_stages_print(tmp_pa
     assert out_d == out_h and sha_d == sha_h and "Skipping invalid feature: 'notatoken'" in out_d
     inv = [ln for ln in out_d.splitlines() if ln.startswith("Skipping invalid")]
     assert [ln.split("'")[1] for ln in inv] == ["", "", "S:N501Y", "", "xyz", "", "notatoken", "", "", "foo"]
+
+
+@pytest.mark.parametrize("quoting", ["all", "minimal"])
+def test_cli_on_a_quoted_table_equals_the_pandas_mirror(quoting, tmp_path, monkeypatch):
+    """pandas' quoting dialect in the native reader (read_table's defaults, breakfast.py:16-21): a table written with
+    csv.QUOTE_ALL, and one whose fields hold quotes, tabs and line breaks where the dialect allows them — ids with doubled
+    quotes, a feature with bytes behind its closing quote (rewritten in place: the device prepare reads the image's spans), a
+    quoted feature that no pattern matches, a free-text column with line breaks — go down the device stages, the host stages
+    and the pandas mirror to the same stdout and the same clusters.tsv"""
+    import click.testing
+    import csv
+
+    from breakfast_amd import console
+
+    rows = synth.generate_profiles(6000, seed=11, p_del=0.05, p_ins=0.02)
+    inp = tmp_path / "in.tsv"
+    with open(inp, "w", newline="") as f:
+        w = csv.writer(f, delimiter="\t", quoting=csv.QUOTE_ALL if quoting == "all" else csv.QUOTE_MINIMAL, lineterminator="\n")
+        w.writerow(["accession", "note", "dna_profile"])
+        for i, r in enumerate(rows):
+            acc = f's{i}' if i % 50 else f'hCoV "x"/{i}' if i % 100 else f"two\nlines {i}"
+            note = "n" if i % 7 else 'said "so"\tthen\nleft'
+            w.writerow([acc, note, r])
+        w.writerow(["dupe", "n", rows[3]])
+    if quoting == "minimal":
+        with open(inp, "a") as f:
+            f.write('tail1\tn\t"C300T"  bogus"\n')          # bytes behind the closing quote: feature is C300T  bogus"
+            f.write('tail2\tn\t"C300T ""q"" A400G"\n')       # doubled quotes inside: the token "q" matches no pattern
+            f.write('"tail3"\t"n"\t""\n')
+            f.write('tail4\tn\t"C300T\nA400G C500T"\n')     # a line break inside the feature: part of a token
+    args = ["--input-file", str(inp), "--max-dist", "1"]
+    outs = {}
+    for name, env in (("device", {}), ("host", {"BFK_DEVICE_PREP": "0"}), ("pandas", {"BFK_NO_FASTPATH": "1"})):
+        for k in ("BFK_DEVICE_PREP", "BFK_NO_FASTPATH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        taken = []
+        real = fastpath.run
+        monkeypatch.setattr(fastpath, "run", lambda *a, **k: taken.append(real(*a, **k)) or taken[-1])
+        res = click.testing.CliRunner().invoke(console.main, args + ["--outdir", str(tmp_path / name)])
+        monkeypatch.setattr(fastpath, "run", real)
+        assert res.exit_code == 0, (res.output, res.exception)
+        assert taken == ([] if name == "pandas" else [True])
+        outs[name] = (res.output.replace(str(tmp_path / name), ""), (tmp_path / name / "clusters.tsv").read_bytes())
+    assert outs["device"] == outs["pandas"] and outs["host"] == outs["pandas"]
+    if quoting == "minimal":
+        assert "Skipping invalid feature: 'bogus\"'" in outs["device"][0] and "Skipping invalid feature: '\"q\"'" in outs["device"][0]
+    assert b'"hCoV ""x""/50"\t' in outs["device"][1] and b'"two\nlines 0"\t' in outs["device"][1]
