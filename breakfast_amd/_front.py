@@ -67,6 +67,8 @@ def load():
                                                   C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
         lib.bfk_table_pipeline_device_gpus.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32, C.c_int32,
                                                        C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
+        lib.bfk_table_pipeline_device_cache.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
+                                                        C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(PrepInfo), C.POINTER(C.c_int64)]
         _lib = lib
     return _lib
 
@@ -146,15 +148,21 @@ class Table:
         return info
 
     def pipeline_device(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length, max_dist: int,
-                        min_cluster_size: int, path, n_gpus: int = 1):
+                        min_cluster_size: int, path, n_gpus: int = 1, cache_path=None, in_cache=None):
         """filter + collapse + CSR + clustering on the device and the writer, one native call (bfk_table_pipeline_device[_gpus]:
-        with n_gpus > 1 the unique rows are clustered on several devices where that pays);
+        with n_gpus > 1 the unique rows are clustered on several devices where that pays; with cache_path every edge is recorded
+        and a side-car cache of the run is written there, with in_cache an exact side-car of this max_dist is checked against the input
+        (every cached row still there: the run equals the cache run) — bfk_table_pipeline_device_cache, one device);
         -> (PrepInfo, clusters written); Unsupported: the device stages decline the input, nothing was done"""
         opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
                           int(reference_length))
         info, n = PrepInfo(), C.c_int64()
         sepb = sep2.encode()
-        if n_gpus > 1:
+        if cache_path is not None or in_cache is not None:
+            rc = self.lib.bfk_table_pipeline_device_cache(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
+                                                          str(path).encode(), None if in_cache is None else str(in_cache).encode(),
+                                                          None if cache_path is None else str(cache_path).encode(), C.byref(info), C.byref(n))
+        elif n_gpus > 1:
             rc = self.lib.bfk_table_pipeline_device_gpus(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
                                                          int(n_gpus), str(path).encode(), C.byref(info), C.byref(n))
         else:

@@ -127,6 +127,10 @@ EXPORTS = {
                                                       C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
     "bfk_table_pipeline_device_gpus": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
+    "bfk_table_cluster_write_device_cache": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
+                                                       C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
+    "bfk_table_pipeline_device_cache": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(FilterOpts), C.c_int32, C.c_int32,
+                                                  C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(PrepInfo), c_i64p]),
     "bfk_table_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(c_i64p)]),
     "bfk_table_cluster_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, c_i64p]),
@@ -450,13 +454,17 @@ class Table:
         return info
 
     def cluster_write_device(self, sep2: str, var_type: str, skip_ins, skip_del, trim_start, trim_end, reference_length, max_dist: int,
-                             min_cluster_size: int, path, n_gpus: int = 1):
-        """bfk_table_cluster_write_device[_gpus] -> (PrepInfo, clusters written)"""
+                             min_cluster_size: int, path, n_gpus: int = 1, cache_path=None, in_cache=None):
+        """bfk_table_cluster_write_device[_gpus | _cache] -> (PrepInfo, clusters written)"""
         opts = FilterOpts(VAR_TYPES[var_type], int(bool(skip_ins)), int(bool(skip_del)), int(trim_start), int(trim_end),
                           int(reference_length))
         info, n = PrepInfo(), C.c_int64()
         sepb = sep2.encode()
-        if n_gpus > 1:
+        if cache_path is not None or in_cache is not None:
+            rc = self.lib.bfk_table_cluster_write_device_cache(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
+                                                               str(path).encode(), None if in_cache is None else str(in_cache).encode(),
+                                                               None if cache_path is None else str(cache_path).encode(), C.byref(info), C.byref(n))
+        elif n_gpus > 1:
             rc = self.lib.bfk_table_cluster_write_device_gpus(self.h, sepb, len(sepb), C.byref(opts), int(max_dist), int(min_cluster_size),
                                                               int(n_gpus), str(path).encode(), C.byref(info), C.byref(n))
         else:

@@ -121,6 +121,18 @@ extern "C" int bfk_table_pipeline_device(bfk_table *t, const char *sep2, int64_t
     return f(t, sep2, sep2_len, opts, max_dist, min_cluster_size, path, info_out, n_clusters_out);  // (errors: same thread, same bfk_last_error)
 }
 
+// ... as a side-car cache run: an exact input cache checked, every edge recorded and a side-car written (bfk_table_cluster_write_device_cache)
+typedef int (*pipeline_cache_fn)(bfk_table *, const char *, int64_t, const bfk_filter_opts *, int32_t, int32_t, const char *, const char *, const char *,
+                                 bfk_prep_info *, int64_t *);
+extern "C" int bfk_table_pipeline_device_cache(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                               int32_t min_cluster_size, const char *path, const char *in_cache, const char *cache_path,
+                                               bfk_prep_info *info_out, int64_t *n_clusters_out) {
+    if (int rc = bfk_preload_wait()) return rc;
+    pipeline_cache_fn f = (pipeline_cache_fn)dlsym(g_handle, "bfk_table_cluster_write_device_cache");
+    if (!f) return bfk_fail(BFK_ENODEV, g_path + " does not export bfk_table_cluster_write_device_cache");
+    return f(t, sep2, sep2_len, opts, max_dist, min_cluster_size, path, in_cache, cache_path, info_out, n_clusters_out);
+}
+
 // ... with the clustering on n_gpus devices where that pays (bfk_table_cluster_write_device_gpus)
 typedef int (*pipeline_gpus_fn)(bfk_table *, const char *, int64_t, const bfk_filter_opts *, int32_t, int32_t, int32_t, const char *, bfk_prep_info *, int64_t *);
 extern "C" int bfk_table_pipeline_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,

@@ -241,6 +241,19 @@ struct PrepArgs {
     uint32_t *u_indices;
     int *fail;                   // PREP_FAIL_*
 };
+// side-car cache: the two hashes of every unique row's feature string (k_row_hashes, bfk_text.hip)
+struct RowHashArgs {
+    const uint8_t *text;       // the prepare's text (blanked between the features), byte 0 = table byte `base`
+    const long long *row_off;  // [n_rows] absolute offsets of the rows' features
+    long long base;
+    const int *span_len;       // [n_rows]
+    const int *first_row;      // [n_unique]
+    int n_unique;
+    uint8_t sep;
+    TokFilter flt;
+    unsigned long long *out;   // [2 n_unique]
+};
+int launch_row_hashes(const RowHashArgs &a, hipStream_t st);
 int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, uint32_t T, uint8_t sep, hipStream_t st);
 int launch_collapse(const PrepArgs &a, hipStream_t st);
 

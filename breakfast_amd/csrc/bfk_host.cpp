@@ -1936,6 +1936,8 @@ struct PrepResult {
     int64_t n_rows = 0, n_unique = 0, nnz = 0, n_invalid = 0;
     int32_t n_vocab = 0;
     bool filtering = false;
+    int64_t base = 0;  // table byte of the device text's byte 0
+    TokFilter flt{};   // the filter the tokeniser ran with
     // the "Skipping invalid feature" lines in the reference's order (rows in input order, tokens in row order): spans into the
     // table's bytes, length 0 for an empty token.  Empty when every invalid token is an empty one (n_invalid lines of '').
     std::vector<int64_t> inv_off;
@@ -2136,6 +2138,8 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     res->n_invalid = n_invalid;
     res->n_vocab = c->tk_stats.n_vocab;
     res->filtering = filtering;
+    res->base = base;
+    res->flt = tp.flt;
     return BFK_OK;
 }
 
@@ -2179,24 +2183,87 @@ extern "C" int bfk_table_prepare_device(bfk_table *t, const char *sep2, int64_t 
 // this input (multi_worth: the rule of bfk_cluster_csr) — the unique rows' CSR comes back to the host ONCE and goes through the
 // multi-device driver (cluster_multi: every device holds the CSR, takes its share of the pair work, labels merged on device 0);
 // elsewhere the one-device path below, whatever n_gpus says.
+// cache_path (round 5; `--output-cache x.bfkc` of the CLI): the same run with every edge recorded, and a side-car cache written from
+// it — the two hashes of every unique row's feature string (k_row_hashes: the vocabulary never leaves the device) and the rows'
+// neighbour lists (self + both directions, ascending: what bfk_neighbours_csr hands out for all rows) in breakfast_amd/sidecar.py's
+// container, marked EXACT (format 2: every list is the neighbourhood of a row of the file, nothing else).
+// in_cache (`--input-cache x.bfkc`): a cache run's result — the components of the cached lists, re-indexed, plus the new rows'
+// lists (breakfast.py:294-326) — is the no-cache run's result when the cached lists are exact and every cached row is still in
+// the input (a row that is gone leaves its list behind, which still chains its neighbours: cache.py:51-71 — then, or with a
+// cache of format 1, BFK_EUNSUPPORTED and the caller's list path runs).  So an exact cache of the same max_dist is checked
+// (its rows' hashes against this input's, computed on the device) and the run is the no-cache run: the whole clustering is a
+// millisecond, less than reading the lists back.  A cache of another max_dist is not used by the reference either (:35-48).
+// One device.
 static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
-                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out);
+                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, const char *in_cache, const char *cache_path,
+                                      bfk_prep_info *info_out, int64_t *n_clusters_out);
+static int lists_from_edges(int64_t n_rows, const int64_t *select_ind, int64_t nq, const int32_t *edges, int64_t ne, int64_t **nbr_indptr_out,
+                            int32_t **nbr_indices_out);
 
 extern "C" int bfk_table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                                               int32_t min_cluster_size, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
-    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, 1, path, info_out, n_clusters_out);
+    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, 1, path, nullptr, nullptr, info_out, n_clusters_out);
+}
+
+extern "C" int bfk_table_cluster_write_device_cache(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                                    int32_t min_cluster_size, const char *path, const char *in_cache, const char *cache_path,
+                                                    bfk_prep_info *info_out, int64_t *n_clusters_out) {
+    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, 1, path, in_cache, cache_path, info_out, n_clusters_out);
 }
 
 extern "C" int bfk_table_cluster_write_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                                                    int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
                                                    int64_t *n_clusters_out) {
     if (n_gpus < 1 || n_gpus > 64) return fail(BFK_EARG, "n_gpus must be 1..64");
-    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, n_gpus, path, info_out, n_clusters_out);
+    return table_cluster_write_device(t, sep2, sep2_len, opts, max_dist, min_cluster_size, n_gpus, path, nullptr, nullptr, info_out, n_clusters_out);
+}
+
+// the side-car container of breakfast_amd/sidecar.py (little endian): MAGIC, int32 max_dist, int64 n_rows, n_lists, total; uint64[n_rows][2]
+// hashes; int64[n_lists + 1] offsets; int32[total] members
+static int write_sidecar(const char *path, int32_t max_dist, const uint64_t *hashes, int64_t n_rows, const int64_t *off, int64_t n_lists,
+                         const int32_t *flat) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(BFK_EIO, std::string("cannot write ") + path);
+    static const char magic[] = "BFKCACHE\x02\n";  // (2: exact lists)
+    const int64_t head[3] = {n_rows, n_lists, off[n_lists]};
+    bool ok = fwrite(magic, 1, 10, f) == 10 && fwrite(&max_dist, 4, 1, f) == 1 && fwrite(head, 8, 3, f) == 3;
+    ok = ok && (n_rows == 0 || fwrite(hashes, 16, (size_t)n_rows, f) == (size_t)n_rows);
+    ok = ok && fwrite(off, 8, (size_t)n_lists + 1, f) == (size_t)n_lists + 1;
+    ok = ok && (off[n_lists] == 0 || fwrite(flat, 4, (size_t)off[n_lists], f) == (size_t)off[n_lists]);
+    if (fclose(f) != 0 || !ok) return fail(BFK_EIO, std::string("short write on ") + path);
+    return BFK_OK;
+}
+
+// the hashes of an EXACT side-car cache of this max_dist -> BFK_OK (*usable = 0: another max_dist, the cache plays no part);
+// BFK_EUNSUPPORTED: format 1, or a file that is not what its header says (the list path reads it and says what is wrong)
+static int read_sidecar_hashes(const char *path, int32_t max_dist, std::vector<uint64_t> *hashes, int *usable) {
+    *usable = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(BFK_EUNSUPPORTED, std::string("cannot read ") + path);
+    char magic[10];
+    int32_t d = 0;
+    int64_t head[3] = {0, 0, 0};
+    bool ok = fread(magic, 1, 10, f) == 10 && memcmp(magic, "BFKCACHE\x02\n", 10) == 0 && fread(&d, 4, 1, f) == 1 && fread(head, 8, 3, f) == 3 &&
+              head[0] >= 0 && head[1] >= 0 && head[2] >= 0 && head[0] <= INT32_MAX;
+    if (ok && d == max_dist) {
+        hashes->resize((size_t)head[0] * 2);
+        ok = head[0] == 0 || fread(hashes->data(), 16, (size_t)head[0], f) == (size_t)head[0];
+        *usable = 1;
+    }
+    fclose(f);
+    if (!ok) return fail(BFK_EUNSUPPORTED, "side-car cache: not an exact cache (format 2) of the size its header says");
+    return BFK_OK;
 }
 
 static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
-                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out, int64_t *n_clusters_out) {
+                                      int32_t min_cluster_size, int32_t n_gpus, const char *path, const char *in_cache, const char *cache_path,
+                                      bfk_prep_info *info_out, int64_t *n_clusters_out) {
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
+    if ((cache_path || in_cache) && n_gpus != 1) return fail(BFK_EARG, "bfk_table_cluster_write_device: side-car caches go with one device");
+    std::vector<uint64_t> cached;
+    int check_cached = 0;
+    if (in_cache)
+        if (int rc = read_sidecar_hashes(in_cache, max_dist, &cached, &check_cached)) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
     DevTimer tm;
@@ -2217,11 +2284,68 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (int rc = cluster_multi(ip.data(), ix.data(), r.n_unique, max_dist, n_gpus, labels.data(), nullptr)) return rc;
     } else if (r.nnz > 0) {
+        std::vector<uint64_t> hashes;
+        if (cache_path || check_cached) {  // (before the clustering kernels run: the text and the rows' spans are the prepare's)
+            int64_t cap = 0;
+            uint64_t *d_hash = nullptr;
+            if (int rc = dev_realloc(&d_hash, &cap, 2 * r.n_unique)) return rc;
+            RowHashArgs ha;
+            ha.text = c->tk_text;
+            ha.row_off = (const long long *)c->tk_rowoff;
+            ha.base = r.base;
+            ha.span_len = c->pr_spanlen;
+            ha.first_row = c->pr_first;
+            ha.n_unique = (int)r.n_unique;
+            ha.sep = (uint8_t)sep2[0];
+            ha.flt = r.flt;
+            ha.out = (unsigned long long *)d_hash;
+            hashes.resize((size_t)(2 * r.n_unique));
+            int e = launch_row_hashes(ha, c->stream);
+            hipError_t e2 = e ? hipSuccess : hipMemcpyAsync(hashes.data(), d_hash, hashes.size() * 8, hipMemcpyDeviceToHost, c->stream);
+            if (!e && e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+            (void)hipFree(d_hash);
+            if (e || e2 != hipSuccess) return fail(BFK_EHIP, std::string("k_row_hashes: ") + hipGetErrorString(e ? (hipError_t)e : e2));
+            tm.lap("pipeline: feature hashes");
+            if (check_cached && !cached.empty()) {
+                std::vector<int64_t> where(cached.size() / 2);
+                if (int rc = bfk_match_hashes(cached.data(), (int64_t)where.size(), hashes.data(), r.n_unique, where.data())) return rc;
+                for (int64_t w : where)
+                    if (w < 0) return fail(BFK_EUNSUPPORTED, "side-car cache: a cached row is gone from the input (its list still chains its neighbours: the list path)");
+                tm.lap("pipeline: cached rows all present");
+            }
+        }
         // the unique rows' CSR is clustered where the collapse left it
         if (int rc = bfk_ctx_bind_csr_device(c, c->pr_uindptr, c->pr_uindices, r.n_unique)) return rc;
         if (int rc = ctx_own_labels(c, r.n_unique)) return rc;
-        if (int rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels)) return rc;
-        if (int rc = bfk_ctx_sync(c, nullptr)) return rc;
+        if (!cache_path) {
+            if (int rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels)) return rc;
+            if (int rc = bfk_ctx_sync(c, nullptr)) return rc;
+        } else {
+            int32_t *edges = nullptr;
+            int64_t ne = 0;
+            int rc = BFK_OK;
+            c->edge_sel_on = false;
+            for (int attempt = 0; attempt < 8; attempt++) {  // grow the queues until the run fits (as bfk_neighbours_csr does)
+                bfk_ctx_set_edge_capture(c, 1);
+                rc = bfk_ctx_cluster(c, max_dist, 0, 1, c->own_labels);
+                if (!rc) rc = bfk_ctx_sync(c, nullptr);
+                if (!rc) rc = bfk_ctx_edges(c, &edges, &ne);
+                if (rc != BFK_EOVERFLOW) break;
+                if ((rc = ctx_size_cand(c, c->cand_cap_total * 4))) break;
+            }
+            bfk_ctx_set_edge_capture(c, 0);
+            if (rc) return rc;
+            tm.lap("pipeline: cluster with every edge recorded");
+            int64_t *lp = nullptr;
+            int32_t *li = nullptr;
+            rc = lists_from_edges(r.n_unique, nullptr, r.n_unique, edges, ne, &lp, &li);
+            free(edges);
+            if (!rc) rc = write_sidecar(cache_path, max_dist, hashes.data(), r.n_unique, lp, r.n_unique, li);
+            free(lp);
+            free(li);
+            if (rc) return rc;
+            tm.lap("pipeline: lists + side-car");
+        }
         HIP_TRY(hipMemcpyAsync(labels.data(), c->own_labels, (size_t)r.n_unique * 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2286,8 +2410,16 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
     bfk_ctx_set_edge_capture(c, 0);
     c->edge_sel_on = false;
     if (rc) return rc;
-    // lists of the query rows (all rows, or the selected ones in the caller's order): neighbours in both directions + self,
-    // ascending.  slot[i] = first query position of row i (a row may be selected more than once: its list is copied)
+    rc = lists_from_edges(n_rows, select_ind, nq, edges, ne, nbr_indptr_out, nbr_indices_out);
+    free(edges);
+    return rc;
+}
+
+// lists of the query rows (all rows, or the selected ones in the caller's order) from the edges {a, b} of a run: neighbours in
+// both directions + self, ascending (get_neighbours_batch's lists, breakfast.py:223-278) -> malloc'ed CSR
+static int lists_from_edges(int64_t n_rows, const int64_t *select_ind, int64_t nq, const int32_t *edges, int64_t ne, int64_t **nbr_indptr_out,
+                            int32_t **nbr_indices_out) {
+    // slot[i] = first query position of row i (a row may be selected more than once: its list is copied)
     std::vector<int32_t> slot((size_t)n_rows, -1);
     std::vector<int64_t> qrow((size_t)nq);
     int64_t n_lists = 0;
@@ -2315,7 +2447,6 @@ extern "C" int bfk_neighbours_csr(const int32_t *indptr, const int32_t *indices,
         if (slot[(size_t)a] >= 0) adj[(size_t)fill[(size_t)slot[(size_t)a]]++] = b;
         if (slot[(size_t)b] >= 0) adj[(size_t)fill[(size_t)slot[(size_t)b]]++] = a;
     }
-    free(edges);
     for (int64_t l = 0; l < n_lists; l++) std::sort(adj.begin() + deg[(size_t)l], adj.begin() + deg[(size_t)l + 1]);
     int64_t total = 0;
     for (int64_t s = 0; s < nq; s++) total += deg[(size_t)list_of[(size_t)s] + 1] - deg[(size_t)list_of[(size_t)s]];

@@ -1078,4 +1078,66 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
     return 0;
 }
 
+// ---- side-car cache: the two 64-bit hashes of every unique row's feature string ---------------------------------------------------
+// What bfk_table_feature_hashes computes on the host (bfk_frontend.cpp: bytes_hash / bytes_hash2 over the string
+// bfk_table_feature hands out — the row's bytes as they are when nothing is filtered, the kept non-empty tokens joined by the
+// separator otherwise), for a table whose vocabulary never left the device.  One lane per unique row, over its first row's
+// bytes in the (blanked) text: both hashes start from the string's length, so a filtered row is walked twice.
+__global__ __launch_bounds__(256) void k_row_hashes(RowHashArgs a) {
+    const int u = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (u >= a.n_unique) return;
+    const int r = a.first_row[u];
+    const uint8_t *p = a.text + (a.row_off[r] - a.base);
+    const uint32_t L = (uint32_t)a.span_len[r];
+    unsigned long long n = L;
+    if (a.flt.on) {
+        n = 0;
+        uint32_t kept = 0;
+        for (uint32_t pos = 0; pos < L;) {
+            uint32_t e = pos;
+            while (e < L && p[e] != a.sep) e++;
+            if (e > pos && tok_classify(a.flt, e - pos, [&](uint32_t i) { return (uint32_t)p[pos + i]; }) == TOKV_KEEP) n += (e - pos) + (kept++ ? 1u : 0u);
+            pos = e + 1;
+        }
+    }
+    unsigned long long h1 = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull), h2 = 0xD6E8FEB86659FD93ull ^ (n * 0x9FB21C651E98DF25ull);
+    unsigned long long acc = 0;
+    uint32_t fill = 0;
+    auto put = [&](uint32_t c) {
+        acc |= (unsigned long long)c << (8 * fill);
+        if (++fill == 8) {
+            h1 = (h1 ^ acc) * 0xC4CEB9FE1A85EC53ull;
+            h1 ^= h1 >> 29;
+            h2 = (h2 ^ acc) * 0xFF51AFD7ED558CCDull;
+            h2 ^= h2 >> 31;
+            acc = 0;
+            fill = 0;
+        }
+    };
+    if (!a.flt.on) {
+        for (uint32_t i = 0; i < L; i++) put(p[i]);
+    } else {
+        uint32_t kept = 0;
+        for (uint32_t pos = 0; pos < L;) {
+            uint32_t e = pos;
+            while (e < L && p[e] != a.sep) e++;
+            if (e > pos && tok_classify(a.flt, e - pos, [&](uint32_t i) { return (uint32_t)p[pos + i]; }) == TOKV_KEEP) {
+                if (kept++) put(a.sep);
+                for (uint32_t i = pos; i < e; i++) put(p[i]);
+            }
+            pos = e + 1;
+        }
+    }
+    h1 = (h1 ^ acc) * 0xC4CEB9FE1A85EC53ull;
+    h2 = (h2 ^ acc) * 0xFF51AFD7ED558CCDull;
+    a.out[2 * (size_t)u] = h1 ^ (h1 >> 32);
+    a.out[2 * (size_t)u + 1] = h2 ^ (h2 >> 29);
+}
+
+int launch_row_hashes(const RowHashArgs &a, hipStream_t st) {
+    if (a.n_unique <= 0) return 0;
+    hipLaunchKernelGGL(k_row_hashes, dim3((unsigned)(a.n_unique + 255) / 256), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace bfk

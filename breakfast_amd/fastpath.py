@@ -39,6 +39,11 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
     if var_type not in _front.VAR_TYPES or len(sep2) == 0:
         return False
     if (input_cache is not None or output_cache) and max_dist != 0:
+        if os.environ.get("BFK_DEVICE_PREP", "1") != "0" and os.environ.get("BFK_CACHE_REUSE", "0") != "1":
+            done = _run_sidecar_on_device(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+                                          reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache)
+            if done is not None:
+                return done
         return _run_with_cache(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
                                reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache)
     if max_dist != 0:
@@ -118,6 +123,116 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
             n_clusters = table.cluster_write(max_dist, min_cluster_size, outdir / "clusters.tsv", n_gpus)
             print("Create graph and recover connected components")
             print("Save clusters")
+        print(f"Number of clusters found: {n_clusters}")
+        return True
+    finally:
+        table.close()
+
+
+_SC_MAGICS = (b"BFKCACHE\x01\n", b"BFKCACHE\x02\n")  # (sidecar.MAGIC, MAGIC_EXACT / SUFFIX / _HEAD, without that module's numpy import)
+_SC_SUFFIX = ".bfkc"
+
+
+def _sidecar_head(path):
+    """-> (max_dist, n_rows, n_lists, total, exact) of a side-car cache whose size is what its header says, else None (another
+    format, or a damaged file: sidecar.load says what is wrong with it)"""
+    import struct
+
+    try:
+        with open(path, "rb") as f:
+            magic = f.read(10)
+            if magic not in _SC_MAGICS:
+                return None
+            head = f.read(28)
+            if len(head) != 28:
+                return None
+            d, n, n_lists, total = struct.unpack("<iqqq", head)
+            if n < 0 or n_lists < 0 or total < 0 or os.fstat(f.fileno()).st_size != 10 + 28 + 16 * n + 8 * (n_lists + 1) + 4 * total:
+                return None
+            return d, n, n_lists, total, magic == _SC_MAGICS[1]
+    except OSError:
+        return None
+
+
+def _run_sidecar_on_device(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, trim_start, trim_end,
+                           reference_length, max_dist, min_cluster_size, outdir, input_cache, output_cache):
+    """Side-car cache runs on the device stages (round 5).  What a cache run computes — the components of (cached lists, re-indexed)
+    + (lists of the new rows), cluster_features' cache branch, breakfast.py:294-326 — is what a run without a cache computes
+    WHEN the cached lists are exact (sidecar.MAGIC_EXACT) and every cached row is still in the input (a row that is gone leaves
+    its list behind, which still chains its neighbours: cache.py:51-71).  The cache exists to save the distance matrix, and
+    here the whole clustering of a million rows is a millisecond, less than reading the cached lists back: so the native call
+    checks just that (the cached rows' hashes against this input's, computed on the device) and the run is the no-cache run of
+    `run` above; with an output cache every edge is recorded in that run and the side-car (feature hashes from the device,
+    lists of ALL rows, exact) is written natively.
+    -> True (done), False (the reader declined: pandas path), None (not a side-car run, a cache that is not exact or has lost
+    a row or needs a closer look, or the device stages declined: `_run_with_cache` reuses the lists; nothing printed or
+    written)."""
+    out_sc = bool(output_cache) and str(output_cache).endswith(_SC_SUFFIX)
+    if output_cache and not out_sc:
+        return None
+    head = None
+    if input_cache is not None:
+        head = _sidecar_head(input_cache)
+        if head is None or (head[0] == max_dist and not head[4]):
+            return None
+    usable = head is not None and head[0] == max_dist  # (a cache of another max-dist is announced and not used: cache.py:35-48)
+    if not out_sc and head is None:
+        return None
+    _front.preload(input_file)
+    try:
+        table = _front.Table.open(input_file, sep, id_col, clust_col)
+    except _front.Unsupported:
+        return False
+    made = not outdir.exists()
+    outdir.mkdir(parents=True, exist_ok=True)
+    if out_sc:
+        from pathlib import Path
+
+        Path(output_cache).parent.mkdir(parents=True, exist_ok=True)
+
+    def drop_outdir():
+        if made:
+            try:
+                outdir.rmdir()
+            except OSError:
+                pass
+
+    try:
+        try:
+            info, n_clusters = table.pipeline_device(sep2, var_type, skip_ins, skip_del, trim_start, trim_end, reference_length, max_dist,
+                                                     min_cluster_size, outdir / "clusters.tsv", 1, output_cache if out_sc else None,
+                                                     input_cache if usable else None)
+        except _front.Unsupported:
+            drop_outdir()
+            return None
+        except _front.FrontError as e:
+            drop_outdir()
+            if e.code in (_front.ENOMEM, _front.EHIP):
+                return None
+            raise
+        n, nu = int(info.n_rows), int(info.n_unique)
+        print(f"Number of sequences: {n}")
+        listed = table.invalid_count()
+        for i in range(int(info.n_invalid)):
+            print(f"Skipping invalid feature: '{table.invalid(i) if listed else ''}'")
+        print(f"Number of duplicates: {n - nu}")
+        print(f"Number of unique sequences: {nu}")
+        if info.nnz == 0:
+            drop_outdir()
+            raise ValueError("unable to infer matrix dimensions")  # (the reference dies here, :214)
+        if head is not None:
+            print("Import from side-car cache")
+            if not usable:  # (cache.validate, cache.py:35-48)
+                print("WARNING: Cached results were created using a differnt max-dist paramter")
+                print(f"Current max-dist parameter: {max_dist}")
+                print(f"Cached max-dist parameter: {head[0]}")
+        if not usable:
+            print("Imported cached results are not available. "
+                  "Distance matrix of complete dataset will be calculated.")
+        if out_sc:
+            print("Export results as side-car cache")
+        print("Create graph and recover connected components")
+        print("Save clusters")
         print(f"Number of clusters found: {n_clusters}")
         return True
     finally:

@@ -25,6 +25,12 @@ from . import _lib
 from . import cache as ca
 
 MAGIC = b"BFKCACHE\x01\n"
+# format 2 = the same layout with a promise: every list lies inside the neighbourhood (at max_dist) of one row OF THE FILE, and
+# together the lists hold every edge — what a run without an input cache writes, and a run that continues such a cache without
+# losing a row.  A list carried over from a row that is gone still chains that row's neighbours (cache.py:51-71): such a file is
+# format 1.  The device stages take an exact cache whose rows are all still in the input as proof that the cache run equals
+# the no-cache run (fastpath._run_sidecar_on_device).
+MAGIC_EXACT = b"BFKCACHE\x02\n"
 SUFFIX = ".bfkc"
 _HEAD = struct.Struct("<iqqq")
 
@@ -32,7 +38,15 @@ _HEAD = struct.Struct("<iqqq")
 def is_sidecar(path) -> bool:
     try:
         with open(path, "rb") as f:
-            return f.read(len(MAGIC)) == MAGIC
+            return f.read(len(MAGIC)) in (MAGIC, MAGIC_EXACT)
+    except OSError:
+        return False
+
+
+def is_exact(path) -> bool:
+    try:
+        with open(path, "rb") as f:
+            return f.read(len(MAGIC)) == MAGIC_EXACT
     except OSError:
         return False
 
@@ -41,7 +55,7 @@ def wants_sidecar(input_cache, output_cache) -> bool:
     return (bool(output_cache) and str(output_cache).endswith(SUFFIX)) or (input_cache is not None and is_sidecar(input_cache))
 
 
-def save(path, max_dist: int, hashes, list_indptr, list_indices):
+def save(path, max_dist: int, hashes, list_indptr, list_indices, exact: bool = False):
     print("Export results as side-car cache")
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
@@ -49,7 +63,7 @@ def save(path, max_dist: int, hashes, list_indptr, list_indices):
     off = np.ascontiguousarray(list_indptr, dtype="<i8")
     flat = np.ascontiguousarray(list_indices, dtype="<i4")
     with open(path, "wb") as f:
-        f.write(MAGIC)
+        f.write(MAGIC_EXACT if exact else MAGIC)
         f.write(_HEAD.pack(int(max_dist), len(hashes), len(off) - 1, len(flat)))
         hashes.tofile(f)
         off.tofile(f)
@@ -61,7 +75,7 @@ def load(path, max_dist: int):
     ValueError on a file that is short, whose counts are negative, whose offsets are not a non-decreasing run from 0 to
     `total` or whose members are not rows of the cached input (a damaged file must never turn into wrong clusters)"""
     with open(path, "rb") as f:
-        if f.read(len(MAGIC)) != MAGIC:
+        if f.read(len(MAGIC)) not in (MAGIC, MAGIC_EXACT):
             raise ValueError(f"{path} is not a side-car cache")
         print("Import from side-car cache")
         head = f.read(_HEAD.size)
@@ -122,11 +136,13 @@ def cluster_with_sidecar(hashes, indptr, indices, max_dist, input_cache, output_
     n = len(indptr) - 1
     off, flat = np.zeros(1, np.int64), np.zeros(0, np.int32)
     select = None
+    exact = True
     try:
         if input_cache is None:
             raise ca.CacheMismatch()
         c_hash, c_off, c_flat = _load_any(input_cache, max_dist)
         c2n = match_rows(c_hash, hashes)
+        exact = is_exact(input_cache) and bool(np.all(c2n >= 0))
         off, flat = update_lists(c_off, c_flat, c2n)
         known = np.zeros(n, dtype=bool)
         known[c2n[c2n >= 0]] = True
@@ -139,5 +155,5 @@ def cluster_with_sidecar(hashes, indptr, indices, max_dist, input_cache, output_
         off = np.concatenate([off, off[-1] + ptr[1:]])
         flat = np.concatenate([flat, idx.astype(np.int32)])
     if output_cache:
-        save(output_cache, max_dist, hashes, off, flat)
+        save(output_cache, max_dist, hashes, off, flat, exact)
     return _lib.labels_from_csr(n, off, flat)

@@ -374,6 +374,24 @@ int bfk_table_cluster_write_device_gpus(bfk_table *t, const char *sep2, int64_t 
 int bfk_table_pipeline_device_gpus(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
                                    int32_t min_cluster_size, int32_t n_gpus, const char *path, bfk_prep_info *info_out,
                                    int64_t *n_clusters_out);
+/* Side-car cache runs on the device stages (round 5; breakfast_amd/sidecar.py's container: the cache of src/breakfast/cache.py:18-32
+ * on flat arrays).  Either path may be NULL (both NULL: bfk_table_cluster_write_device).  One device.
+ *   cache_path (`--output-cache x.bfkc`): the same run with every edge recorded, and a side-car written from it — two 64-bit hashes
+ *     of every unique row's feature string, computed on the device where the vocabulary is, and every row's neighbour list (itself
+ *     + its neighbours, ascending: get_neighbours_batch's lists, breakfast.py:223-278) — marked EXACT (format 2).
+ *   in_cache (`--input-cache x.bfkc`): a cache run yields the components of (cached lists, re-indexed) + (lists of the new rows)
+ *     (breakfast.py:294-326), which is the no-cache run's result when the cached lists are exact and every cached row is still in
+ *     the input.  That is checked (format 2, max_dist, the cached rows' hashes against this input's) and the run is the no-cache
+ *     run — on this hardware cheaper than reading the lists back.  BFK_EUNSUPPORTED (nothing written) when a cached row is gone
+ *     (its list still chains its neighbours, cache.py:51-71) or the cache is of format 1: bfk_neighbours_csr(select_ind) +
+ *     bfk_labels_from_lists reuse the lists, as before.  A cache of another max_dist must not be passed (the reference does not
+ *     use it either, cache.py:35-48).                                                                                         */
+int bfk_table_cluster_write_device_cache(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                         int32_t min_cluster_size, const char *path, const char *in_cache, const char *cache_path,
+                                         bfk_prep_info *info_out, int64_t *n_clusters_out);
+int bfk_table_pipeline_device_cache(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, int32_t max_dist,
+                                    int32_t min_cluster_size, const char *path, const char *in_cache, const char *cache_path,
+                                    bfk_prep_info *info_out, int64_t *n_clusters_out);
 
 /* write `path` = "id\tcluster_id" per input row in input order; cluster_of_unique[u] = any positive cluster
  * number or 0 for none; numbers are re-assigned 1.. by first appearance in input order (:51-60).       */

@@ -195,3 +195,94 @@ def test_sidecar_incremental_at_100k_rows_equals_a_fresh_run(tmp_path):
         # every fresh cluster lies inside one cached cluster (the cache can only ADD connections)
         both = pd.DataFrame({"g": g["cluster_id"], "w": w["cluster_id"]}).dropna(subset=["w"])
         assert both.groupby("w")["g"].nunique(dropna=False).max() == 1
+
+
+# ---- side-car runs on the device stages (fastpath._run_sidecar_on_device, bfk_table_cluster_write_device_cache) ----------------
+def _synth_tsv(path, rows, ids=None):
+    with open(path, "w") as f:
+        f.write("accession\tdna_profile\n")
+        for i, r in enumerate(rows):
+            f.write(f"{ids[i] if ids else f'seq{i:07d}'}\t{r}\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var_type,filt,d", [("covsonar_dna", True, 1), ("covsonar_dna", True, 2), ("covsonar_dna", False, 1), ("raw", True, 1)])
+def test_device_written_sidecar_holds_the_host_stage_hashes_and_the_lists_of_all_rows(var_type, filt, d, tmp_path):
+    """bfk_table_cluster_write_device_cache: the two hashes of every unique row's feature string come from the device
+    (k_row_hashes: kept tokens re-joined, or the raw bytes when nothing is filtered) and equal bfk_table_feature_hashes of the
+    host stage; the lists are bfk_neighbours_csr's for all rows; the file is marked exact; clusters.tsv is the plain run's"""
+    from breakfast_amd import synth
+
+    rows = synth.generate_profiles(20000, seed=31, p_del=0.05, p_ins=0.02)
+    rows[7] += " notatoken"
+    rows[8] = "  " + rows[8] + "  C241T"   # empty tokens, a token the trim drops
+    rows[9] = ""
+    rows += rows[100:400]
+    inp = tmp_path / "in.tsv"
+    _synth_tsv(inp, rows)
+    opts = (" ", var_type, filt, filt, 264 if filt else 0, 228 if filt else 0, 29903)
+    t = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    info, k = t.cluster_write_device(*opts, d, 2, tmp_path / "dev.tsv", cache_path=tmp_path / "c.bfkc")
+    t.close()
+    t = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    info_h = t.prepare(*opts)
+    assert (info.n_unique, info.nnz, info.n_invalid) == (info_h.n_unique, info_h.nnz, info_h.n_invalid)
+    assert sidecar.is_exact(tmp_path / "c.bfkc")
+    h, off, flat = sidecar.load(tmp_path / "c.bfkc", d)
+    assert np.array_equal(h, t.feature_hashes())
+    ptr, idx = _lib.neighbours_csr(t.indptr, t.indices, d, None)
+    assert np.array_equal(off, ptr) and np.array_equal(flat, idx)
+    t.close()
+    t = _lib.Table.open(inp, "\t", "accession", "dna_profile")
+    _, k2 = t.cluster_write_device(*opts, d, 2, tmp_path / "host.tsv")   # (the plain run: labels only, no edge recorded)
+    t.close()
+    assert k == k2 and (tmp_path / "dev.tsv").read_bytes() == (tmp_path / "host.tsv").read_bytes()
+
+
+@pytest.mark.gpu
+def test_sidecar_runs_take_the_device_stages_when_that_is_the_same_run(tmp_path, monkeypatch):
+    """A growing input continued through exact side-cars runs as the no-cache run on the device stages (the list path is never
+    entered), with the stdout and clusters.tsv of the list path (BFK_CACHE_REUSE=1); an input that LOST a cached row, a
+    format-1 cache, and a cache of another max-dist go where the reference's semantics need them to."""
+    from breakfast_amd import fastpath, synth
+
+    rows = synth.generate_profiles(30000, seed=77, p_del=0.05, p_ins=0.02)
+    _synth_tsv(tmp_path / "a.tsv", rows[:24000])
+    _synth_tsv(tmp_path / "b.tsv", rows)                                        # grown: every cached row still there
+    lost = list(range(0, 9000)) + list(range(9500, 30000))
+    _synth_tsv(tmp_path / "c.tsv", [rows[i] for i in lost], [f"seq{i:07d}" for i in lost])   # 500 cached rows gone
+    list_path = []
+    real = fastpath._run_with_cache
+    monkeypatch.setattr(fastpath, "_run_with_cache", lambda *a, **k: list_path.append(1) or real(*a, **k))
+
+    def run(name, inp, *extra, reuse=False):
+        monkeypatch.setenv("BFK_CACHE_REUSE", "1" if reuse else "0")
+        list_path.clear()
+        res = _cli(["--input-file", str(tmp_path / inp), "--outdir", str(tmp_path / name), *extra])
+        # (the prints from the first result line on: the parameter echo in front names the run's own files)
+        return res.output[res.output.index("Number of sequences"):], (tmp_path / name / "clusters.tsv").read_bytes(), bool(list_path)
+
+    out, tsv, lp = run("a", "a.tsv", "--output-cache", str(tmp_path / "a.bfkc"))
+    assert not lp and sidecar.is_exact(tmp_path / "a.bfkc")
+    out_r, tsv_r, lp_r = run("a_r", "a.tsv", "--output-cache", str(tmp_path / "a_r.bfkc"), reuse=True)
+    assert lp_r and (out, tsv) == (out_r, tsv_r) and sidecar.is_exact(tmp_path / "a_r.bfkc")
+    for x, y in zip(sidecar.load(tmp_path / "a.bfkc", 1), sidecar.load(tmp_path / "a_r.bfkc", 1)):
+        assert np.array_equal(x, y)
+    # grown input: device stages, same prints and clusters as the list path and as a run without a cache
+    out, tsv, lp = run("b", "b.tsv", "--input-cache", str(tmp_path / "a.bfkc"), "--output-cache", str(tmp_path / "b.bfkc"))
+    out_r, tsv_r, lp_r = run("b_r", "b.tsv", "--input-cache", str(tmp_path / "a.bfkc"), "--output-cache", str(tmp_path / "b_r.bfkc"), reuse=True)
+    fresh = run("b_f", "b.tsv")
+    assert not lp and lp_r and (out, tsv) == (out_r, tsv_r) and tsv == fresh[1]
+    assert "Import from side-car cache" in out and "not available" not in out
+    assert sidecar.is_exact(tmp_path / "b.bfkc") and sidecar.is_exact(tmp_path / "b_r.bfkc")
+    # the input lost cached rows: their lists still chain their neighbours (cache.py:51-71) — the list path, format 1 out
+    out, tsv, lp = run("c", "c.tsv", "--input-cache", str(tmp_path / "b.bfkc"), "--output-cache", str(tmp_path / "c.bfkc"))
+    out_r, tsv_r, _ = run("c_r", "c.tsv", "--input-cache", str(tmp_path / "b.bfkc"), reuse=True)
+    assert lp and tsv == tsv_r and not sidecar.is_exact(tmp_path / "c.bfkc")
+    # ... and a format-1 cache is never proof of anything: list path even though no row is missing
+    out, tsv, lp = run("c2", "c.tsv", "--input-cache", str(tmp_path / "c.bfkc"))
+    assert lp and tsv == tsv_r
+    # another max-dist: announced, not used (cache.py:35-48) — the device stages
+    out, tsv, lp = run("d2", "b.tsv", "--input-cache", str(tmp_path / "c.bfkc"), "--max-dist", "2")
+    out_r, tsv_r, _ = run("d2_r", "b.tsv", "--input-cache", str(tmp_path / "c.bfkc"), "--max-dist", "2", reuse=True)
+    assert not lp and (out, tsv) == (out_r, tsv_r) and "differnt max-dist" in out and "not available" in out
