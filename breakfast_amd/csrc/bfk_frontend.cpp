@@ -667,9 +667,11 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
     {   // byte checks, in parallel slices
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / chunk_bytes(1 << 20) + 1));
         std::atomic<int> bad{0}, high{0}, quotes{0};
+        // (a byte-order mark in front of everything is dropped below: not "bytes >= 0x80" of the table)
+        const int64_t bom = n >= 3 && (unsigned char)b[0] == 0xEF && (unsigned char)b[1] == 0xBB && (unsigned char)b[2] == 0xBF ? 3 : 0;
         parallel_chunks(parts, [&](int q) {
-            int64_t i = n * q / parts;
-            const int64_t e = n * (q + 1) / parts;
+            int64_t i = std::max(n * q / parts, bom);
+            const int64_t e = std::max(n * (q + 1) / parts, i);
             bool seen_high = false, seen_quote = false;
             auto bad_byte = [&](int64_t j) {
                 const unsigned char c = (unsigned char)b[j];
@@ -707,13 +709,8 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
         any_high = high.load() != 0;
         any_quote = quotes.load() != 0;
         if (any_high) {
-            // bytes >= 0x80 (accession names with accents, say) are opaque to an unquoted table with an ASCII separator — if
-            // the file is valid UTF-8 (pandas raises UnicodeDecodeError otherwise) and does not start with a byte-order mark
-            // (pandas strips it from the first column name)
-            if (n >= 3 && (unsigned char)b[0] == 0xEF && (unsigned char)b[1] == 0xBB && (unsigned char)b[2] == 0xBF) {
-                delete t;
-                return unsupported("byte-order mark");
-            }
+            // bytes >= 0x80 (accession names with accents, say) are opaque to a table with an ASCII separator — if
+            // the file is valid UTF-8 (pandas raises UnicodeDecodeError otherwise)
             std::atomic<int> inval{0};
             parallel_chunks(parts, [&](int q) {
                 if (!utf8_valid_from(b, n * q / parts, n * (q + 1) / parts, n, q == 0)) inval.store(1);
@@ -732,11 +729,18 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
         *content_end = (lf > p && b[lf - 1] == '\r') ? lf - 1 : lf;
         return lf;
     };
-    // header = first non-empty line
+    // a line that pandas skips (skip_blank_lines): empty, or nothing but blanks and tabs that are not the separator
+    auto skipped_line = [&](int64_t p, int64_t le) {
+        for (int64_t i = p; i < le; i++)
+            if ((b[i] != ' ' && b[i] != '\t') || b[i] == sp) return false;
+        return true;
+    };
+    // header = first line that is not skipped; a UTF-8 byte-order mark in front of everything is not data (pandas drops it)
     int64_t pos = 0, he = 0;
+    if (n >= 3 && (unsigned char)b[0] == 0xEF && (unsigned char)b[1] == 0xBB && (unsigned char)b[2] == 0xBF) pos = 3;
     while (pos < n) {
         const int64_t lf = line_end(pos, &he);
-        if (he > pos) break;
+        if (!skipped_line(pos, he)) break;
         pos = lf + 1;
     }
     if (pos >= n) {
@@ -829,7 +833,7 @@ extern "C" int bfk_table_open(const char *path, const char *sep, int64_t sep_len
             while (p < pe) {
                 int64_t le;
                 const int64_t lf = line_end(p, &le);
-                if (le == p) {  // blank line: skipped
+                if (skipped_line(p, le)) {  // blank line
                     p = lf + 1;
                     continue;
                 }

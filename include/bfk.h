@@ -257,11 +257,11 @@ int bfk_ctx_edges(bfk_ctx *ctx, int32_t **edges_out, int64_t *n_edges_out);
  *   bfk_table_write       replaces write_output          :32-69
  * The reader restates read_table's default dialect as pandas' C tokeniser applies it — '"' opens a quoted
  * field only as the field's first byte, "" inside is one quote, separators and line breaks inside are
- * content, bytes behind the closing quote run on verbatim, NA strings are NaN quoted or not — and valid
- * UTF-8.  It is strict about the rest: what pandas would refuse or read in a way not restated here (a file
- * that ends inside a quoted field, a lone CR, NUL, invalid UTF-8 or a byte-order mark, ragged or
- * whitespace-only rows, NA-valued or duplicate ids, duplicate / missing column names, multi-byte
- * separators, no data rows) returns BFK_EUNSUPPORTED and the caller uses the
+ * content, bytes behind the closing quote run on verbatim, NA strings are NaN quoted or not —, valid
+ * UTF-8 with or without a byte-order mark, and its skipping of empty and blank-only lines.  It is strict
+ * about the rest: what pandas would refuse or read in a way not restated here (a file that ends inside a
+ * quoted field, a lone CR, NUL, invalid UTF-8, ragged rows, NA-valued or duplicate ids, duplicate /
+ * missing column names, multi-byte separators, no data rows) returns BFK_EUNSUPPORTED and the caller uses the
  * reference's own pandas reader, which also raises the reference's exceptions.  For every input it accepts,
  * the result is byte-identical to that path (tests/test_frontend.py).
  * ------------------------------------------------------------------------------------------------- */

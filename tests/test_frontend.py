@@ -137,6 +137,12 @@ def _both_readers(path, sep="\t", id_col="id", feat="f"):
     ("id\tf\nhCoV-19/Cote d\u2019Ivoire/\u00e9\u00e8/2021\tX Y\nM\u00fcnchen-7\tX\n\u6771\u4eac\U0001f9ec\tZ\n", "\t"),  # UTF-8 ids (2-, 3-, 4-byte forms)
     ("id\tf\na\tX\u00e9 Y\nb\tY X\u00e9\nc\tX\u00e9 Y\n", "\t"),   # UTF-8 in the feature column, nothing filtered: opaque bytes
     ("n\u00e4me\tid\tf\n\u00e9\ta\tX\n\u00e8\tb\tY\n", "\t"),     # UTF-8 in a column that is not used, and in its name
+    ("\ufeffid\tf\na\tX\n", "\t"),            # byte-order mark (pandas drops it)
+    ('\ufeff"id"\tf\n\u00e9\tX\n', "\t"),     # ... in front of a quoted name
+    ("\ufeff\n  \nid\tf\na\tX\n", "\t"),      # ... in front of skipped lines
+    ("id\tf\n   \nc\td\n \n", "\t"),         # lines of blanks are skipped like empty ones
+    ("  \nid,f\na,X\n \t \nb,Y\n\t\n", ","),   # ... blanks and tabs, when the tab is not the separator
+    ("id\tf\na\tX\n \t \nc\tZ\n", "\t"),     # ... but not when it is: a row of two blank fields
 ])
 @pytest.mark.parametrize("chunk_bytes", [None, "1", "5"])
 def test_reader_accepts_and_matches_pandas(text, sep, chunk_bytes, tmp_path, monkeypatch):
@@ -162,8 +168,7 @@ def test_reader_accepts_and_matches_pandas(text, sep, chunk_bytes, tmp_path, mon
     "id\tf\tf\na\tX\tY\n",            # duplicate column names
     "id\tf\n",                        # no rows
     "",                               # empty
-    "\ufeffid\tf\na\tX\n",             # byte-order mark (pandas strips it from the first column name)
-    "id\tf\n   \nc\td\n",             # whitespace-only line
+    "id\tf\na\tX\n\t\nb\tY\n",          # a row of two empty fields: NA-valued id
 ])
 @pytest.mark.parametrize("chunk_bytes", [None, "3"])
 def test_reader_declines(text, chunk_bytes, tmp_path, monkeypatch):
