@@ -189,6 +189,8 @@ def compact_line(out: dict) -> dict:
     line.update(pick(out, ("clusters_tsv_wall_s", "clusters_tsv_wall_median_s", "clusters_tsv_wall_ordinary_exit_s")))
     if cli:
         line["clusters_tsv_sha256_matches_reference"] = cli.get("sha256_matches_reference")
+    if out.get("labels_only_any_ids"):
+        line["labels_only_any_ids"] = pick(out["labels_only_any_ids"], ("ms_per_step", "value", "labels_equal"))
     line["value_resident_csr"] = out.get("value_resident_csr")
     line["resident_csr_ms_per_step"] = (out.get("resident_csr") or {}).get("ms_per_step")
     if out.get("all_pairs"):
@@ -631,6 +633,24 @@ def main():
         n_sus = int(min(100000, max(a.steps, math.ceil(1.0 / max(ms_step * 1e-3, 1e-6)))))
         e2, _ = timed(run_step, n_sus, run_sync)
         sustained = {"steps": n_sus, "seconds": round(e2, 4), "ms_per_step": e2 / n_sus * 1e3}
+    # ---- beside it, not `value`: the same steps with bfk_ctx_set_token_ids(ctx, 1) — a labels-only step at max-dist 1 may keep the
+    # vocabulary table's slot numbers as column ids (an injective renaming of the reference's first-appearance ids: same distances,
+    # same labels; three kernels and the first-occurrence walk fewer).  `value` stays the step that builds the reference's CSR.
+    any_ids = None
+    if world == 1 and not a.quick and d == 1:
+        ctxs = [e.ctx for e in pipe.engines] if n_ctx != 1 else [eng.ctx]
+        for c_ in ctxs:
+            c_.set_token_ids(True)
+        warm(run_step, 100, run_sync)
+        e3, _ = timed(run_step, a.steps, run_sync)
+        lab_any = [x[:n_u].cpu().numpy() for x in (p_labels if n_ctx != 1 else [sc.labels[0]])]
+        for c_ in ctxs:
+            c_.set_token_ids(False)
+        warm(run_step, 20, run_sync)
+        any_ids = {"ms_per_step": e3 / a.steps * 1e3, "value": n_u * (n_u - 1) / 2 * a.steps / e3, "contexts": n_ctx,
+                   "labels_equal": bool(all(np.array_equal(x, labels) for x in lab_any)),
+                   "what": "the timed steps again with bfk_ctx_set_token_ids(ctx, 1): column ids = vocabulary table slots (no "
+                           "k_voc_count / k_voc_ids / k_tok_ids, no first-occurrence walk); not the reference's CSR, the same labels"}
     st, tk = profiled_text()
     edges_per_rank = None
     if world > 1:
@@ -952,6 +972,8 @@ def main():
         }
         if sustained:
             out["sustained"] = sustained
+        if any_ids:
+            out["labels_only_any_ids"] = any_ids
         if cold is not None:
             out["resident_csr"]["ms_per_step_cold"] = cold
         if host:

@@ -103,6 +103,7 @@ EXPORTS = {
     "bfk_ctx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bfk_ctx_set_edge_capture": (C.c_int, [C.c_void_p, C.c_int32]),
     "bfk_ctx_set_exact_edges": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bfk_ctx_set_token_ids": (C.c_int, [C.c_void_p, C.c_int32]),
     "bfk_ctx_edges": (C.c_int, [C.c_void_p, C.POINTER(c_i32p), c_i64p]),
     "bfk_table_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "bfk_table_from_buffers": (C.c_int, [C.c_char_p, c_i64p, C.c_char_p, c_i64p, C.c_int64, C.POINTER(C.c_void_p)]),
@@ -263,11 +264,12 @@ class PinnedBuffer:
             pass
 
 
-def cluster_text(buf, row_off, sep: str, max_dist: int, want_stats: bool = True, indptr_out=None, labels_out=None):
+def cluster_text(buf, row_off, sep: str, max_dist: int, want_stats: bool = True, indptr_out=None, labels_out=None, want_vocab: bool = True):
     """bfk_cluster_text: profile text -> (labels, stats dict, nnz, n_vocab); the CSR is built and stays on the device.
     buf: bytes, or a PinnedBuffer (bfk_host_alloc).  want_stats=False passes stats_out = NULL (the counters that need
     host-side sums are then not gathered); indptr_out: optional int32[N+1] array that receives the CSR's row pointer;
-    labels_out: optional int32[N] array to write the labels into (no allocation per call)."""
+    labels_out: optional int32[N] array to write the labels into (no allocation per call); want_vocab=False passes
+    n_vocab_out = NULL (n_vocab comes back as -1): with BFK_TOK_ANY_IDS=1 a max_dist-1 step then keeps table slots as ids."""
     lib = load()
     off = np.ascontiguousarray(row_off, dtype=np.int64)
     n = len(off) - 1
@@ -278,12 +280,12 @@ def cluster_text(buf, row_off, sep: str, max_dist: int, want_stats: bool = True,
     if isinstance(buf, PinnedBuffer):
         buf = C.cast(buf.ptr, C.c_char_p)
     rc = lib.bfk_cluster_text(buf, _p64(off), n, sepb, len(sepb), int(max_dist), _p32(labels),
-                              C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv),
+                              C.byref(st) if want_stats else None, C.byref(nnz), C.byref(nv) if want_vocab else None,
                               None if indptr_out is None else _p32(indptr_out))
     if rc == -1 and len(sepb) == 0:
         raise ValueError("empty separator")
     _check(rc)
-    return labels[:n], (st.as_dict() if want_stats else None), int(nnz.value), int(nv.value)
+    return labels[:n], (st.as_dict() if want_stats else None), int(nnz.value), int(nv.value) if want_vocab else -1
 
 
 def cluster_csr(indptr, indices, max_dist: int, n_gpus: int = 1):
@@ -590,6 +592,12 @@ class Context:
         """on: every candidate pair is checked, `n_edges` is the number of edges of the graph; off (default): labels-only
         steps at max_dist >= 3 drop candidates whose rows are already in one component (`n_connected`)."""
         _check(self.lib.bfk_ctx_set_exact_edges(self.h, 1 if on else 0))
+        self.config_epoch += 1
+
+    def set_token_ids(self, any_ids: bool = True):
+        """any_ids: labels-only text steps at max_dist 1 keep the vocabulary table's slot numbers as column ids (an injective
+        renaming of the reference's first-appearance ids: same labels, three kernels fewer); off (default): the reference's CSR"""
+        _check(self.lib.bfk_ctx_set_token_ids(self.h, 1 if any_ids else 0))
         self.config_epoch += 1
 
     def set_candidate_path(self, mode: str = "auto"):

@@ -181,6 +181,8 @@ struct TokArgs {
     uint8_t sep;
     int strict;                // 1: also check row_off[0] == base and row_off[n_rows] == base + T (offsets from a caller's device memory)
     uint32_t *rowbits, *startbits, *boundbits;  // one bit per byte position: row start / token start / separator or row start
+    int any_ids;               // 1: the CSR's column ids are the tokens' table SLOTS (an injective renaming of the first-appearance
+                               // ids; what clustering needs) — no first-occurrence bits, no k_voc_count / k_voc_ids / k_tok_ids
     uint32_t *firstbits;       // ... / a token's first occurrence starts here
     uint32_t *keptbits;        // filter mode: ... / a token that survives the filter starts here (the CSR counts these instead of startbits)
     uint32_t *keptwin, *keptblk; // filter mode: kept tokens in front of every window inside its scan block / in front of every scan block

@@ -51,6 +51,8 @@ struct bfk_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool profiling = false, edge_capture = false;
     int exact_edges = -1;  // -1: library default (BFK_EXACT_EDGES, else off), 0 / 1: bfk_ctx_set_exact_edges
+    int tok_any_ids = -1;  // -1: library default (BFK_TOK_ANY_IDS, else off), 0 / 1: bfk_ctx_set_token_ids
+    bool tok_any_now = false;
     static constexpr int EV_SLOTS = 64;  // ring of per-step event sets: up to 64 steps are averaged per sync
     hipEvent_t ev[EV_SLOTS][5] = {};
     bool ev_ready = false;
@@ -175,6 +177,7 @@ struct bfk_ctx {
         uint2 *d_inv = nullptr;           // filter mode: where the invalid token occurrences are noted (inv_cap of them)
         uint32_t inv_cap = 0;
         uint32_t *d_row_empties = nullptr;  // filter mode: empty tokens per row
+        bool any_ids = false;               // the CSR's column ids may be any injective renaming (TokArgs::any_ids)
     };
     struct SpecStep {
         TokPlan tp;
@@ -311,6 +314,22 @@ extern "C" int bfk_ctx_set_candidate_path(bfk_ctx *c, int32_t mode) {
     }
     c->path_mode = mode;
     return BFK_OK;
+}
+
+// Text steps at max_dist 1 that hand out labels only: the column ids of the CSR they bind need not be the reference's
+// first-appearance numbers — any injective renaming gives the same distances, hence the same labels — so the tokeniser may
+// stop at the vocabulary table's slot numbers (TokArgs::any_ids: no first-occurrence walk, no k_voc_count / k_voc_ids /
+// k_tok_ids).  Off by default: bfk_ctx_download_csr after such a step shows slots, not the reference's ids.
+extern "C" int bfk_ctx_set_token_ids(bfk_ctx *c, int32_t any_ids) {
+    if (int rc = ctx_enter(c)) return rc;
+    c->tok_any_ids = any_ids != 0;
+    return BFK_OK;
+}
+static bool tok_any_ids_wanted(const bfk_ctx *c, int32_t max_dist) {
+    if (max_dist != 1) return false;  // (the prefix groups of max_dist >= 2 count tokens in tables indexed by id)
+    if (c->tok_any_ids >= 0) return c->tok_any_ids != 0;
+    const char *e = getenv("BFK_TOK_ANY_IDS");
+    return e && atoi(e) != 0;
 }
 
 extern "C" int bfk_ctx_set_exact_edges(bfk_ctx *c, int32_t enable) {
@@ -558,6 +577,7 @@ static int ctx_tok_launch(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int attempt, b
     a.keptwin = c->tk_winbase + 2 * n_win + 2 * n_blk;
     a.keptblk = c->tk_winbase + 3 * n_win + 2 * n_blk;
     a.flt = tp.flt;
+    a.any_ids = tp.any_ids && !tp.flt.on ? 1 : 0;
     a.inv_queue = tp.d_inv;
     a.inv_cap = tp.d_inv ? tp.inv_cap : 0u;
     a.row_empties = tp.d_row_empties;
@@ -655,9 +675,10 @@ static int ctx_tok_finish(bfk_ctx *c, const bfk_ctx::TokPlan &tp, bool *retry, i
     if ((int64_t)(tp.flt.on ? tc.nnz_kept : tc.nnz) != c->nnz) return fail(BFK_EHIP, "device tokeniser: token count and indptr disagree");
     c->tk_stats.n_invalid = tc.n_invalid;
     c->tk_stats.n_empty = tc.n_empty;
-    c->max_tok = (int)tc.n_vocab - 1;  // ids are 0 .. n_vocab - 1: the prefix-group path needs no k_maxtok pass
+    const bool any_ids = tp.any_ids && !tp.flt.on;  // (slots as ids: the vocabulary was not counted, the largest id is not known)
+    c->max_tok = any_ids ? -1 : (int)tc.n_vocab - 1;  // ids are 0 .. n_vocab - 1: the prefix-group path needs no k_maxtok pass
     c->tk_stats.nnz = c->nnz;
-    c->tk_stats.n_vocab = (int32_t)tc.n_vocab;
+    c->tk_stats.n_vocab = any_ids ? -1 : (int32_t)tc.n_vocab;
     if (hipEvent_t *ev = c->profiling ? c->tk_ev : nullptr) {  // (profiled steps are completed one at a time: the events are this step's)
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tk_stats.ms_scan = ms;
@@ -895,6 +916,7 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     tp.strict = false;
     tp.n_pieces = n_pieces;
     memcpy(tp.piece_blk, piece_blk, sizeof tp.piece_blk);
+    tp.any_ids = spec_d >= 0 && !n_vocab_out && tok_any_ids_wanted(c, spec_d);  // (bfk_cluster_text without a vocabulary count)
     int rc;
     if (spec_d >= 0 && spec_wanted(c, n_rows, T, spec_d)) {
         // bfk_cluster_text: the clustering kernels follow the tokeniser without the host in between; the caller's buffers are
@@ -932,6 +954,7 @@ extern "C" int bfk_ctx_build_csr_device(bfk_ctx *c, void *d_text, int64_t text_b
     tp.n_rows = n_rows;
     tp.sep = sep[0];
     tp.strict = true;
+    tp.any_ids = c->tok_any_now;  // (set by bfk_ctx_cluster_text_device around its call: a caller of this entry gets the reference's ids)
     return ctx_tokenize(c, tp, nnz_out, n_vocab_out);
 }
 
@@ -955,9 +978,13 @@ extern "C" int bfk_ctx_cluster_text_device(bfk_ctx *c, void *d_text, int64_t tex
         tp.n_rows = n_rows;
         tp.sep = sep[0];
         tp.strict = true;
+        tp.any_ids = tok_any_ids_wanted(c, max_dist);
         return ctx_spec_enqueue(c, tp, max_dist, d_labels_out);
     }
-    if (int rc = bfk_ctx_build_csr_device(c, d_text, text_bytes, d_row_off, n_rows, sep, sep_len, nullptr, nullptr)) return rc;
+    c->tok_any_now = tok_any_ids_wanted(c, max_dist);
+    const int rc = bfk_ctx_build_csr_device(c, d_text, text_bytes, d_row_off, n_rows, sep, sep_len, nullptr, nullptr);
+    c->tok_any_now = false;
+    if (rc) return rc;
     return bfk_ctx_cluster(c, max_dist, 0, 1, d_labels_out);
 }
 

@@ -786,6 +786,13 @@ __global__ __launch_bounds__(256) void k_tok_rows(TokArgs a) {
             if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(small + 1, 1);
         }
     }
+    if (a.any_ids) {  // slots serve as ids: no vocabulary walk; the row-start bits are cleared for the next build here (k_voc_ids' job)
+        if (a.rows_clear_after) {
+            uint4 *rb4 = reinterpret_cast<uint4 *>(a.rowbits);
+            for (uint32_t i = tid, n16 = (a.T_pad / 32u + 16u) / 4u; i < n16; i += nth) rb4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
     for (uint32_t s = tid; s <= a.tmask; s += nth) {
         const TokSlot e = a.table[s];
         if (e.key != TOK_EMPTY) {
@@ -1055,8 +1062,13 @@ int launch_tokenize(const TokArgs &a, hipStream_t st, hipEvent_t *ev, int n_piec
             LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(k_tok_rows, dim3(std::max(table_blocks, (unsigned)std::min(8192, (a.n_rows + 256) / 256))), dim3(256), 0, st, a);
+    const bool any_ids = a.any_ids && !a.flt.on;
+    hipLaunchKernelGGL(k_tok_rows, dim3(std::max(any_ids ? 256u : table_blocks, (unsigned)std::min(8192, (a.n_rows + 256) / 256))), dim3(256), 0, st, a);
     LAUNCH_CHECK();
+    if (any_ids) {  // the slot array IS the indices array, and stays as it is
+        if (ev) (void)hipEventRecord(ev[3], st);
+        return 0;
+    }
     hipLaunchKernelGGL(k_voc_count, dim3(scan_blocks), dim3(512), 0, st, a.firstbits, a.vocwin, a.vocblk);
     LAUNCH_CHECK();
     const bool voc_scan_in_ids = scan_blocks <= 1024 && !(a.dbg & 64);

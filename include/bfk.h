@@ -242,6 +242,15 @@ int bfk_ctx_device_free(bfk_ctx *ctx, void *d_ptr);
  * graph (what the parity tests compare); 0: the default (pruning at max_dist >= 3). */
 int bfk_ctx_set_exact_edges(bfk_ctx *ctx, int32_t enable);
 
+/* Text steps that only deliver labels (bfk_ctx_cluster_text_device, bfk_cluster_text without n_vocab_out) at max_dist 1 do
+ * not need the reference's first-appearance column numbers (sparse_feature_matrix hands out `len(vocabulary)` at a token's first
+ * sight, breakfast.py:210; nothing the reference writes depends on the numbering): any injective renaming gives the same
+ * distances and the same labels.  any_ids = 1: such steps stop at the vocabulary table's slot numbers — three kernels and the
+ * first-occurrence walk fewer; bfk_ctx_download_csr then shows slots, bfk_text_stats.n_vocab is -1.  0: the default — every
+ * bound CSR is the reference's CSR.  bfk_build_csr_device / bfk_ctx_build_csr / bfk_ctx_build_csr_device always number by
+ * first appearance. */
+int bfk_ctx_set_token_ids(bfk_ctx *ctx, int32_t any_ids);
+
 /* edges of the last bfk_ctx_cluster run with edge capture enabled: (i<j) int32 pairs, library-allocated */
 int bfk_ctx_set_edge_capture(bfk_ctx *ctx, int32_t enable);
 int bfk_ctx_edges(bfk_ctx *ctx, int32_t **edges_out, int64_t *n_edges_out);

@@ -206,6 +206,66 @@ def test_text_resident_in_hbm_gives_the_same_csr_and_labels(case):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["synthetic", "indels", "kat_shapes", "long_rows", "big_vocabulary"])
+@pytest.mark.parametrize("path", ["auto", "allpairs"])
+def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, path, monkeypatch):
+    """bfk_ctx_set_token_ids(ctx, 1): a labels-only text step at max_dist 1 stops at the vocabulary table's slot numbers (no
+    first-occurrence walk, no k_voc_count / k_voc_ids / k_tok_ids).  The labels are the oracle's; the CSR it leaves bound has
+    the reference's indptr and an INJECTIVE renaming of the reference's column ids; the same context numbers by first
+    appearance again as soon as it is asked for a CSR or for another max_dist (device-driven steps, steps that wait once, the
+    band kernels, rows longer than the device-driven form assumes, a vocabulary that makes the table grow)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    rows = {"synthetic": list(dict.fromkeys(generate_profiles(20000))),
+            "indels": list(dict.fromkeys(generate_profiles(5000, p_del=0.05, p_ins=0.01))),
+            "kat_shapes": ["X Y", "X X Y", "", "Y X", "X  Y", "Q R S", "ab", "cd", "ab cd", "abcd", " ", "X", "X Y Z", "Y Z"],
+            "long_rows": [" ".join(f"T{int(x)}" for x in rng.integers(0, 400, size=int(rng.integers(120, 200)))) for _ in range(300)],
+            "big_vocabulary": [" ".join(f"U{i}_{j}" for j in range(20)) for i in range(6000)] + ["U5_1 U5_2", "U5_1 U5_2 U5_3"]}[case]
+    if case == "long_rows":
+        rows += [r + " EXTRA" for r in rows[:50]]
+    buf, off, d_text, d_off = _device_text(rows)
+    want = orc.sparse_feature_matrix(rows, " ")
+    want_labels = {d: orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"] for d in (1, 2)}
+    ctx = _lib.Context(0)
+    ctx.set_candidate_path(path)
+    ctx.set_token_ids(True)
+    d_lab = torch.empty(len(rows), dtype=torch.int32, device="cuda")
+    for rep in range(3):  # (steps on one context: the row bits cleared by one step serve the next)
+        ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())
+        ctx.sync()
+        assert np.array_equal(d_lab.cpu().numpy(), want_labels[1]), rep
+    ip, ix = ctx.download_csr()
+    assert np.array_equal(ip, want[0])
+    fwd, back = {}, {}
+    for a, b in zip(want[1].tolist(), ix.tolist()):   # the renaming is a bijection between the two vocabularies
+        assert fwd.setdefault(a, b) == b and back.setdefault(b, a) == a
+    assert ctx.text_stats()["n_vocab"] == -1
+    # another max_dist, and any entry that hands out a CSR: first-appearance ids, as ever
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 2, d_lab.data_ptr())
+    ctx.sync()
+    assert np.array_equal(d_lab.cpu().numpy(), want_labels[2])
+    ip, ix = ctx.download_csr()
+    assert np.array_equal(ip, want[0]) and np.array_equal(ix, want[1])
+    nnz, nv = ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ")
+    assert (nnz, nv) == (len(want[1]), want[2])
+    ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(rows), " ", 1, d_lab.data_ptr())   # and slots again
+    ctx.sync()
+    assert np.array_equal(d_lab.cpu().numpy(), want_labels[1])
+    # a slot-numbered CSR that stays bound serves other max_dist too (the prefix groups find the largest id themselves)
+    for d in (2, 3):
+        ctx.cluster(d, d_lab.data_ptr())
+        ctx.sync()
+        assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"]), d
+    ctx.close()
+    # the one-shot entry: host text -> labels, without the vocabulary count (slots) and with it (first appearance)
+    monkeypatch.setenv("BFK_TOK_ANY_IDS", "1")
+    got = _lib.cluster_text(buf, off, " ", 1, want_vocab=False)
+    assert np.array_equal(got[0], want_labels[1]) and got[2] == len(want[1]) and got[3] == -1
+    got = _lib.cluster_text(buf, off, " ", 1)
+    assert np.array_equal(got[0], want_labels[1]) and got[3] == want[2]
+
+
 def test_builds_of_changing_size_on_one_context_leave_no_row_bits_behind():
     """the row-start bits of a build are cleared by the build itself when it is done with them, and the next build sets its
     own in k_tok_clear (no k_tok_rowbits launch) — as long as it is no longer than what was cleared: texts that shrink, grow,
