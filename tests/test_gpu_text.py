@@ -207,8 +207,7 @@ def test_text_resident_in_hbm_gives_the_same_csr_and_labels(case):
 
 
 @pytest.mark.parametrize("case", ["synthetic", "indels", "kat_shapes", "long_rows", "big_vocabulary"])
-@pytest.mark.parametrize("path", ["auto", "allpairs"])
-def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, path, monkeypatch):
+def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, monkeypatch):
     """bfk_ctx_set_token_ids(ctx, 1): a labels-only text step at max_dist 1 stops at the vocabulary table's slot numbers (no
     first-occurrence walk, no k_voc_count / k_voc_ids / k_tok_ids).  The labels are the oracle's; the CSR it leaves bound has
     the reference's indptr and an INJECTIVE renaming of the reference's column ids; the same context numbers by first
@@ -217,7 +216,7 @@ def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, path, monkey
     import torch
 
     rng = np.random.default_rng(5)
-    rows = {"synthetic": list(dict.fromkeys(generate_profiles(20000))),
+    rows = {"synthetic": list(dict.fromkeys(generate_profiles(12000))),
             "indels": list(dict.fromkeys(generate_profiles(5000, p_del=0.05, p_ins=0.01))),
             "kat_shapes": ["X Y", "X X Y", "", "Y X", "X  Y", "Q R S", "ab", "cd", "ab cd", "abcd", " ", "X", "X Y Z", "Y Z"],
             "long_rows": [" ".join(f"T{int(x)}" for x in rng.integers(0, 400, size=int(rng.integers(120, 200)))) for _ in range(300)],
@@ -226,7 +225,20 @@ def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, path, monkey
         rows += [r + " EXTRA" for r in rows[:50]]
     buf, off, d_text, d_off = _device_text(rows)
     want = orc.sparse_feature_matrix(rows, " ")
-    want_labels = {d: orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"] for d in (1, 2)}
+    want_labels = {d: orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"] for d in (1, 2, 3)}
+    for path in ("auto", "allpairs"):
+        _slots_as_ids_on_one_context(rows, buf, off, d_text, d_off, want, want_labels, path)
+    # the one-shot entry: host text -> labels, without the vocabulary count (slots) and with it (first appearance)
+    monkeypatch.setenv("BFK_TOK_ANY_IDS", "1")
+    got = _lib.cluster_text(buf, off, " ", 1, want_vocab=False)
+    assert np.array_equal(got[0], want_labels[1]) and got[2] == len(want[1]) and got[3] == -1
+    got = _lib.cluster_text(buf, off, " ", 1)
+    assert np.array_equal(got[0], want_labels[1]) and got[3] == want[2]
+
+
+def _slots_as_ids_on_one_context(rows, buf, off, d_text, d_off, want, want_labels, path):
+    import torch
+
     ctx = _lib.Context(0)
     ctx.set_candidate_path(path)
     ctx.set_token_ids(True)
@@ -256,14 +268,8 @@ def test_labels_only_steps_may_keep_table_slots_as_column_ids(case, path, monkey
     for d in (2, 3):
         ctx.cluster(d, d_lab.data_ptr())
         ctx.sync()
-        assert np.array_equal(d_lab.cpu().numpy(), orc.cluster_csr(want[0], want[1], d, n_threads=ORACLE_THREADS)["labels"]), d
+        assert np.array_equal(d_lab.cpu().numpy(), want_labels[d]), d
     ctx.close()
-    # the one-shot entry: host text -> labels, without the vocabulary count (slots) and with it (first appearance)
-    monkeypatch.setenv("BFK_TOK_ANY_IDS", "1")
-    got = _lib.cluster_text(buf, off, " ", 1, want_vocab=False)
-    assert np.array_equal(got[0], want_labels[1]) and got[2] == len(want[1]) and got[3] == -1
-    got = _lib.cluster_text(buf, off, " ", 1)
-    assert np.array_equal(got[0], want_labels[1]) and got[3] == want[2]
 
 
 def test_builds_of_changing_size_on_one_context_leave_no_row_bits_behind():
