@@ -317,3 +317,41 @@ def test_cli_on_a_quoted_table_equals_the_pandas_mirror(quoting, tmp_path, monke
     if quoting == "minimal":
         assert "Skipping invalid feature: 'bogus\"'" in outs["device"][0] and "Skipping invalid feature: '\"q\"'" in outs["device"][0]
     assert b'"hCoV ""x""/50"\t' in outs["device"][1] and b'"two\nlines 0"\t' in outs["device"][1]
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_device_stages_on_random_quoted_tables_equal_the_host_stages(seed, tmp_path, monkeypatch):
+    """random tables whose id / feature fields are plain, quoted, quoted with doubled quotes or with a tail behind the closing
+    quote (rewritten in place by the reader), NA strings and empty features among them: the device stages read the features through
+    the reader's {offset, length} spans of the one image — same stdout and clusters.tsv as the host stages"""
+    rng = np.random.default_rng(700 + seed)
+    toks = synth.generate_profiles(400, seed=seed, p_del=0.05, p_ins=0.02)
+
+    def field(text, uniq=False):
+        kind = int(rng.integers(0, 5))
+        if kind == 0 or (uniq and kind == 4):
+            return text
+        if kind == 1:
+            return '"' + text + '"'
+        if kind == 2:   # a doubled quote inside: part of the content (for a feature: a token that matches no pattern)
+            return '"' + text + (' ""x""' if not uniq else '""') + '"'
+        if kind == 3:   # bytes behind the closing quote
+            return '"' + text + '"' + ("z" if uniq else " C5T")
+        return rng.choice(["NA", '"NA"', '""', "", "null"])
+    for trial in range(8):
+        n = int(rng.integers(50, 400))
+        lines = ["accession\tnote\tdna_profile"]
+        for r in range(n):
+            lines.append("\t".join([field(f"s{trial}_{r}", True), field("n"), field(toks[int(rng.integers(0, len(toks)))])]))
+        inp = tmp_path / f"in{trial}.tsv"
+        inp.write_text(("\r\n" if trial % 3 == 0 else "\n").join(lines) + "\n")
+        outs = []
+        for dev in ("1", "0"):
+            monkeypatch.setenv("BFK_DEVICE_PREP", dev)
+            buf = io.StringIO()
+            with redirect_stdout(buf):
+                ok = fastpath.run(inp, "\t", "accession", "dna_profile", "covsonar_dna", " ", True, True, 264, 228, 29903, 1, 2,
+                                  tmp_path / f"o{trial}_{dev}")
+            assert ok
+            outs.append((buf.getvalue(), (tmp_path / f"o{trial}_{dev}" / "clusters.tsv").read_bytes()))
+        assert outs[0] == outs[1], trial
