@@ -189,6 +189,54 @@ class ShardedClusterer:
             cur = self.labels
 
 
+def concurrent_streams(device_index: int, depth: int, candidates: int = 12):
+    """`depth` streams of which no two share a hardware queue, as far as that can be had.  The HIP runtime deals streams onto
+    a few hardware queues (four by default, GPU_MAX_HW_QUEUES) and kernels of two streams on one queue run behind each other:
+    a pipeline whose three streams sat on queues {2, 4, 4} never had three kernels in flight and took 0.166 ms per step, on
+    {4, 1, 2} it had them 57 % of the time and took 0.134 (rocprofv3 kernel trace, `Queue_Id`: profiles/r05_d_pipeline_overlap.txt).
+    The API does not say which queue a stream got, but it shows: a one-block spin kernel is put on a stream already chosen and a
+    tiny kernel on the candidate — if the tiny one finishes while the spin kernel still runs, the two are on different queues.
+    Candidates that fail are kept alive until the choice is made (so that the next stream created lands elsewhere)."""
+    dev = torch.device("cuda", device_index)
+    torch.cuda.set_device(dev)
+    probe = torch.zeros(64, device=dev)
+    torch.cuda.synchronize(dev)
+    try:
+        # the spin kernel's length in its own unit: aim at ~0.3 ms
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(200_000)
+        e1.record()
+        e1.synchronize()
+        spin = int(200_000 * 0.3 / max(e0.elapsed_time(e1), 1e-3))
+    except Exception:  # (no spin kernel in this torch build: the streams as they come)
+        return [torch.cuda.Stream(dev) for _ in range(depth)]
+
+    def beside(a, b):
+        ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(spin)
+            ev_a.record(a)
+        with torch.cuda.stream(b):
+            probe.add_(1.0)
+            ev_b.record(b)
+        ev_b.synchronize()
+        ran_beside = not ev_a.query()
+        ev_a.synchronize()
+        return ran_beside
+
+    chosen, rejected = [], []
+    for _ in range(max(candidates, depth)):
+        if len(chosen) == depth:
+            break
+        s = torch.cuda.Stream(dev)
+        (chosen if all(beside(c, s) for c in chosen) else rejected).append(s)
+    while len(chosen) < depth:  # (fewer queues than contexts: the rest share)
+        chosen.append(rejected.pop() if rejected else torch.cuda.Stream(dev))
+    torch.cuda.synchronize(dev)
+    return chosen
+
+
 class TextPipeline:
     """Text steps (profile strings resident in HBM -> labels in HBM, bfk_ctx_cluster_text_device) on `depth` resident contexts of
     ONE GPU that take the steps in turn, each context with its own stream and its own buffers (0.15 GB at 100k rows, 2.5 GB at
@@ -208,12 +256,10 @@ class TextPipeline:
     def __init__(self, device_index: int, depth: int = 3, candidate_path: str | None = None):
         if depth < 1:
             raise ValueError("depth must be at least 1")
-        # The streams the steps run on are created ONE AFTER THE OTHER, before anything else creates a stream: the HIP runtime deals
-        # streams round-robin onto its hardware queues (four by default, GPU_MAX_HW_QUEUES), and two of the pipeline's streams on one
-        # queue run behind each other — with a stream per context created in between (every context owns one) the 1st and the 3rd
-        # stream shared a queue: 0.157 ms per step instead of 0.128 at 100k rows.
+        # the streams the steps run on: on hardware queues of their own where that can be had (concurrent_streams: two of the
+        # pipeline's streams on one queue run behind each other — 0.157-0.166 ms per step instead of 0.128-0.134 at 100k rows)
         torch.cuda.set_device(torch.device("cuda", device_index))
-        streams = [torch.cuda.Stream(torch.device("cuda", device_index)) for _ in range(depth)]
+        streams = concurrent_streams(device_index, depth)
         self.engines = [GpuEngine(device_index, st) for st in streams]
         if candidate_path is not None:
             for e in self.engines:
