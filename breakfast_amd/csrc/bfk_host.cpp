@@ -51,6 +51,10 @@ struct bfk_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     bool profiling = false, edge_capture = false;
     int exact_edges = -1;  // -1: library default (BFK_EXACT_EDGES, else off), 0 / 1: bfk_ctx_set_exact_edges
+    // a run has been enqueued whose outcome — candidate queue overflow, a give-up of the join or of the prefix groups: repaired by
+    // bfk_ctx_sync, which redoes the run — has not been looked at yet.  Whatever would put that out of reach (a new bind, a run
+    // with another max_dist or into other labels) settles it first (ctx_settle)
+    bool unsettled = false;
     int tok_any_ids = -1;  // -1: library default (BFK_TOK_ANY_IDS, else off), 0 / 1: bfk_ctx_set_token_ids
     bool tok_any_now = false;
     static constexpr int EV_SLOTS = 64;  // ring of per-step event sets: up to 64 steps are averaged per sync
@@ -206,6 +210,16 @@ static int ctx_enter(bfk_ctx *c, bool finish_spec = true) {
     HIP_TRY(hipSetDevice(c->device));
     if (finish_spec && c->spec_count > 0) return ctx_spec_finish(c);
     return BFK_OK;
+}
+
+// An entry point that binds another CSR, or enqueues a run whose repair would not be the pending run's: the pending run is
+// completed first, repaired where it has to be (the soak of round 5 found it: a max-dist 2 text step whose candidate queue
+// overflowed, followed on the same context by another step before any bfk_ctx_sync, kept its incomplete labels).  An error
+// of the pending run surfaces here, once.
+static int ctx_settle(bfk_ctx *c) {
+    if (!c->unsettled) return BFK_OK;
+    c->unsettled = false;
+    return bfk_ctx_sync(c, nullptr);
 }
 
 template <typename T>
@@ -473,6 +487,7 @@ static int ctx_after_bind(bfk_ctx *c) {
 
 extern "C" int bfk_ctx_bind_csr_device(bfk_ctx *c, const void *d_indptr, const void *d_indices, int64_t n_rows) {
     if (int rc = ctx_enter(c)) return rc;
+    if (int rc = ctx_settle(c)) return rc;
     if (n_rows < 0 || n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
     if (n_rows > 0 && !d_indptr) return fail(BFK_EARG, "null indptr");
     c->d_indptr = (const int *)d_indptr;
@@ -483,6 +498,7 @@ extern "C" int bfk_ctx_bind_csr_device(bfk_ctx *c, const void *d_indptr, const v
 
 extern "C" int bfk_ctx_upload_csr(bfk_ctx *c, const int32_t *indptr, const int32_t *indices, int64_t n_rows) {
     if (int rc = ctx_enter(c)) return rc;
+    if (int rc = ctx_settle(c)) return rc;
     if (n_rows < 0 || n_rows > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EARG, "n_rows out of range");
     if (!indptr) return fail(BFK_EARG, "null indptr");
     const int64_t nnz = indptr[n_rows];
@@ -721,25 +737,6 @@ static bool spec_wanted(const bfk_ctx *c, int64_t n_rows, int64_t T, int32_t max
 
 static int ctx_spec_finish_one(bfk_ctx *c);
 
-// waits for the step that was enqueued last and, when its variant join gave up (a probe chain beyond JOIN_MAX_PROBE, a dup list
-// or a candidate queue that overflowed), redoes it on the all-pairs path.  -> *redone (may be NULL)
-static int ctx_join_repair(bfk_ctx *c, bool *redone = nullptr) {
-    if (redone) *redone = false;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!c->ran || c->n <= 0 || !c->plan.join) return BFK_OK;
-    struct { int join_fail; int overflow; } f{};
-    const Counters *dc = reinterpret_cast<const Counters *>(c->d_head);
-    HIP_TRY(hipMemcpy(&f.join_fail, &dc->join_fail, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&f.overflow, &dc->overflow, sizeof(int), hipMemcpyDeviceToHost));
-    if (!f.join_fail && !f.overflow) return BFK_OK;
-    if (f.join_fail) c->join_off = true;
-    c->need_zero = c->ctr_dirty = true;
-    c->join_clear = true;
-    if (int rc = ctx_enqueue(c, c->last_d, c->plan.shard, c->plan.n_shards, c->plan.labels, false)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (redone) *redone = true;
-    return BFK_OK;
-}
 
 // tokeniser launched -> the join's kernels behind it on device-resident counts; nothing waits
 static int ctx_spec_enqueue(bfk_ctx *c, const bfk_ctx::TokPlan &tp, int32_t max_dist, void *d_labels_out) {
@@ -813,9 +810,9 @@ static int ctx_spec_finish_one(bfk_ctx *c) {
     for (const bfk_ctx::SpecStep &r : redo) {
         if (int r2 = ctx_tokenize(c, r.tp, nullptr, nullptr)) return r2;
         if (int r2 = ctx_enqueue(c, r.d, 0, 1, r.labels, !(first && join_gave_up))) return r2;
-        // every redone step is completed before the next one goes out: its own give-up (bfk_ctx_sync would only see the last
-        // step's) is repaired here
-        if (int r2 = ctx_join_repair(c)) return r2;
+        // every redone step is completed before the next one goes out: its own give-up or queue overflow (bfk_ctx_sync would
+        // only see the last step's) is repaired here
+        if (int r2 = ctx_settle(c)) return r2;
         first = false;
     }
     return BFK_OK;
@@ -856,6 +853,7 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     const int64_t base = n_rows >= 0 ? row_off[0] : 0, T = n_rows >= 0 ? row_off[n_rows] - base : -1;
     if (int rc = ctx_check_text_args(n_rows, sep, sep_len, T)) return rc;
     if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
+    if (int rc = ctx_settle(c)) return rc;  // (the tokeniser is about to write this context's CSR)
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
     if (int rc = dev_realloc(&c->tk_rowoff, &c->tk_rowoff_cap, n_rows + 1, 1.05)) return rc;
@@ -946,6 +944,7 @@ extern "C" int bfk_ctx_build_csr_device(bfk_ctx *c, void *d_text, int64_t text_b
     if (int rc = ctx_check_text_args(n_rows, sep, sep_len, text_bytes)) return rc;
     if (!d_text || !d_row_off) return fail(BFK_EARG, "bfk_ctx_build_csr_device: null device pointer");
     if (n_rows == 0 && text_bytes != 0) return fail(BFK_EARG, "bfk_ctx_build_csr_device: text without rows");
+    if (int rc = ctx_settle(c)) return rc;
     if (int rc = ctx_text_events(c)) return rc;
     bfk_ctx::TokPlan tp;
     tp.d_text = (uint8_t *)d_text;
@@ -969,6 +968,7 @@ extern "C" int bfk_ctx_cluster_text_device(bfk_ctx *c, void *d_text, int64_t tex
     if (int rc = ctx_check_text_args(n_rows, sep, sep_len, text_bytes)) return rc;
     if (!d_text || !d_row_off) return fail(BFK_EARG, "bfk_ctx_cluster_text_device: null device pointer");
     if (n_rows == 0 && text_bytes != 0) return fail(BFK_EARG, "bfk_ctx_cluster_text_device: text without rows");
+    if (int rc = ctx_settle(c)) return rc;  // (a step that waited once and whose clustering kernels' outcome is still unread)
     if (int rc = ctx_text_events(c)) return rc;
     if (spec_wanted(c, n_rows, text_bytes, max_dist)) {
         bfk_ctx::TokPlan tp;
@@ -1201,11 +1201,15 @@ extern "C" int bfk_ctx_cluster(bfk_ctx *c, int32_t max_dist, int32_t shard, int3
     if (n_shards <= 0) n_shards = 1;
     if (shard < 0 || shard >= n_shards) return fail(BFK_EARG, "shard out of range");
     if (c->n > 0 && !d_labels_out) return fail(BFK_EARG, "null labels");
+    // (the same run again — a caller that times steps — needs no settling in between: the last one is repaired by the sync)
+    if (c->unsettled && (max_dist != c->last_d || d_labels_out != c->plan.labels || shard != c->plan.shard || n_shards != c->plan.n_shards))
+        if (int rc = ctx_settle(c)) return rc;
     return ctx_enqueue(c, max_dist, shard, n_shards, d_labels_out, true);
 }
 
 static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_shards, void *d_labels_out, bool allow_join) {
     c->ran = true;
+    if (!c->spec_enqueueing) c->unsettled = true;  // (a device-driven text step carries its outcome in its own slot: ctx_spec_finish_one)
     c->last_d = max_dist;
     c->last_shards = n_shards;
     c->last_w1 = sig_words_for(max_dist);
@@ -1650,6 +1654,7 @@ extern "C" int bfk_ctx_sync(bfk_ctx *c, bfk_stats *out) {
     }
     c->stats = s;
     if (out) *out = s;
+    c->unsettled = false;  // (the run — redone where it had to be — is complete)
     return BFK_OK;
 }
 
@@ -1986,6 +1991,7 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     int64_t n_bytes = 0, stride = 0, n = 0;
     if (int rc = bfk_table_raw(t, &bytes, &n_bytes, &spans, &stride, &n)) return rc;
     if (n <= 0) return fail(BFK_EUNSUPPORTED, "device prepare: no rows");
+    if (int rc = ctx_settle(c)) return rc;
     if (n > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EUNSUPPORTED, "device prepare: too many rows");
     const bool filtering = opts->skip_del || opts->skip_ins || opts->trim_start > 0 || opts->trim_end > 0;
     if (filtering && opts->var_type != BFK_VAR_RAW && bfk_table_any_high(t))

@@ -470,6 +470,46 @@ def test_a_join_give_up_in_an_open_text_step_that_is_not_the_last_is_repaired():
         ctx.close()
 
 
+@pytest.mark.parametrize("d", [2, 3])
+def test_a_step_that_waits_once_is_repaired_before_the_next_one_on_its_context_rebinds(d):
+    """max-dist >= 2 text steps wait once between their halves and leave the clustering kernels' outcome unread; a step whose
+    candidate queue overflows (a run of 330 identical rows among 3 000: ~54 000 pairs at distance 0 against a queue sized for
+    the forest) is redone by bfk_ctx_sync — but the NEXT step on the context re-binds the CSR that redo needs.  Every entry that
+    binds, and every run into other labels or at another max-dist, settles the pending run first (ctx_settle; found by
+    tools/soak_text.py): three steps without a sync in between, the overflowing one first, in the middle, last."""
+    import torch
+
+    base = list(dict.fromkeys(generate_profiles(9000)))
+    dense = base[:1500] + [base[1500]] * 330 + base[1501:3000]
+    batches = {"dense": dense, "a": base[3000:6000], "b": base[6000:9000]}
+    want = {}
+    for k, rows in batches.items():
+        ip, ix, _ = orc.sparse_feature_matrix(rows, " ")
+        want[k] = orc.cluster_csr(ip, ix, d, n_threads=ORACLE_THREADS)["labels"]
+    dev = {k: _device_text(rows) for k, rows in batches.items()}
+    for order in (("dense", "a", "b"), ("a", "dense", "b"), ("a", "b", "dense")):
+        ctx = _lib.Context(0)
+        labs = {}
+        for k in order:
+            buf, off, d_text, d_off = dev[k]
+            labs[k] = torch.full((len(batches[k]),), -3, dtype=torch.int32, device="cuda")
+            ctx.cluster_text_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(batches[k]), " ", d, labs[k].data_ptr())
+        ctx.sync()
+        for k in order:
+            assert np.array_equal(labs[k].cpu().numpy(), want[k]), (order, k)
+        # the bound-CSR entries: a run into other labels, or at another max-dist, behind an unread one
+        buf, off, d_text, d_off = dev["dense"]
+        ctx.build_csr_device(d_text.data_ptr(), len(buf), d_off.data_ptr(), len(dense), " ")
+        l1 = torch.full((len(dense),), -3, dtype=torch.int32, device="cuda")
+        l2 = torch.full((len(dense),), -3, dtype=torch.int32, device="cuda")
+        ctx.cluster(d, l1.data_ptr())
+        ctx.cluster(d, l2.data_ptr())
+        ctx.cluster(d + 1, l2.data_ptr())
+        ctx.sync()
+        assert np.array_equal(l1.cpu().numpy(), want["dense"])
+        ctx.close()
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_text_pipeline_overlaps_the_steps_of_different_batches_and_keeps_every_batch_s_labels(depth):
     """distributed.TextPipeline: `depth` contexts of one GPU (a stream and buffers each) take the text steps in turn, so steps of
