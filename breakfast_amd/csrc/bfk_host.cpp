@@ -2269,7 +2269,10 @@ static int write_sidecar(const char *path, int32_t max_dist, const uint64_t *has
 
 // the hashes of an EXACT side-car cache of this max_dist -> BFK_OK (*usable = 0: another max_dist, the cache plays no part);
 // BFK_EUNSUPPORTED: format 1, or a file that is not what its header says (the list path reads it and says what is wrong)
-static int read_sidecar_hashes(const char *path, int32_t max_dist, std::vector<uint64_t> *hashes, int *usable) {
+// off / flat (may be NULL): the cached lists too — wanted when the run continues the cache into a new one — checked as sidecar.load
+// checks them (offsets a non-decreasing run from 0 to the total, members rows of the cached input)
+static int read_sidecar_hashes(const char *path, int32_t max_dist, std::vector<uint64_t> *hashes, int *usable, std::vector<int64_t> *off = nullptr,
+                               std::vector<int32_t> *flat = nullptr) {
     *usable = 0;
     FILE *f = fopen(path, "rb");
     if (!f) return fail(BFK_EUNSUPPORTED, std::string("cannot read ") + path);
@@ -2277,14 +2280,22 @@ static int read_sidecar_hashes(const char *path, int32_t max_dist, std::vector<u
     int32_t d = 0;
     int64_t head[3] = {0, 0, 0};
     bool ok = fread(magic, 1, 10, f) == 10 && memcmp(magic, "BFKCACHE\x02\n", 10) == 0 && fread(&d, 4, 1, f) == 1 && fread(head, 8, 3, f) == 3 &&
-              head[0] >= 0 && head[1] >= 0 && head[2] >= 0 && head[0] <= INT32_MAX;
+              head[0] >= 0 && head[1] >= 0 && head[2] >= 0 && head[0] <= INT32_MAX && head[1] <= INT32_MAX;
     if (ok && d == max_dist) {
         hashes->resize((size_t)head[0] * 2);
         ok = head[0] == 0 || fread(hashes->data(), 16, (size_t)head[0], f) == (size_t)head[0];
+        if (ok && off && flat) {
+            off->resize((size_t)head[1] + 1);
+            flat->resize((size_t)head[2]);
+            ok = fread(off->data(), 8, off->size(), f) == off->size() && (head[2] == 0 || fread(flat->data(), 4, flat->size(), f) == flat->size());
+            ok = ok && (*off)[0] == 0 && off->back() == head[2];
+            for (size_t i = 1; ok && i < off->size(); i++) ok = (*off)[i] >= (*off)[i - 1];
+            for (size_t i = 0; ok && i < flat->size(); i++) ok = (*flat)[i] >= 0 && (*flat)[i] < head[0];
+        }
         *usable = 1;
     }
     fclose(f);
-    if (!ok) return fail(BFK_EUNSUPPORTED, "side-car cache: not an exact cache (format 2) of the size its header says");
+    if (!ok) return fail(BFK_EUNSUPPORTED, "side-car cache: not an exact cache (format 2), or not what its header says (the list path reads it and says what is wrong)");
     return BFK_OK;
 }
 
@@ -2294,9 +2305,12 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
     if ((cache_path || in_cache) && n_gpus != 1) return fail(BFK_EARG, "bfk_table_cluster_write_device: side-car caches go with one device");
     std::vector<uint64_t> cached;
+    std::vector<int64_t> c_off, where;  // the cached lists (when the run continues the cache); the cached rows' places in this input
+    std::vector<int32_t> c_flat;
     int check_cached = 0;
     if (in_cache)
-        if (int rc = read_sidecar_hashes(in_cache, max_dist, &cached, &check_cached)) return rc;
+        if (int rc = read_sidecar_hashes(in_cache, max_dist, &cached, &check_cached, cache_path ? &c_off : nullptr, cache_path ? &c_flat : nullptr))
+            return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     bfk_ctx *c;
     DevTimer tm;
@@ -2340,7 +2354,7 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
             if (e || e2 != hipSuccess) return fail(BFK_EHIP, std::string("k_row_hashes: ") + hipGetErrorString(e ? (hipError_t)e : e2));
             tm.lap("pipeline: feature hashes");
             if (check_cached && !cached.empty()) {
-                std::vector<int64_t> where(cached.size() / 2);
+                where.resize(cached.size() / 2);
                 if (int rc = bfk_match_hashes(cached.data(), (int64_t)where.size(), hashes.data(), r.n_unique, where.data())) return rc;
                 for (int64_t w : where)
                     if (w < 0) return fail(BFK_EUNSUPPORTED, "side-car cache: a cached row is gone from the input (its list still chains its neighbours: the list path)");
@@ -2371,9 +2385,35 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
             tm.lap("pipeline: cluster with every edge recorded");
             int64_t *lp = nullptr;
             int32_t *li = nullptr;
-            rc = lists_from_edges(r.n_unique, nullptr, r.n_unique, edges, ne, &lp, &li);
-            free(edges);
-            if (!rc) rc = write_sidecar(cache_path, max_dist, hashes.data(), r.n_unique, lp, r.n_unique, li);
+            if (!check_cached) {  // no cache to continue: every row's list (cluster_features without a cache, breakfast.py:314-319)
+                rc = lists_from_edges(r.n_unique, nullptr, r.n_unique, edges, ne, &lp, &li);
+                free(edges);
+                if (!rc) rc = write_sidecar(cache_path, max_dist, hashes.data(), r.n_unique, lp, r.n_unique, li);
+            } else {
+                // the cache continued, as the reference continues its own (:294-304, cache.py:51-71, sidecar.cluster_with_sidecar):
+                // the cached lists re-indexed onto this input (no cached row is gone: nothing drops out) and, behind them, the
+                // lists of the rows the cache did not know, in row order — what the NEXT run finds has to be what the list
+                // path would have left, or a later run that loses rows chains other neighbours than the reference would
+                std::vector<char> known((size_t)r.n_unique, 0);
+                for (int64_t w : where) known[(size_t)w] = 1;
+                std::vector<int64_t> fresh;
+                for (int64_t u = 0; u < r.n_unique; u++)
+                    if (!known[(size_t)u]) fresh.push_back(u);
+                static const int64_t none = 0;
+                rc = lists_from_edges(r.n_unique, fresh.empty() ? &none : fresh.data(), (int64_t)fresh.size(), edges, ne, &lp, &li);
+                free(edges);
+                if (!rc) {
+                    const size_t n_old = c_off.empty() ? 0 : c_off.size() - 1, n_new = fresh.size();
+                    std::vector<int64_t> o_off(n_old + n_new + 1, 0);
+                    std::vector<int32_t> o_flat(c_flat.size() + (size_t)lp[n_new]);
+                    for (size_t i = 0; i < n_old; i++) o_off[i + 1] = c_off[i + 1];
+                    for (size_t i = 0; i < c_flat.size(); i++) o_flat[i] = (int32_t)where[(size_t)c_flat[i]];
+                    const int64_t base_ = n_old ? c_off[n_old] : 0;
+                    for (size_t i = 0; i < n_new; i++) o_off[n_old + i + 1] = base_ + lp[i + 1];
+                    if (lp[n_new]) memcpy(o_flat.data() + c_flat.size(), li, sizeof(int32_t) * (size_t)lp[n_new]);
+                    rc = write_sidecar(cache_path, max_dist, hashes.data(), r.n_unique, o_off.data(), (int64_t)(n_old + n_new), o_flat.data());
+                }
+            }
             free(lp);
             free(li);
             if (rc) return rc;

@@ -95,7 +95,7 @@ while time.time() < t_end:
         grown = inp
         lost = tmp / f"c{n_runs}_l.tsv"
         lost.write_text(head + "".join(body[len(body) // 10:]))
-        caches = {}
+        caches, files = {}, {}
         for flow, env in (("dev", {}), ("list", {"BFK_CACHE_REUSE": "1"})):
             c1, c2, c3 = (tmp / f"c{n_runs}_{flow}_{k}.bfkc" for k in (1, 2, 3))
             r1 = run(first, tmp / f"c{n_runs}_{flow}_o1", env, **kw, output_cache=c1)
@@ -104,8 +104,11 @@ while time.time() < t_end:
             kw2 = dict(kw, d=kw["d"] % 3 + 1)
             r4 = run(grown, tmp / f"c{n_runs}_{flow}_o4", env, **kw2, input_cache=c3)
             caches[flow] = (r1, r2, r3, r4)
-        for x, y in zip(caches["dev"], caches["list"]):
-            assert x == y, ("side-car chain: device stages differ from the list path", n_runs, kw, x[:3], y[:3])
+            files[flow] = [c.read_bytes() if c.exists() else None for c in (c1, c2, c3)]
+        for k, (x, y) in enumerate(zip(caches["dev"], caches["list"])):
+            assert x == y, ("side-car chain: device stages differ from the list path at run", k + 1, n_runs, kw, x[:3], y[:3])
+        for k, (x, y) in enumerate(zip(files["dev"], files["list"])):
+            assert x == y, ("side-car chain: the caches written differ at run", k + 1, n_runs, kw)
         assert caches["dev"][1][3] == a[3], "a grown input through an exact cache is the run without a cache"
     if n_runs % 10 == 0:
         print(f"[soak_cli] {n_runs} tables, {n_chains} cache chains", flush=True)
