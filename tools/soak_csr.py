@@ -71,6 +71,10 @@ def brute_lists(ip, ix, d):
     return [np.flatnonzero(row <= d) for row in dist]
 
 
+import os  # noqa: E402
+
+os.environ.setdefault("BFK_MULTI_ONE_DEVICE", "1")
+os.environ.setdefault("BFK_MULTI_FORCE", "1")
 t_end = time.time() + budget
 n_runs = n_binds = 0
 ctx = _lib.Context(0)
@@ -118,6 +122,11 @@ while time.time() < t_end:
         d = int(rng.choice([1, 2, 3]))
         lab, st = _lib.cluster_csr(ip, ix, d)
         assert np.array_equal(lab, want(key, ip, ix, d)["labels"]), ("cluster_csr", kind, n, d, seed)
+    if rng.random() < 0.25:   # the one-process multi-device driver, every context on this device (BFK_MULTI_ONE_DEVICE / _FORCE, set below)
+        d = int(rng.choice([1, 2, 3, 5]))
+        g = int(rng.choice([2, 3, 4]))
+        lab, st = _lib.cluster_csr(ip, ix, d, n_gpus=g)
+        assert np.array_equal(lab, want(key, ip, ix, d)["labels"]), ("cluster_csr n_gpus", kind, n, d, g, seed)
     if rng.random() < 0.5 and n <= 2500:
         d = int(rng.choice([1, 2, 3]))
         sel = None if rng.random() < 0.4 else rng.integers(0, n, size=int(rng.integers(1, max(2, n // 3)))).astype(np.int64)  # (unsorted, repeats)
