@@ -65,7 +65,8 @@ def brute_lists(ip, ix, d):
     from scipy.sparse import csr_matrix
     from sklearn.metrics.pairwise import manhattan_distances
 
-    x = csr_matrix((np.ones(len(ix), dtype=np.int64), ix, ip), shape=(len(ip) - 1, int(ix.max()) + 1))
+    # (copies: sum_duplicates works in place on the arrays the matrix was built from)
+    x = csr_matrix((np.ones(len(ix), dtype=np.int64), ix.copy(), ip.copy()), shape=(len(ip) - 1, int(ix.max()) + 1))
     x.sum_duplicates()
     dist = manhattan_distances(x)
     return [np.flatnonzero(row <= d) for row in dist]
@@ -137,7 +138,7 @@ while time.time() < t_end:
             assert idx[ptr[pos]: ptr[pos + 1]].tolist() == w[r].tolist(), ("neighbour list", kind, n, d, r, seed)
         if sel is None:
             lab = _lib.labels_from_csr(n, ptr, idx)
-            assert np.array_equal(lab, want(key, ip, ix, d)["labels"]), ("labels_from_lists", kind, n, d, seed)
+            assert np.array_equal(lab, want(key, ip, ix, d)["labels"]), ("labels_from_lists", kind, n, d, seed, rows if n < 30 else None)
     if n_binds % 10 == 0:
         print(f"[soak_csr] {n_binds} CSRs, {n_runs} runs checked", flush=True)
 ctx.close()
