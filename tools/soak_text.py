@@ -104,6 +104,47 @@ while time.time() < t_end:
         assert np.array_equal(lab_.cpu().numpy(), want_), ("labels differ", k_, d_, n_, depth, any_ids, seed, n_rounds)
         n_batches += 1
     pipe.close()
+    # one context, entry points mixed: text steps, a CSR built and clustered by hand, downloads in between, slots-as-ids and the
+    # candidate generator switched while steps are open
+    ctx = _lib.Context(0)
+    pending = []
+    for _ in range(int(rng.integers(3, 12))):
+        kind, rows = batch()
+        d = int(rng.choice([1, 1, 1, 2, 3]))
+        want = want_labels(rows, d)
+        if want is None:
+            continue
+        T, d_text, d_off = on_device(rows)
+        lab = torch.full((len(rows),), -7, dtype=torch.int32, device="cuda")
+        op = int(rng.integers(0, 4))
+        if rng.random() < 0.3:
+            ctx.set_token_ids(bool(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            ctx.set_candidate_path(str(rng.choice(["auto", "allpairs", "join" if d == 1 else "auto"])))
+        if op <= 1:
+            ctx.cluster_text_device(d_text.data_ptr(), T, d_off.data_ptr(), len(rows), " ", d, lab.data_ptr())
+        elif op == 2:
+            ctx.build_csr_device(d_text.data_ptr(), T, d_off.data_ptr(), len(rows), " ")
+            ctx.cluster(d, lab.data_ptr())
+        else:
+            ctx.build_csr_device(d_text.data_ptr(), T, d_off.data_ptr(), len(rows), " ")
+            ip, ix = ctx.download_csr()
+            w = orc.sparse_feature_matrix(rows, " ")
+            assert np.array_equal(ip, w[0]) and np.array_equal(ix, w[1]), ("CSR differs", kind, len(rows), seed, n_rounds)
+            ctx.cluster(d, lab.data_ptr())
+        pending.append((kind, d, len(rows), lab, want, d_text, d_off))
+        kinds[kind] = kinds.get(kind, 0) + 1
+        if rng.random() < 0.35:
+            ctx.sync()
+            for k_, d_, n_, lab_, want_, *_ in pending:
+                assert np.array_equal(lab_.cpu().numpy(), want_), ("labels differ (one context)", k_, d_, n_, seed, n_rounds)
+                n_batches += 1
+            pending = []
+    ctx.sync()
+    for k_, d_, n_, lab_, want_, *_ in pending:
+        assert np.array_equal(lab_.cpu().numpy(), want_), ("labels differ (one context)", k_, d_, n_, seed, n_rounds)
+        n_batches += 1
+    ctx.close()
     if n_rounds % 5 == 0:
         print(f"[soak] {n_rounds} pipelines, {n_batches} batches checked, {kinds}", flush=True)
 print(f"[soak] done: {n_rounds} pipelines, {n_batches} batches, all labels equal the oracle's; {kinds}")
