@@ -257,6 +257,13 @@ struct RowHashArgs {
 };
 int launch_row_hashes(const RowHashArgs &a, hipStream_t st);
 int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, uint32_t T, uint8_t sep, hipStream_t st);
+constexpr int SEP_MAX_BYTES = 16;  // longest token separator the device prepare folds (k_sepfold)
+struct SepPattern {
+    uint8_t b[SEP_MAX_BYTES];
+    int m;
+};
+int launch_sepfold(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, const SepPattern &pat,
+                   uint8_t standin, int *seps, unsigned long long *total, hipStream_t st);
 int launch_collapse(const PrepArgs &a, hipStream_t st);
 
 int sort_records(void *temp, size_t *temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const int *rows_in,

@@ -998,6 +998,7 @@ extern "C" int bfk_table_from_buffers(const char *id_buf, const int64_t *id_off,
 extern "C" int64_t bfk_table_rows(const bfk_table *t) { return t ? (int64_t)t->ids.size() : -1; }
 extern "C" void bfk_table_close(bfk_table *t) { delete t; }
 
+extern "C" int bfk_table_feature_high(const bfk_table *t);
 extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, bfk_prep_info *info) {
     if (!t || !sep2 || !opts || !info) return bfk_fail(BFK_EARG, "bfk_table_prepare: null argument");
     if (sep2_len <= 0) return bfk_fail(BFK_EARG, "empty separator");
@@ -1015,13 +1016,7 @@ extern "C" int bfk_table_prepare(bfk_table *t, const char *sep2, int64_t sep2_le
         // the reference's patterns (:135-155) are str patterns: \d also matches the decimal digits of other scripts, which the
         // ASCII matchers here do not restate — a FEATURE with non-ASCII bytes under a grammar is the general path's (ids and
         // other columns may hold what they like)
-        std::atomic<int> high{0};
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 16384 + 1));
-        parallel_chunks(parts, [&](int q) {
-            for (int64_t r = n * q / parts, e = n * (q + 1) / parts; r < e && !high.load(std::memory_order_relaxed); r++)
-                if (has_high_byte(b + t->feats[(size_t)r].off, t->feats[(size_t)r].len)) high.store(1);
-        });
-        if (high.load()) return unsupported("non-ASCII bytes in a feature that is matched against the token patterns");
+        if (bfk_table_feature_high(t)) return unsupported("non-ASCII bytes in a feature that is matched against the token patterns");
     }
     t->filtered = filtering;
     t->device_prepared = false;
@@ -1139,6 +1134,21 @@ extern "C" int bfk_table_raw(const bfk_table *t, const char **bytes_out, int64_t
 }
 
 extern "C" int bfk_table_any_high(const bfk_table *t) { return t && t->any_high ? 1 : 0; }
+
+// does any FEATURE hold a byte >= 0x80 (ids and other columns may): what decides whether the token patterns' ASCII matchers — the
+// host stage's and the device stage's — may take a table whose bytes are not all ASCII
+extern "C" int bfk_table_feature_high(const bfk_table *t) {
+    if (!t || !t->any_high) return 0;
+    const int64_t n = (int64_t)t->feats.size();
+    const char *b = t->bytes.data();
+    std::atomic<int> high{0};
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 16384 + 1));
+    parallel_chunks(parts, [&](int q) {
+        for (int64_t r = n * q / parts, e = n * (q + 1) / parts; r < e && !high.load(std::memory_order_relaxed); r++)
+            if (has_high_byte(b + t->feats[(size_t)r].off, t->feats[(size_t)r].len)) high.store(1);
+    });
+    return high.load();
+}
 
 extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
                                       const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len) {

@@ -1944,6 +1944,7 @@ extern "C" int bfk_cluster_text(const char *buf, const int64_t *row_off, int64_t
 extern "C" int bfk_table_raw(const bfk_table *t, const char **bytes_out, int64_t *n_bytes_out, const void **feat_spans_out,
                              int64_t *span_stride_out, int64_t *n_rows_out);  // libbfk_front.so
 extern "C" int bfk_table_any_high(const bfk_table *t);
+extern "C" int bfk_table_feature_high(const bfk_table *t);
 extern "C" int bfk_table_set_prepared(bfk_table *t, const int32_t *group, const int32_t *first_row, int64_t n_unique, const bfk_prep_info *info,
                                       const int32_t *indptr, const int32_t *indices, const char *sep2, int64_t sep2_len);
 extern "C" int bfk_table_set_invalid(bfk_table *t, const int64_t *off, const int32_t *len, int64_t n);
@@ -1977,15 +1978,18 @@ struct PrepResult {
 };
 
 // -> BFK_EUNSUPPORTED (nothing printed, nothing written: the host stages take the input) for what the device stages do not
-// restate: multi-byte token separators, 4 GiB of text, more than PREP_INV_CAP non-empty tokens that match no pattern, a feature
+// restate: token separators of over 16 bytes, 4 GiB of text, more than PREP_INV_CAP non-empty tokens that match no pattern, a feature
 // with non-ASCII bytes under a grammar, two different rows with one 64-bit hash
 static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, int64_t sep2_len, const bfk_filter_opts *opts, PrepResult *res) {
     if (!t || !sep2 || !opts || !res) return fail(BFK_EARG, "device prepare: null argument");
     if (sep2_len <= 0) return fail(BFK_EARG, "empty separator");
     if (opts->var_type < BFK_VAR_COVSONAR_DNA || opts->var_type > BFK_VAR_RAW) return fail(BFK_EARG, "device prepare: unknown var_type");
-    if (sep2_len != 1) return fail(BFK_EUNSUPPORTED, "device prepare: one-byte token separators only");
-    const unsigned char sp = (unsigned char)sep2[0];
-    if (sp >= 0x80 || sp == '\n' || sp == '\r' || sp == 0) return fail(BFK_EUNSUPPORTED, "device prepare: token separator");
+    if (sep2_len > SEP_MAX_BYTES) return fail(BFK_EUNSUPPORTED, "device prepare: token separator of more than 16 bytes");
+    for (int64_t i = 0; i < sep2_len; i++) {
+        const unsigned char b = (unsigned char)sep2[i];
+        if (b >= 0x80 || b == '\n' || b == '\r' || b == 0) return fail(BFK_EUNSUPPORTED, "device prepare: token separator");
+    }
+    unsigned char sp = (unsigned char)sep2[0];  // (a separator of several bytes: the stand-in byte chosen below)
     const char *bytes = nullptr;
     const void *spans = nullptr;
     int64_t n_bytes = 0, stride = 0, n = 0;
@@ -1994,15 +1998,34 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     if (int rc = ctx_settle(c)) return rc;
     if (n > (int64_t)INT32_MAX - 2 * SIG_PAD_ROWS) return fail(BFK_EUNSUPPORTED, "device prepare: too many rows");
     const bool filtering = opts->skip_del || opts->skip_ins || opts->trim_start > 0 || opts->trim_end > 0;
-    if (filtering && opts->var_type != BFK_VAR_RAW && bfk_table_any_high(t))
-        return fail(BFK_EUNSUPPORTED, "device prepare: non-ASCII bytes (the host stage decides whether a feature holds them)");
+    // (the reference's str patterns let \d match the digits of other scripts: a FEATURE with non-ASCII bytes under a grammar is
+    // the pandas mirror's — the host stage declines it too; accents in ids or other columns do not matter)
+    if (filtering && opts->var_type != BFK_VAR_RAW && bfk_table_feature_high(t))
+        return fail(BFK_EUNSUPPORTED, "device prepare: non-ASCII bytes in a feature that is matched against the token patterns");
     struct SpanView {
         int64_t off;
         int32_t len;
     };
     auto span = [&](int64_t r) { return *(const SpanView *)((const char *)spans + (size_t)r * (size_t)stride); };
     const int64_t base = span(0).off, T = n_bytes - base;
-    if (int rc = ctx_check_text_args(n, sep2, sep2_len, T)) return rc;
+    // A token separator of several bytes (breakfast.py:164: str.split takes any string) is folded on the device into runs of ONE
+    // byte that the table does not hold (k_sepfold), and the stages below run with that byte.  Control characters first: a TSV of
+    // profiles holds none of them.
+    if (sep2_len > 1) {
+        static const unsigned char cand[] = {0x1F, 0x1E, 0x1D, 0x1C, 0x1B, 0x1A, 0x19, 0x18, 0x17, 0x16, 0x15, 0x14, 0x13, 0x12, 0x11, 0x10,
+                                             0x0F, 0x0E, 0x0C, 0x0B, 0x08, 0x07, 0x06, 0x05, 0x04, 0x03, 0x02, 0x01, 0x7F};
+        sp = 0;
+        for (unsigned char b : cand)
+            if (!memchr(bytes + base, b, (size_t)T)) {
+                sp = b;
+                break;
+            }
+        if (!sp) return fail(BFK_EUNSUPPORTED, "device prepare: no free byte to stand for the token separator");
+    }
+    {
+        const char one = (char)sp;
+        if (int rc = ctx_check_text_args(n, &one, 1, T)) return rc;
+    }
     std::vector<int64_t> row_off((size_t)n + 1);
     std::vector<int32_t> row_len((size_t)n);
     {
@@ -2054,6 +2077,18 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
         ~StreamGuard() { (void)hipStreamSynchronize(s); }
     } guard{c->stream};
     tm.lap("prepare: H2D", c->stream);
+    const int64_t sep_extra = sep2_len - 1;  // empty tokens every folded separator adds to the device's counts
+    if (sep2_len > 1) {
+        SepPattern pat{};
+        pat.m = (int)sep2_len;
+        memcpy(pat.b, sep2, (size_t)sep2_len);
+        HIP_TRY(hipMemsetAsync(c->pr_small, 0, 64, c->stream));
+        // (occurrences per row into pr_rep, which the collapse only fills further down; their sum into the words behind the
+        // collapse's totals)
+        if (int e = launch_sepfold(c->tk_text, c->tk_rowoff, c->pr_spanlen, (int)n, base, pat, (uint8_t)sp, c->pr_rep,
+                                   (unsigned long long *)(c->pr_small + 8), c->stream))
+            return fail(BFK_EHIP, std::string("k_sepfold launch: ") + hipGetErrorString((hipError_t)e));
+    }
     if (int e = launch_blank(c->tk_text, c->tk_rowoff, c->pr_spanlen, (int)n, base, (uint32_t)T, (uint8_t)sp, c->stream))
         return fail(BFK_EHIP, std::string("k_blank launch: ") + hipGetErrorString((hipError_t)e));
     bfk_ctx::TokPlan tp;
@@ -2080,6 +2115,18 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     if (int rc = ctx_text_events(c)) return rc;
     if (int rc = ctx_tokenize(c, tp, nullptr, nullptr)) return rc;  // (the CSR of ALL rows is bound now)
     tm.lap("prepare: tokenise + filter");
+    std::vector<int32_t> row_seps;  // folded separators per row (several-byte separator, empty tokens counted)
+    if (sep2_len > 1 && filtering) {
+        unsigned long long total_seps = 0;
+        HIP_TRY(hipMemcpy(&total_seps, c->pr_small + 8, 8, hipMemcpyDeviceToHost));
+        const unsigned long long extra = total_seps * (unsigned long long)sep_extra;
+        if (extra > (unsigned long long)c->tk_stats.n_empty) return fail(BFK_EHIP, "device prepare: folded separators and empty tokens do not add up");
+        c->tk_stats.n_empty -= (int64_t)extra;
+        if (total_seps) {
+            row_seps.resize((size_t)n);
+            HIP_TRY(hipMemcpy(row_seps.data(), c->pr_rep, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+    }
     // empty tokens are "invalid" for every grammar whose patterns do not match the empty string (:182-184)
     const int64_t n_empty_inv = (filtering && opts->var_type != BFK_VAR_RAW && opts->var_type != BFK_VAR_NEXTCLADE_AA) ? c->tk_stats.n_empty : 0;
     const int64_t n_other_inv = c->tk_stats.n_invalid;
@@ -2100,6 +2147,7 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
         if (n_empty_inv > 0) {
             emp.resize((size_t)n);
             HIP_TRY(hipMemcpy(emp.data(), c->pr_empties, (size_t)n * 4, hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < row_seps.size(); r++) emp[r] -= (uint32_t)(sep_extra * row_seps[r]);
         }
         res->inv_off.reserve((size_t)n_invalid);
         res->inv_len.reserve((size_t)n_invalid);
@@ -2116,8 +2164,21 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
                 // separator that follows the row's start or another separator
                 int64_t in_row = 0;
                 const char *rb = bytes + row_off[(size_t)r];
-                for (int64_t k = 0, lim = off - row_off[(size_t)r]; k < lim; k++)
-                    if ((unsigned char)rb[k] == sp && (k == 0 || (unsigned char)rb[k - 1] == sp)) in_row++;
+                const int64_t lim = off - row_off[(size_t)r];
+                if (sep2_len == 1) {
+                    for (int64_t k = 0; k < lim; k++)
+                        if ((unsigned char)rb[k] == sp && (k == 0 || (unsigned char)rb[k - 1] == sp)) in_row++;
+                } else {  // str.split's matches, from the left: a piece that starts where it ends is empty
+                    for (int64_t k = 0, piece = 0; k + sep2_len <= lim;) {
+                        if (memcmp(rb + k, sep2, (size_t)sep2_len) == 0) {
+                            if (k == piece) in_row++;
+                            k += sep2_len;
+                            piece = k;
+                        } else {
+                            k++;
+                        }
+                    }
+                }
                 want = before_rows + in_row;
             }
             for (; emitted < want; emitted++) {
@@ -2304,6 +2365,8 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
                                       bfk_prep_info *info_out, int64_t *n_clusters_out) {
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
     if ((cache_path || in_cache) && n_gpus != 1) return fail(BFK_EARG, "bfk_table_cluster_write_device: side-car caches go with one device");
+    if ((cache_path || in_cache) && sep2_len != 1)  // (k_row_hashes re-joins the kept tokens with ONE byte: the list path takes these)
+        return fail(BFK_EUNSUPPORTED, "device stages: side-car caches with a token separator of several bytes");
     std::vector<uint64_t> cached;
     std::vector<int64_t> c_off, where;  // the cached lists (when the run continues the cache); the cached rows' places in this input
     std::vector<int32_t> c_flat;

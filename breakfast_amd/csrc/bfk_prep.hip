@@ -65,6 +65,38 @@ __global__ __launch_bounds__(256) void k_blank(uint8_t *text, const long long *_
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sepfold: a token separator of m > 1 bytes (breakfast.py:164 splits on any string).  Thread r walks row r's span from the left —
+// str.split's matches: leftmost, never overlapping — and overwrites every occurrence with m STAND-IN bytes, a byte the table
+// does not hold: the tokeniser then runs with that one byte as its separator.  Offsets stay what they are (the host prints a
+// token from its own image of the table by offset and length), rows that differ still differ (no row holds the stand-in, so the
+// runs of it say where the separators were), and an occurrence leaves m - 1 empty tokens that are not the reference's: seps[r]
+// = occurrences in row r, *total = their sum — the host takes (m - 1) x these off the empty-token counts.
+__global__ __launch_bounds__(256) void k_sepfold(uint8_t *text, const long long *__restrict__ row_off, const int *__restrict__ span_len, int n,
+                                                 long long base, SepPattern pat, uint8_t standin, int *__restrict__ seps,
+                                                 unsigned long long *total) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    unsigned cnt = 0;
+    if (r < n) {
+        uint8_t *t = text + (size_t)(row_off[r] - base);
+        const int len = span_len[r], m = pat.m;
+        for (int k = 0; k + m <= len;) {
+            bool eq = t[k] == pat.b[0];
+            for (int j = 1; eq && j < m; j++) eq = t[k + j] == pat.b[j];
+            if (eq) {
+                for (int j = 0; j < m; j++) t[k + j] = standin;
+                cnt++;
+                k += m;
+            } else {
+                k++;
+            }
+        }
+        seps[r] = (int)cnt;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long)cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_row_hash: 16 lanes per row.  The 64-bit hash of the row's identity — order-dependent: position i enters every term — and the
 // row's place in the table {hash -> smallest row with it}.  A plain load first: a hub (thousands of rows with one string) would
 // otherwise send every one of its rows through a compare-and-swap and an atomicMin on ONE slot (same-address atomics serialise
@@ -268,6 +300,14 @@ __global__ __launch_bounds__(256) void k_row_out(PrepArgs a) {
 int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, uint32_t T, uint8_t sep, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_blank, dim3((n + 255) / 256), dim3(256), 0, st, text, row_off, span_len, n, base, T, sep);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sepfold(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, const SepPattern &pat,
+                   uint8_t standin, int *seps, unsigned long long *total, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_sepfold, dim3((n + 255) / 256), dim3(256), 0, st, text, row_off, span_len, n, base, pat, standin, seps, total);
     LAUNCH_CHECK();
     return 0;
 }

@@ -55,7 +55,7 @@ def run(input_file, sep, id_col, clust_col, var_type, sep2, skip_ins, skip_del, 
     if max_dist != 0 and os.environ.get("BFK_DEVICE_PREP", "1") != "0":
         # filter + collapse + CSR on the device, the unique rows clustered where they lie, the writer: ONE native call
         # (bfk_table_cluster_write_device).  It declines — nothing printed, nothing written — what only the host stage restates
-        # (multi-byte token separators, tokens that match no pattern and have to be listed, ...): the stages below take over.
+        # (more than 65 536 tokens that match no pattern, a feature with non-ASCII bytes under a grammar, ...): the stages below take over.
         made = not outdir.exists()
         outdir.mkdir(parents=True, exist_ok=True)
 

@@ -360,8 +360,11 @@ int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cl
  * rows in first-appearance order (:72-79).  Tokens that match no pattern (the reference prints each: rows in input order, tokens
  * in row order, :182-184) are noted on the device as {offset, length}, put into that order on the host and handed out by
  * bfk_table_invalid (when every one of them is an EMPTY token the table lists nothing: info_out->n_invalid lines of '').
- * BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token separators of several bytes, 4 GiB of text,
- * more than 65 536 non-empty tokens that match no pattern, non-ASCII bytes under a grammar.
+ * A token separator of several bytes (:164, str.split takes any string; up to 16) is folded on the device into a byte the table
+ * does not hold (k_sepfold: leftmost, non-overlapping matches per row), the stages run with that byte.
+ * BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token separators of over 16 bytes or with a line break,
+ * 4 GiB of text, more than 65 536 non-empty tokens that match no pattern, a FEATURE with non-ASCII bytes under a grammar (ids and
+ * other columns may hold them), side-car cache runs with a separator of several bytes.
  *   bfk_table_prepare_device        results installed in the table like bfk_table_prepare's (group, weight, CSR of the unique
  *                                   rows; the filtered feature STRINGS stay with the host stage: BFK_ESTATE from their accessors)
  *   bfk_table_cluster_write_device  the CLI's whole middle: the unique rows are clustered where the collapse left them (no CSR

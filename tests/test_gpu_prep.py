@@ -196,7 +196,9 @@ def test_device_prepare_lists_invalid_tokens_and_declines_only_beyond_its_queue(
 def test_device_prepare_declines_what_it_does_not_restate():
     t = _lib.Table.from_lists(["a", "b"], ["A1T||C2G", "A1T"])
     with pytest.raises(_lib.Unsupported):
-        t.prepare_device("||", "raw", False, False, 0, 0, 0)
+        t.prepare_device("|" * 17, "raw", False, False, 0, 0, 0)  # (up to 16 bytes are folded: the tests below)
+    with pytest.raises(_lib.Unsupported):
+        t.prepare_device("|\n", "raw", False, False, 0, 0, 0)
     with pytest.raises(ValueError):
         t.prepare_device("", "raw", False, False, 0, 0, 0)
     t = _lib.Table.from_lists(["é", "b"], ["A1T C２G", "A1T"])  # non-ASCII under a grammar
@@ -204,11 +206,78 @@ def test_device_prepare_declines_what_it_does_not_restate():
         t.prepare_device(" ", "covsonar_dna", True, True, 0, 0, 29903)
     info = t.prepare_device(" ", "raw", True, True, 5, 5, 29903)
     assert info.n_unique == 2
+    # accents in the ids (or in other columns) are nobody's business: only a FEATURE with non-ASCII bytes goes to the mirror
+    ids, feats = ["é", "Köln-1", "b", "c"], ["A1T C2G bogus", "A1T C2G", "A1T  C2G", "A300T"]
+    assert_same(*both(ids, feats, " ", "covsonar_dna", (True, True, 0, 0, 29903)))
     t = _lib.Table.from_lists(["a"], ["A1T C2G"])
     t.prepare_device(" ", "covsonar_dna", True, True, 0, 0, 29903)
     with pytest.raises(_lib.BfkError) as ei:  # the filtered strings stay with the host stage
         t.feature(0)
     assert ei.value.code == -6
+
+
+@pytest.mark.parametrize("sep2", [", ", "::", " | ", "--", "ab", ";;;", "0123456789abcdef"])
+@pytest.mark.parametrize("var_type,opts", [("covsonar_dna", OPTS[0]), ("covsonar_aa", OPTS[1]), ("nextclade_dna", OPTS[0]), ("raw", OPTS[2]),
+                                           ("nextclade_aa", OPTS[0]), ("covsonar_dna", OPTS[-1])])
+def test_device_prepare_takes_token_separators_of_several_bytes(sep2, var_type, opts):
+    """--sep2 may be any string (breakfast.py:164, str.split): the device stage folds every occurrence — leftmost, never
+    overlapping, as str.split finds them — into a byte the table does not hold and gives what the host stage gives: groups,
+    CSR, counts, and the invalid tokens (empty ones among them) in the reference's order.  Separators that overlap themselves
+    ('::' in ':::', ' | ' in ' | | '), tokens that hold pieces of the separator, empty tokens in front, between and behind."""
+    rng = np.random.default_rng(zlib.crc32(repr((sep2, var_type, opts)).encode()))
+    toks = sorted({t for t in _fuzz_tokens(rng, 800) + _structured_tokens(rng, 800) if t})
+    piece = [sep2[:1], sep2[-1:], sep2[:-1], sep2[1:]]
+    feats = []
+    for _ in range(500):
+        k = int(rng.integers(0, 9))
+        row = [toks[int(rng.integers(0, len(toks)))] for _ in range(k)]
+        for _ in range(int(rng.integers(0, 3))):  # empty tokens, and tokens made of (or ending in) pieces of the separator
+            row.insert(int(rng.integers(0, len(row) + 1)), ["", "", piece[int(rng.integers(4))], toks[int(rng.integers(len(toks)))] + piece[0]][int(rng.integers(4))])
+        feats.append(sep2.join(row))
+    feats += ["", sep2, sep2 + sep2, sep2[:-1], sep2 + sep2[:1], toks[0] + sep2, sep2 + toks[1], feats[3], feats[4], feats[3]]
+    ids = [f"s{i}" for i in range(len(feats))]
+    th, ih, td, idv = both(ids, feats, sep2, var_type, opts)
+    assert_same(th, ih, td, idv)
+    assert ih.n_unique < len(feats)
+
+
+def test_device_prepare_finds_a_stand_in_byte_the_table_does_not_hold():
+    """the first candidates (0x1F, 0x1E, ...) occur in the features: the next free one is taken; with every candidate in the table
+    the device stage declines and the host stage takes the input"""
+    feats = ["A1T, C2G\x1f, G3A", "A1T, C2G\x1e", "A1T, C2G\x1f, G3A", ", \x1d"]
+    th, ih, td, idv = both(["a", "b", "c", "d"], feats, ", ", "raw", (False, False, 0, 0, 0))
+    assert_same(th, ih, td, idv)
+    assert ih.n_unique == 3
+    every = "".join(chr(b) for b in list(range(1, 9)) + [0x0B, 0x0C] + list(range(0x0E, 0x20)) + [0x7F])
+    th, ih, td, idv = both(["a", "b"], ["A1T, " + every, "C2G"], ", ", "raw", (False, False, 0, 0, 0))
+    assert td is None and ih.n_unique == 2
+
+
+def test_cli_with_a_token_separator_of_several_bytes_runs_the_device_stages(tmp_path, monkeypatch):
+    """--sep2 ', ' through fastpath.run: the device stages (the default) print and write what the host stages do"""
+    rows = synth.generate_profiles(20000, seed=11, p_del=0.05, p_ins=0.01)
+    lines = ["accession\tdna_profile"] + [f"q{i}\t" + ", ".join(r.split(" ")) for i, r in enumerate(rows)]
+    lines[50] += ", , notatoken, "
+    lines[9000] = "q8999\t, A300T,, C400G ,"
+    lines += ["e1\t", "d1\t" + lines[5].split("\t")[1]]
+    inp = tmp_path / "in.tsv"
+    inp.write_text("\n".join(lines) + "\n")
+
+    def run(outdir, device):
+        monkeypatch.setenv("BFK_DEVICE_PREP", "1" if device else "0")
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            ok = fastpath.run(inp, "\t", "accession", "dna_profile", "covsonar_dna", ", ", True, True, 264, 228, 29903, 1, 2, outdir)
+        assert ok
+        return buf.getvalue(), (outdir / "clusters.tsv").read_bytes()
+
+    out_d, tsv_d = run(tmp_path / "dev", True)
+    out_h, tsv_h = run(tmp_path / "host", False)
+    assert out_d == out_h and tsv_d == tsv_h
+    inv = [ln.split("'")[1] for ln in out_d.splitlines() if ln.startswith("Skipping invalid")]
+    assert "notatoken" in inv and "A300T," in inv and "C400G ," in inv and inv.count("") >= 4
+    td = _lib.Table.open(inp, "\t", "accession", "dna_profile")  # and the device stage did not decline
+    td.prepare_device(", ", "covsonar_dna", True, True, 264, 228, 29903)
 
 
 @pytest.mark.parametrize("max_dist,indels,opts", [(1, False, OPTS[0]), (3, True, OPTS[1]), (2, True, OPTS[0])])

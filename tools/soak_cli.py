@@ -1,6 +1,6 @@
 """Soak of the CLI's native paths in ONE process (development tooling): random tables — synthetic profiles with duplicates, stray and
 empty tokens, NA features, quoted / unquoted fields, CRLF or LF — under random feature types and filter options through
-fastpath.run on the device stages and on the host stages (same stdout, same clusters.tsv), and chains of side-car cache runs
+fastpath.run on the device stages and on the host stages (same stdout, same clusters.tsv), token separators of one and of several bytes, and chains of side-car cache runs
 (write, grow, lose rows, another max-dist) on the device stages against the list path.  The default context, the preload thread
 and the table machinery are reused from run to run: state that leaks from one run into the next shows here.
 usage (GPU box): python tools/soak_cli.py [seconds] [seed]"""
@@ -25,10 +25,11 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 tmp = Path(tempfile.mkdtemp(prefix="bfk_soak_cli_"))
 POOL = {"dna": generate_profiles(20000, seed=seed, p_del=0.05, p_ins=0.02), "aa": generate_family("aa", 6000, seed=seed + 1)}
+SEP2 = [" "]   # the token separator of the table in hand
 STRAY = ["bogus", "S:N501Y", "xyz!", "a12c", "del:x:1", "C241", "", "  "]
 
 
-def table(path, kind, n, quoting, crlf):
+def table(path, kind, n, quoting, crlf, sep2=" "):
     src = POOL[kind]
     a = int(rng.integers(0, len(src) - n))
     rows = list(src[a:a + n])
@@ -44,6 +45,8 @@ def table(path, kind, n, quoting, crlf):
         else:
             rows[i] = "NA"
     rows += [rows[int(i)] for i in rng.integers(0, n, size=int(rng.integers(0, n // 4 + 1)))]   # duplicates
+    if sep2 != " ":   # (NA stays a missing feature; a token separator of several bytes, or another byte)
+        rows = [r if r == "NA" else sep2.join(r.split(" ")) for r in rows]
     with open(path, "w", newline="") as f:
         w = csv.writer(f, delimiter="\t", quoting=quoting, lineterminator="\r\n" if crlf else "\n")
         w.writerow(["accession", "note", "dna_profile"])
@@ -60,7 +63,7 @@ def run(inp, outdir, env, **kw):
     err = None
     with redirect_stdout(buf):
         try:
-            ok = fastpath.run(inp, "\t", "accession", "dna_profile", kw["var_type"], " ", kw["skip_ins"], kw["skip_del"], kw["trim_start"],
+            ok = fastpath.run(inp, "\t", "accession", "dna_profile", kw["var_type"], SEP2[0], kw["skip_ins"], kw["skip_del"], kw["trim_start"],
                               kw["trim_end"], 29903, kw["d"], kw["mcs"], outdir, kw.get("input_cache"), kw.get("output_cache"))
         except ValueError as e:   # (an all-empty matrix: the reference raises too)
             ok, err = "raised", str(e)
@@ -80,7 +83,8 @@ while time.time() < t_end:
               d=int(rng.choice([1, 1, 1, 2, 3])), mcs=int(rng.choice([1, 2, 2, 3])))
     quoting = [csv.QUOTE_MINIMAL, csv.QUOTE_ALL][int(rng.integers(0, 2))]
     inp = tmp / f"in{n_runs}.tsv"
-    n = table(inp, kind, int(rng.integers(20, 6000)), quoting, bool(rng.integers(0, 2)))
+    SEP2[0] = " " if rng.random() < 0.6 else str(rng.choice([",", ", ", "; ", " | ", "||", "--", "  "]))   # (folded on the device when it has several bytes)
+    n = table(inp, kind, int(rng.integers(20, 6000)), quoting, bool(rng.integers(0, 2)), SEP2[0])
     a = run(inp, tmp / f"d{n_runs}", {"BFK_DEVICE_PREP": "1"}, **kw)
     b = run(inp, tmp / f"h{n_runs}", {"BFK_DEVICE_PREP": "0"}, **kw)
     assert a == b, ("device stages differ from host stages", n_runs, kw, n, a[:3], b[:3])
