@@ -244,6 +244,11 @@ struct PrepArgs {
     int *fail;                   // PREP_FAIL_*
 };
 // side-car cache: the two hashes of every unique row's feature string (k_row_hashes, bfk_text.hip)
+constexpr int SEP_MAX_BYTES = 16;  // longest token separator the device prepare folds (k_sepfold)
+struct SepPattern {
+    uint8_t b[SEP_MAX_BYTES];
+    int m;
+};
 struct RowHashArgs {
     const uint8_t *text;       // the prepare's text (blanked between the features), byte 0 = table byte `base`
     const long long *row_off;  // [n_rows] absolute offsets of the rows' features
@@ -251,17 +256,13 @@ struct RowHashArgs {
     const int *span_len;       // [n_rows]
     const int *first_row;      // [n_unique]
     int n_unique;
-    uint8_t sep;
+    uint8_t sep;               // the separator byte of the text (the stand-in, when the table's separator has several bytes)
+    SepPattern pat;            // the table's separator as the feature strings hold it: pat.m bytes (1: sep itself)
     TokFilter flt;
     unsigned long long *out;   // [2 n_unique]
 };
 int launch_row_hashes(const RowHashArgs &a, hipStream_t st);
 int launch_blank(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, uint32_t T, uint8_t sep, hipStream_t st);
-constexpr int SEP_MAX_BYTES = 16;  // longest token separator the device prepare folds (k_sepfold)
-struct SepPattern {
-    uint8_t b[SEP_MAX_BYTES];
-    int m;
-};
 int launch_sepfold(uint8_t *text, const long long *row_off, const int *span_len, int n, long long base, const SepPattern &pat,
                    uint8_t standin, int *seps, unsigned long long *total, hipStream_t st);
 int launch_collapse(const PrepArgs &a, hipStream_t st);

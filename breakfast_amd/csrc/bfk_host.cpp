@@ -1971,6 +1971,7 @@ struct PrepResult {
     bool filtering = false;
     int64_t base = 0;  // table byte of the device text's byte 0
     TokFilter flt{};   // the filter the tokeniser ran with
+    unsigned char sep_byte = 0;  // the separator byte of the device text (a stand-in when --sep2 has several bytes)
     // the "Skipping invalid feature" lines in the reference's order (rows in input order, tokens in row order): spans into the
     // table's bytes, length 0 for an empty token.  Empty when every invalid token is an empty one (n_invalid lines of '').
     std::vector<int64_t> inv_off;
@@ -2234,6 +2235,7 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     res->filtering = filtering;
     res->base = base;
     res->flt = tp.flt;
+    res->sep_byte = sp;
     return BFK_OK;
 }
 
@@ -2365,8 +2367,6 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
                                       bfk_prep_info *info_out, int64_t *n_clusters_out) {
     if (!info_out || !path || max_dist <= 0 || min_cluster_size < 0) return fail(BFK_EARG, "bfk_table_cluster_write_device: bad argument");
     if ((cache_path || in_cache) && n_gpus != 1) return fail(BFK_EARG, "bfk_table_cluster_write_device: side-car caches go with one device");
-    if ((cache_path || in_cache) && sep2_len != 1)  // (k_row_hashes re-joins the kept tokens with ONE byte: the list path takes these)
-        return fail(BFK_EUNSUPPORTED, "device stages: side-car caches with a token separator of several bytes");
     std::vector<uint64_t> cached;
     std::vector<int64_t> c_off, where;  // the cached lists (when the run continues the cache); the cached rows' places in this input
     std::vector<int32_t> c_flat;
@@ -2406,7 +2406,10 @@ static int table_cluster_write_device(bfk_table *t, const char *sep2, int64_t se
             ha.span_len = c->pr_spanlen;
             ha.first_row = c->pr_first;
             ha.n_unique = (int)r.n_unique;
-            ha.sep = (uint8_t)sep2[0];
+            ha.sep = (uint8_t)r.sep_byte;
+            ha.pat = SepPattern{};
+            ha.pat.m = (int)sep2_len;
+            memcpy(ha.pat.b, sep2, (size_t)sep2_len);
             ha.flt = r.flt;
             ha.out = (unsigned long long *)d_hash;
             hashes.resize((size_t)(2 * r.n_unique));

@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_row_hashes(RowHashArgs a) {
             uint32_t e = pos;
             while (e < L && bw.at(e) != a.sep) e++;
             if (e > pos && tok_classify(a.flt, e - pos, [&](uint32_t i) { return bw.at(pos + i); }) == TOKV_KEEP) {
-                n += (e - pos) + (kept++ ? 1u : 0u);
+                n += (e - pos) + (kept++ ? (uint32_t)a.pat.m : 0u);
                 if (k < 64) keep0 |= 1ull << k;
                 else if (k < 128) keep1 |= 1ull << (k - 64);
             }
@@ -1146,7 +1146,17 @@ __global__ __launch_bounds__(256) void k_row_hashes(RowHashArgs a) {
         }
     };
     if (!a.flt.on) {
-        for (uint32_t i = 0; i < L; i++) put(bw.at(i));
+        // (a separator of several bytes stands in the text as runs of the stand-in byte, k_sepfold: the string holds the separator)
+        for (uint32_t i = 0, run = 0; i < L; i++) {
+            const uint32_t c = bw.at(i);
+            if (a.pat.m > 1 && c == a.sep) {
+                put(a.pat.b[run]);
+                run = run + 1 == (uint32_t)a.pat.m ? 0u : run + 1;
+            } else {
+                put(c);
+                run = 0;
+            }
+        }
     } else {
         uint32_t kept = 0, k = 0;
         for (uint32_t pos = 0; pos < L; k++) {
@@ -1159,7 +1169,12 @@ __global__ __launch_bounds__(256) void k_row_hashes(RowHashArgs a) {
                 else keep = tok_classify(a.flt, e - pos, [&](uint32_t i) { return bw.at(pos + i); }) == TOKV_KEEP;
             }
             if (keep) {
-                if (kept++) put(a.sep);
+                if (kept++) {
+                    if (a.pat.m > 1)
+                        for (int j = 0; j < a.pat.m; j++) put(a.pat.b[j]);
+                    else
+                        put(a.sep);
+                }
                 for (uint32_t i = pos; i < e; i++) put(bw.at(i));
             }
             pos = e + 1;

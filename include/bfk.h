@@ -364,7 +364,7 @@ int bfk_table_cluster_write(const bfk_table *t, int32_t max_dist, int32_t min_cl
  * does not hold (k_sepfold: leftmost, non-overlapping matches per row), the stages run with that byte.
  * BFK_EUNSUPPORTED — nothing done, the host stage takes the input — for: token separators of over 16 bytes or with a line break,
  * 4 GiB of text, more than 65 536 non-empty tokens that match no pattern, a FEATURE with non-ASCII bytes under a grammar (ids and
- * other columns may hold them), side-car cache runs with a separator of several bytes.
+ * other columns may hold them).
  *   bfk_table_prepare_device        results installed in the table like bfk_table_prepare's (group, weight, CSR of the unique
  *                                   rows; the filtered feature STRINGS stay with the host stage: BFK_ESTATE from their accessors)
  *   bfk_table_cluster_write_device  the CLI's whole middle: the unique rows are clustered where the collapse left them (no CSR

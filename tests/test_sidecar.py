@@ -206,8 +206,10 @@ def _synth_tsv(path, rows, ids=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var_type,filt,d", [("covsonar_dna", True, 1), ("covsonar_dna", True, 2), ("covsonar_dna", False, 1), ("raw", True, 1)])
-def test_device_written_sidecar_holds_the_host_stage_hashes_and_the_lists_of_all_rows(var_type, filt, d, tmp_path):
+@pytest.mark.parametrize("var_type,filt,d,sep2", [("covsonar_dna", True, 1, " "), ("covsonar_dna", True, 2, " "), ("covsonar_dna", False, 1, " "),
+                                                  ("raw", True, 1, " "), ("covsonar_dna", True, 1, ", "), ("covsonar_dna", False, 1, "::"),
+                                                  ("raw", True, 2, " | ")])
+def test_device_written_sidecar_holds_the_host_stage_hashes_and_the_lists_of_all_rows(var_type, filt, d, sep2, tmp_path):
     """bfk_table_cluster_write_device_cache: the two hashes of every unique row's feature string come from the device
     (k_row_hashes: kept tokens re-joined, or the raw bytes when nothing is filtered) and equal bfk_table_feature_hashes of the
     host stage; the lists are bfk_neighbours_csr's for all rows; the file is marked exact; clusters.tsv is the plain run's"""
@@ -218,9 +220,11 @@ def test_device_written_sidecar_holds_the_host_stage_hashes_and_the_lists_of_all
     rows[8] = "  " + rows[8] + "  C241T"   # empty tokens, a token the trim drops
     rows[9] = ""
     rows += rows[100:400]
+    if sep2 != " ":   # (a separator of several bytes: folded on the device, the hashes are those of the strings that hold it)
+        rows = [sep2.join(r.split(" ")) for r in rows]
     inp = tmp_path / "in.tsv"
     _synth_tsv(inp, rows)
-    opts = (" ", var_type, filt, filt, 264 if filt else 0, 228 if filt else 0, 29903)
+    opts = (sep2, var_type, filt, filt, 264 if filt else 0, 228 if filt else 0, 29903)
     t = _lib.Table.open(inp, "\t", "accession", "dna_profile")
     info, k = t.cluster_write_device(*opts, d, 2, tmp_path / "dev.tsv", cache_path=tmp_path / "c.bfkc")
     t.close()
