@@ -124,9 +124,9 @@ def cluster(meta_nodups, sep2, max_dist, min_cluster_size, input_cache, output_c
 def _feature_csr(features, feature_sep):
     """sparse_feature_matrix's CSR (breakfast.py:193-215): tokenised on the GPU (bfk_build_csr_device) when there is one; the
     host tokeniser of the same library (bfk_build_csr — same contract, same CSR) takes what the device path declines
-    (multi-byte separators, 4 GiB of text) and the GPU-less callers of this function (the shell tests, the cache tools)."""
+    (separators of over 16 bytes, 4 GiB of text) and the GPU-less callers of this function (the shell tests, the cache tools)."""
     features = list(features)
-    if _lib.load().bfk_device_count() > 0 and len(feature_sep.encode()) == 1:
+    if _lib.load().bfk_device_count() > 0 and len(feature_sep) > 0:
         try:
             return _lib.build_csr_device(features, feature_sep)
         except _lib.Unsupported:

@@ -833,6 +833,28 @@ static int ctx_text_events(bfk_ctx *c) {
     return BFK_OK;
 }
 
+// A token separator of several bytes (breakfast.py:164, :204: str.split takes any string) is folded on the device into runs of ONE
+// byte that the text does not hold (k_sepfold), and the kernels run with that byte.  -> the separator's pattern and the stand-in
+// (control characters first: a table of profiles holds none of them), or BFK_EUNSUPPORTED.
+static int sep_stand_in(const char *sep, int64_t sep_len, const char *text, int64_t T, SepPattern *pat, unsigned char *stand_in) {
+    if (sep_len > SEP_MAX_BYTES) return fail(BFK_EUNSUPPORTED, "device stages: token separator of more than 16 bytes");
+    for (int64_t i = 0; i < sep_len; i++) {
+        const unsigned char b = (unsigned char)sep[i];
+        if (b >= 0x80 || b == '\n' || b == '\r' || b == 0) return fail(BFK_EUNSUPPORTED, "device stages: token separator");
+    }
+    *pat = SepPattern{};
+    pat->m = (int)sep_len;
+    memcpy(pat->b, sep, (size_t)sep_len);
+    static const unsigned char cand[] = {0x1F, 0x1E, 0x1D, 0x1C, 0x1B, 0x1A, 0x19, 0x18, 0x17, 0x16, 0x15, 0x14, 0x13, 0x12, 0x11, 0x10,
+                                         0x0F, 0x0E, 0x0C, 0x0B, 0x08, 0x07, 0x06, 0x05, 0x04, 0x03, 0x02, 0x01, 0x7F};
+    for (unsigned char b : cand)
+        if (T <= 0 || !memchr(text, b, (size_t)T)) {
+            *stand_in = b;
+            return BFK_OK;
+        }
+    return fail(BFK_EUNSUPPORTED, "device stages: no free byte to stand for the token separator");
+}
+
 static int ctx_check_text_args(const int64_t n_rows, const char *sep, int64_t sep_len, int64_t T) {
     if (n_rows < 0) return fail(BFK_EARG, "bfk_ctx_build_csr: negative n_rows");
     if (!sep || sep_len <= 0) return fail(BFK_EARG, "empty separator");
@@ -851,8 +873,15 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
                           bool *spec_done = nullptr) {
     if (!row_off) return fail(BFK_EARG, "bfk_ctx_build_csr: null argument");
     const int64_t base = n_rows >= 0 ? row_off[0] : 0, T = n_rows >= 0 ? row_off[n_rows] - base : -1;
-    if (int rc = ctx_check_text_args(n_rows, sep, sep_len, T)) return rc;
     if (T > 0 && !buf) return fail(BFK_EARG, "bfk_ctx_build_csr: null text");
+    SepPattern pat{};
+    unsigned char sp = sep && sep_len > 0 ? (unsigned char)sep[0] : 0;
+    if (sep && sep_len > 1 && n_rows >= 0 && T >= 0 && T <= (int64_t)0xFFF00000ll)  // (several bytes: folded below)
+        if (int rc = sep_stand_in(sep, sep_len, buf + base, T, &pat, &sp)) return rc;
+    {
+        const char one = (char)sp;
+        if (int rc = ctx_check_text_args(n_rows, sep_len > 1 ? &one : sep, sep_len > 1 ? 1 : sep_len, T)) return rc;
+    }
     if (int rc = ctx_settle(c)) return rc;  // (the tokeniser is about to write this context's CSR)
     const int64_t T_pad = round_up(T + 1, TOK_PAD_BYTES);
     if (int rc = dev_realloc(&c->tk_text, &c->tk_text_cap, T_pad + TOK_TEXT_SLACK, 1.05)) return rc;
@@ -868,7 +897,7 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
     int n_pieces = 1;
     unsigned piece_blk[bfk_ctx::TK_PIECES + 1] = {0};
     const int64_t scan_blocks = T_pad / TOK_PAD_BYTES;
-    if (!c->profiling && T >= ((int64_t)8 << 20) && getenv("BFK_TOK_PIECES") && atoi(getenv("BFK_TOK_PIECES")) >= 2) {
+    if (!c->profiling && sep_len == 1 && T >= ((int64_t)8 << 20) && getenv("BFK_TOK_PIECES") && atoi(getenv("BFK_TOK_PIECES")) >= 2) {
         n_pieces = std::min((int)bfk_ctx::TK_PIECES, atoi(getenv("BFK_TOK_PIECES")));
         for (int k = 0; k <= n_pieces; k++)  // boundaries at multiples of 4 scan blocks (256 KiB: 16-byte pieces of blkbase)
             piece_blk[k] = k == n_pieces ? (unsigned)scan_blocks : (unsigned)(scan_blocks * k / n_pieces / 4 * 4);
@@ -904,13 +933,16 @@ static int ctx_build_text(bfk_ctx *c, const char *buf, const int64_t *row_off, i
         }
     }
     if (ev) HIP_TRY(hipEventRecord(ev[5], c->stream));
+    if (sep_len > 1 && n_rows > 0)
+        if (int e = launch_sepfold(c->tk_text, c->tk_rowoff, nullptr, (int)n_rows, base, pat, (uint8_t)sp, nullptr, nullptr, c->stream))
+            return fail(BFK_EHIP, std::string("k_sepfold launch: ") + hipGetErrorString((hipError_t)e));
     bfk_ctx::TokPlan tp;
     tp.d_text = c->tk_text;
     tp.d_rowoff = c->tk_rowoff;
     tp.base = base;
     tp.T = T;
     tp.n_rows = n_rows;
-    tp.sep = sep[0];
+    tp.sep = (char)sp;
     tp.strict = false;
     tp.n_pieces = n_pieces;
     memcpy(tp.piece_blk, piece_blk, sizeof tp.piece_blk);
@@ -1985,7 +2017,6 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     if (!t || !sep2 || !opts || !res) return fail(BFK_EARG, "device prepare: null argument");
     if (sep2_len <= 0) return fail(BFK_EARG, "empty separator");
     if (opts->var_type < BFK_VAR_COVSONAR_DNA || opts->var_type > BFK_VAR_RAW) return fail(BFK_EARG, "device prepare: unknown var_type");
-    if (sep2_len > SEP_MAX_BYTES) return fail(BFK_EUNSUPPORTED, "device prepare: token separator of more than 16 bytes");
     for (int64_t i = 0; i < sep2_len; i++) {
         const unsigned char b = (unsigned char)sep2[i];
         if (b >= 0x80 || b == '\n' || b == '\r' || b == 0) return fail(BFK_EUNSUPPORTED, "device prepare: token separator");
@@ -2009,20 +2040,9 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     };
     auto span = [&](int64_t r) { return *(const SpanView *)((const char *)spans + (size_t)r * (size_t)stride); };
     const int64_t base = span(0).off, T = n_bytes - base;
-    // A token separator of several bytes (breakfast.py:164: str.split takes any string) is folded on the device into runs of ONE
-    // byte that the table does not hold (k_sepfold), and the stages below run with that byte.  Control characters first: a TSV of
-    // profiles holds none of them.
-    if (sep2_len > 1) {
-        static const unsigned char cand[] = {0x1F, 0x1E, 0x1D, 0x1C, 0x1B, 0x1A, 0x19, 0x18, 0x17, 0x16, 0x15, 0x14, 0x13, 0x12, 0x11, 0x10,
-                                             0x0F, 0x0E, 0x0C, 0x0B, 0x08, 0x07, 0x06, 0x05, 0x04, 0x03, 0x02, 0x01, 0x7F};
-        sp = 0;
-        for (unsigned char b : cand)
-            if (!memchr(bytes + base, b, (size_t)T)) {
-                sp = b;
-                break;
-            }
-        if (!sp) return fail(BFK_EUNSUPPORTED, "device prepare: no free byte to stand for the token separator");
-    }
+    SepPattern pat{};
+    if (sep2_len > 1)  // (several bytes: folded on the device, the stages below run with the stand-in byte)
+        if (int rc = sep_stand_in(sep2, sep2_len, bytes + base, T, &pat, &sp)) return rc;
     {
         const char one = (char)sp;
         if (int rc = ctx_check_text_args(n, &one, 1, T)) return rc;
@@ -2080,9 +2100,6 @@ static int ctx_prepare_table(bfk_ctx *c, const bfk_table *t, const char *sep2, i
     tm.lap("prepare: H2D", c->stream);
     const int64_t sep_extra = sep2_len - 1;  // empty tokens every folded separator adds to the device's counts
     if (sep2_len > 1) {
-        SepPattern pat{};
-        pat.m = (int)sep2_len;
-        memcpy(pat.b, sep2, (size_t)sep2_len);
         HIP_TRY(hipMemsetAsync(c->pr_small, 0, 64, c->stream));
         // (occurrences per row into pr_rep, which the collapse only fills further down; their sum into the words behind the
         // collapse's totals)

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_blank(uint8_t *text, const long long *_
 // does not hold: the tokeniser then runs with that one byte as its separator.  Offsets stay what they are (the host prints a
 // token from its own image of the table by offset and length), rows that differ still differ (no row holds the stand-in, so the
 // runs of it say where the separators were), and an occurrence leaves m - 1 empty tokens that are not the reference's: seps[r]
-// = occurrences in row r, *total = their sum — the host takes (m - 1) x these off the empty-token counts.
+// = occurrences in row r, *total = their sum — the host takes (m - 1) x these off the empty-token counts (both NULL where nobody
+// counts empty tokens: sparse_feature_matrix skips them, :208-209).
 __global__ __launch_bounds__(256) void k_sepfold(uint8_t *text, const long long *__restrict__ row_off, const int *__restrict__ span_len, int n,
                                                  long long base, SepPattern pat, uint8_t standin, int *__restrict__ seps,
                                                  unsigned long long *total) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_sepfold(uint8_t *text, const long long 
     unsigned cnt = 0;
     if (r < n) {
         uint8_t *t = text + (size_t)(row_off[r] - base);
-        const int len = span_len[r], m = pat.m;
+        const int len = span_len ? span_len[r] : (int)(row_off[r + 1] - row_off[r]), m = pat.m;  // (no spans: the rows abut)
         for (int k = 0; k + m <= len;) {
             bool eq = t[k] == pat.b[0];
             for (int j = 1; eq && j < m; j++) eq = t[k + j] == pat.b[j];
@@ -90,8 +91,9 @@ __global__ __launch_bounds__(256) void k_sepfold(uint8_t *text, const long long 
                 k++;
             }
         }
-        seps[r] = (int)cnt;
+        if (seps) seps[r] = (int)cnt;
     }
+    if (!total) return;  // (kernel argument: the whole grid leaves)
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long)cnt);
 }

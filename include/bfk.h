@@ -96,8 +96,12 @@ int bfk_build_csr(const char *buf, const int64_t *row_off, int64_t n_rows, const
 
 /* The same contract computed ON THE DEVICE (bfk_text.hip: separator scan, vocabulary table keyed by hash + length + bytes
  * with atomicMin on the first byte offset, first-appearance ids by a prefix sum over the first occurrences), host outputs:
- * indptr / indices / n_vocab identical to bfk_build_csr's and to the reference's CSR.  One-byte separators, text below
- * 4 GiB, tokens below 64 KiB; anything else -> BFK_EUNSUPPORTED and nothing done (bfk_build_csr takes those).           */
+ * indptr / indices / n_vocab identical to bfk_build_csr's and to the reference's CSR.  A separator of several bytes (up to 16;
+ * str.split takes any string, breakfast.py:204) is folded in the device copy of the text — every occurrence, leftmost and
+ * never overlapping, never across a row boundary, becomes a run of a byte the text does not hold (k_sepfold) — and the kernels
+ * run with that byte.  Text below 4 GiB, tokens below 64 KiB; anything else (a separator of over 16 bytes, a text that holds
+ * every stand-in byte) -> BFK_EUNSUPPORTED and nothing done (bfk_build_csr takes those).  The entries that read text from the
+ * CALLER's device memory (bfk_ctx_build_csr_device, bfk_ctx_cluster_text_device) do not write to it: one-byte separators there. */
 int bfk_build_csr_device(const char *buf, const int64_t *row_off, int64_t n_rows, const char *sep, int64_t sep_len,
                          int32_t *indptr_out, int32_t **indices_out, int64_t *nnz_out, int32_t *n_vocab_out);
 

@@ -25,9 +25,7 @@ def _same(got, want):
 
 @pytest.mark.parametrize("name", stage_names())
 def test_device_csr_matches_reference_golden(name):
-    g = load_stage(name)
-    if len(g["sep"]) != 1:
-        pytest.skip("multi-byte separator: host tokeniser")
+    g = load_stage(name)   # (a separator of several bytes is folded on the device: k_sepfold)
     _same(_lib.build_csr_device(g["ufeatures"], g["sep"]), (g["indptr"], g["indices"], g["n_vocab"]))
     # the raw (uncollapsed) feature column too: duplicates rows, other first appearances
     want = orc.sparse_feature_matrix(g["features"], g["sep"])
@@ -36,7 +34,7 @@ def test_device_csr_matches_reference_golden(name):
 
 def test_device_csr_kats(kats):
     for c in kats["cluster"]:
-        if "error" in c or len(c["sep"]) != 1:
+        if "error" in c or len(c["sep"]) < 1:
             continue
         uf = list(dict.fromkeys(c["features"]))
         indptr, indices, _ = _lib.build_csr_device(uf, c["sep"])
@@ -53,8 +51,23 @@ def test_device_csr_edge_cases():
     assert indptr.tolist() == [0, 0, 0, 0] and len(indices) == 0 and nv == 0
     indptr, indices, nv = _lib.build_csr_device(["a|b||||a", float("nan"), "||", "|a"], "|")
     assert indptr.tolist() == [0, 3, 3, 3, 4] and indices.tolist() == [0, 1, 0, 0] and nv == 2
-    with pytest.raises(_lib.Unsupported):  # multi-byte separators are the host tokeniser's
-        _lib.build_csr_device(["a||b"], "||")
+    # separators of several bytes (str.split takes any string, breakfast.py:204): folded on the device, leftmost matches, never
+    # across a row boundary; over 16 bytes, or with every stand-in byte in the text: the host tokeniser's
+    for sep, rows in (("||", ["a||b", "|||a", "a|", "|b||", "", "||||", "b|||"]), (", ", ["A, B,C , ", ", ,", "A,  B", " ,A"]),
+                      ("aba", ["xabababay", "aba", "abaaba", "ab", "a"]), ("0123456789abcdef", ["x0123456789abcdefy0123456789abcde"])):
+        _same(_lib.build_csr_device(rows, sep), orc.sparse_feature_matrix(rows, sep))
+    rng = np.random.default_rng(12)
+    for sep in ("::", " | ", "--", ", "):
+        alphabet = ["A1T", "C22G", ":", "-", "|", " ", ",", "del:5:1", "S:N501Y", "x" * 9]
+        rows = [sep.join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), int(rng.integers(0, 12)))) for _ in range(3000)]
+        _same(_lib.build_csr_device(rows, sep), orc.sparse_feature_matrix(rows, sep))
+        lab, _, nnz, nv = _lib.cluster_text(*_lib.pack_rows(rows), sep, 1, want_stats=False)
+        want = orc.sparse_feature_matrix(rows, sep)
+        assert nnz == len(want[1]) and np.array_equal(lab[:len(rows)], orc.cluster_csr(want[0], want[1], 1, n_threads=ORACLE_THREADS)["labels"])
+    with pytest.raises(_lib.Unsupported):
+        _lib.build_csr_device(["a||b"], "|" * 17)
+    with pytest.raises(_lib.Unsupported):
+        _lib.build_csr_device(["a||b" + "".join(chr(b) for b in list(range(1, 9)) + [0x0B, 0x0C] + list(range(0x0E, 0x20)) + [0x7F])], "||")
     with pytest.raises(ValueError):
         _lib.build_csr_device(["a b"], "")
     # rows that abut without a separator: the row boundary ends a token ("ab" + "cd" are two tokens, not "abcd")
