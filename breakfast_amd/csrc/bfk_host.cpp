@@ -726,12 +726,27 @@ static int ctx_enqueue(bfk_ctx *c, int32_t max_dist, int32_t shard, int32_t n_sh
 // counters k_maxlen leaves in device memory (JoinArgs::dyn), their grids are sized by the most tokens the text can hold, and
 // they assume what nearly every profile input satisfies — no row longer than JOIN_INLINE_ROW tokens (k_join then decides every
 // match itself: no k_verify launch) and at least one token.  An input outside that flags it and is redone by ctx_spec_finish.
+// max-dist 1: the variant join or the band kernels.  ms per step on a bound CSR, fitted on the default generator (20k .. 1M rows,
+// ~43 tokens per row) and on rows of ~105 tokens (30k .. 400k rows: profiles/r05_long_crossover.txt) — the join looks every TOKEN
+// up (and its table outgrows the L2s with the rows), the band kernels' pair work goes with the ROWS:
+//     join 0.019 + 0.00525 nnz/1M + 0.176 n/1M        band 0.03 + 0.41 n/1M
+// (long rows, join / band measured: 50k 0.057 / 0.060, 70k 0.072 / 0.068, 100k 0.097 / 0.081, 200k 0.175 / 0.127, 400k 0.321 / 0.202;
+// default: 100k 0.053 / 0.067, 1M 0.42 / 0.45.)  The join keeps a 10 % margin: hubs do not hurt it, and they hurt the band
+// kernels' tiles a lot (a star phylogeny at 1M rows: 0.45 / 1.45).
+static bool join_pays(int64_t n, int64_t nnz) {
+    const double nM = (double)n * 1e-6, zM = (double)nnz * 1e-6;
+    return 0.019 + 0.00525 * zM + 0.176 * nM <= 1.1 * (0.03 + 0.41 * nM);
+}
+
 static bool spec_wanted(const bfk_ctx *c, int64_t n_rows, int64_t T, int32_t max_dist) {
     if (const char *e = getenv("BFK_SPEC")) if (atoi(e) == 0) return false;
     if (const char *e = getenv("BFK_JOIN")) if (atoi(e) == 0) return false;
     if (getenv("BFK_JOIN_INLINE") || getenv("BFK_JOIN_DEBUG")) return false;
     if (max_dist != 1 || n_rows < 1 || n_rows > 800000 || c->edge_capture) return false;
     if (c->path_mode != 0 && c->path_mode != 2) return false;
+    // (long rows — the text says so before it is tokenised: a token is ~8 bytes with its separator — are the band kernels': the
+    // step waits once for its counters and join_wanted decides on the real count)
+    if (c->path_mode == 0 && !join_pays(n_rows, T / 8)) return false;
     return T / 2 + n_rows + 1 < ((int64_t)1 << 30);
 }
 
@@ -1084,10 +1099,14 @@ static bool join_wanted(const bfk_ctx *c, int max_dist) {
     // amino-acid tokens 0.511 / 0.486, rows of ~110 tokens 1.04 / 0.59 (the join's lookups are per token), a star phylogeny
     // 0.51 / 1.47 (the hubs' neighbours fill a few cells of the band kernels' sort key: tiles of thousands of rows).  Hence the
     // join beyond 800k rows too while rows are short — it never loses much there and is the one the hubs do not hurt.
-    if (c->n <= 800000) return true;
+    // (a device-driven text step has decided already — spec_wanted, on the text's size: what the context holds as nnz while the
+    // step is being enqueued is the most tokens the text can hold, not a count)
+    if (c->spec_enqueueing) return true;
+    // Round 5: rows of ~105 tokens turn to the band kernels from ~60k rows on (0.097 / 0.081 at 100k, 0.321 / 0.202 at 400k): the
+    // fixed "800k rows" became join_pays' two lines (above).
     // (with the filter bitmap capped at 2 MB the join stays ahead of the band kernels up to 2M short rows — 1.5M: 0.702 / 0.726 ms,
     // 2M: 0.957 / 0.997; beyond, 8 bits per row no longer fit the cap)
-    return c->n <= 2000000 && c->nnz <= 64 * c->n;
+    return c->n <= 2000000 && join_pays(c->n, c->nnz);
 }
 
 static int ctx_size_join(bfk_ctx *c) {

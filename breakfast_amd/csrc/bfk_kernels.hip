@@ -17,7 +17,7 @@
 //                lock-free union-find hooks of the verified edges (one edge per lane);
 //                k_verify_long for pairs > 192 tokens
 //   k_flatten    labels[i] = root(i) = smallest row index of the component
-//   max_dist == 1 (up to 800k rows; up to 2M while rows average at most 64 tokens: join_wanted in bfk_host.cpp) replaces
+//   max_dist == 1 (up to 2M rows while join_pays says so — short rows always, rows of ~105 tokens up to ~60k: join_wanted in bfk_host.cpp) replaces
 //                k_sig .. k_verify by the VARIANT JOIN: k_jhash (additive multiset hash
 //                of every row -> hash table + bitmap), k_join (one lookup per token occurrence: H(B) - h(t); matches
 //                certified by a 64-lane compare and hooked at once; what the compare cannot decide: counted exactly by

@@ -153,7 +153,7 @@ int bfk_ctx_set_stream(bfk_ctx *ctx, void *hip_stream);   /* NULL = the ctx's ow
 int bfk_ctx_set_profiling(bfk_ctx *ctx, int32_t enable);  /* record HIP events between phases */
 
 /* which candidate generator bfk_ctx_cluster uses: 0 = automatic (the default: variant join at max_dist 1 up to
- * 800k rows, up to 2M while rows average at most 64 tokens; prefix groups at max_dist 2..7 from the row counts of PG_MIN_ROWS() in bfk_host.cpp — the one place that
+ * 2M rows while join_pays() in bfk_host.cpp says so (rows of ~105 tokens turn to the band kernels from ~60k rows on, rows of ~43 never); prefix groups at max_dist 2..7 from the row counts of PG_MIN_ROWS() in bfk_host.cpp — the one place that
  * states them: 200k rows at max_dist 2 (more where the rows are longer than 50 tokens on average), 10k at 3, 4k at 4,
  * 2.5k at 5..7; the all-pairs band kernels otherwise and for
  * the shards of a multi-device max_dist 2 step), 1 = always the band kernels, 2 = the variant join wherever it

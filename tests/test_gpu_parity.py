@@ -956,6 +956,32 @@ def oracle_labels_indel(n, d):
     return _ORACLE_LABELS[(n, d)]
 
 
+def test_max_dist_1_long_rows_turn_to_the_band_kernels_where_the_join_stops_paying():
+    """join_pays (bfk_host.cpp): the join's look-ups go with the tokens, the band kernels' pair work with the rows — rows of ~105
+    tokens take the band kernels from ~60k rows on (by CSR, and by text: the step's text says 'long rows' before it is tokenised and
+    the step waits once), rows of ~40 tokens stay on the join; every choice gives the labels of the forced generators"""
+    from breakfast_amd.synth import generate_family
+
+    for family, n, want_path in (("long", 90000, 0), ("long", 30000, 1), ("default", 90000, 1)):
+        uf = list(dict.fromkeys(generate_family(family, n) if family != "default" else generate_profiles(n)))
+        indptr, indices, _ = _lib.build_csr(uf, " ")
+        got = {}
+        for path in ("auto", "join", "allpairs"):
+            ctx = _lib.Context(0)
+            ctx.set_candidate_path(path)
+            ctx.upload_csr(indptr, indices)
+            d_out = ctx.alloc(4 * len(uf))
+            ctx.cluster(1, d_out)
+            st = ctx.sync()
+            got[path] = ctx.download_i32(d_out, len(uf)).copy()
+            if path == "auto":
+                assert st["path"] == want_path, (family, n, st["path"])
+            ctx.close()
+        assert np.array_equal(got["auto"], got["join"]) and np.array_equal(got["auto"], got["allpairs"]), (family, n)
+        lab_t, st_t, nnz, _ = _lib.cluster_text(*_lib.pack_rows(uf), " ", 1)
+        assert nnz == len(indices) and np.array_equal(lab_t, got["auto"]) and st_t["path"] == want_path, (family, n)
+
+
 @pytest.mark.parametrize("family,d", [("long", 1), ("long", 3), ("star", 1), ("star", 2), ("star", 5), ("aa", 1), ("aa", 3)])
 def test_other_workload_families_equal_the_oracle_at_20k_rows(family, d):
     """workload shapes the dispatch thresholds were not fitted on (breakfast_amd/synth.py: generate_family — rows of 100+

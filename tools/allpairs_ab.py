@@ -16,7 +16,8 @@ from breakfast_amd import _lib, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-rows = list(dict.fromkeys(synth.generate_profiles(n)))
+fam = os.environ.get("AB_FAMILY", "default")   # default | long | star | aa (synth.generate_family)
+rows = list(dict.fromkeys(synth.generate_profiles(n) if fam == "default" else synth.generate_family(fam, n)))
 indptr, indices, _ = _lib.build_csr(rows, " ")
 nu = len(indptr) - 1
 ctx = _lib.Context(0)
@@ -49,5 +50,5 @@ for _ in range(16):
 lab = ctx.download_i32(d_out, nu)
 keys = ("ms_prep", "ms_prefilter", "ms_verify", "ms_flatten")
 med = {k: round(sorted(p[k] for p in ph)[8], 4) for k in keys if k in ph[0]}
-print(f"{nu} rows d={d}: ms/step min {min(best):.4f} median {sorted(best)[2]:.4f} | phases {med} | candidates {ph[-1]['n_candidates']} "
+print(f"{fam} {os.environ.get('AB_PATH', 'allpairs')} {nu} rows k_mean {np.diff(indptr).mean():.1f} d={d}: ms/step min {min(best):.4f} median {sorted(best)[2]:.4f} | phases {med} | candidates {ph[-1]['n_candidates']} "
       f"edges {ph[-1]['n_edges']} tiles {ph[-1]['n_work_items']} | labels crc {zlib.crc32(lab.tobytes()):08x}")
