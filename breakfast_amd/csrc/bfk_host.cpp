@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1175,9 +1176,20 @@ static int ctx_size_join(bfk_ctx *c) {
 // the groups' prep reads every token, the band's pair kernel does not care how long the rows are: the crossover moves up
 // with the mean row length (the star family — the band's queue takes ten times the candidates — would want the groups at
 // every size: known only after a step, not used)
+// round 5 (tools/allpairs_ab.py, profiles/r05_long_d3.txt), rows of ~105 tokens, band / prefix groups:
+//   rows    d = 3            d = 4
+//   20k     0.191 / 0.238
+//   50k     0.223 / 0.275    0.316 / 0.289
+//   100k    0.350 / 0.412    0.453 / 0.432
+//   200k    0.595 / 0.580    0.796 / 0.594
+//   400k    1.143 / 0.875
+// at max-dist 3 the crossover sits at ~10k rows of 43 tokens and at ~180k rows of 105: it moves with about the cube of the mean
+// row length (the groups' prep and walk read every token, the band's pair kernel does not care how long the rows are); from
+// max-dist 4 on the band scan grows so steeply that the groups win at every size measured.
 static int64_t PG_MIN_ROWS(int max_dist, int64_t n, int64_t nnz) {
-    if (max_dist >= 3) return max_dist >= 5 ? 2500 : (max_dist == 4 ? 4000 : 10000);
     const int64_t mean_len = n > 0 ? nnz / n : 0;
+    if (max_dist == 3) return (int64_t)(10000.0 * std::pow((double)std::max<int64_t>(44, mean_len) / 44.0, 3.3));
+    if (max_dist >= 3) return max_dist >= 5 ? 2500 : 4000;
     return 200000 * std::max<int64_t>(50, mean_len) / 50;
 }
 
