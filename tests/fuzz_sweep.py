@@ -24,7 +24,7 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(770000 + seed)
     # 1. text -> CSR, and text -> labels
-    sep = [" ", ",", ";", "\t", "|", "-"][seed % 6]
+    sep = [" ", ",", ";", "\t", "|", "-", ", ", "--", "A1", " | ", "::"][seed % 11]   # (several bytes: folded on the device, k_sepfold)
     na = int(rng.choice([5, 50, 500, 5000]))
     alphabet = [f"{chr(65 + int(a))}{int(p)}{chr(65 + int(b))}" * int(rng.integers(1, 3)) for a, p, b in
                 zip(rng.integers(0, 26, na), rng.integers(1, 30000, na), rng.integers(0, 26, na))]
@@ -71,11 +71,12 @@ for seed in range(first, first + count):
     badt = host_invalid_tokens(toks, var_type, opts) if filtering else set()
     good = [t for t in toks if t not in badt]
     if good:
-        feats = [" ".join(good[int(rng.integers(len(good)))] for _ in range(int(rng.integers(0, 12)))) for _ in range(int(rng.integers(1, 1500)))]
-        feats += feats[: len(feats) // 3] + ["", " ", "  "]
+        sep2 = [" ", " ", ", ", "::", " | ", ";;"][seed % 6]   # (tokens may hold pieces of the separator: both stages split the same string)
+        feats = [sep2.join(good[int(rng.integers(len(good)))] for _ in range(int(rng.integers(0, 12)))) for _ in range(int(rng.integers(1, 1500)))]
+        feats += feats[: len(feats) // 3] + ["", sep2, sep2 + sep2, sep2[:1]]
         rng.shuffle(feats)
         try:
-            assert_same(*both([f"s{i}" for i in range(len(feats))], feats, " ", var_type, opts))
+            assert_same(*both([f"s{i}" for i in range(len(feats))], feats, sep2, var_type, opts))
         except AssertionError as e:
             print("PREPARE MISMATCH seed", seed, var_type, opts, str(e)[:200])
             bad += 1
